@@ -1,0 +1,182 @@
+/*
+ * repconc_hip.h — C ABI of librepconc_hip.so, the MI355X (gfx950) implementation of the
+ * RepCONC product-quantisation hot path.
+ *
+ * The reference (jingtaozhan/RepCONC) is pure Python: the "plugin interface" of this path is
+ * the Python surface of `repconc.models.repconc`.  This header is the C-level
+ * boundary a maintainer binds with ctypes from those Python functions (INTEGRATION.md shows the
+ * stubs).  Each entry point names the reference lines it replaces; paths are relative to
+ * /root/reference/src/repconc/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the handle's HIP device unless suffixed `_host`;
+ *   - the caller allocates every buffer (sizes given below / by the *_bytes helpers);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); functions only
+ *     ENQUEUE work on it and return, they never synchronise;
+ *   - return value: RC_OK (0) or a negative RC_E* code, never throws; rc_error_string() decodes;
+ *   - no global mutable state outside the handle; handles are independent and re-entrant;
+ *   - K (centroids per sub-quantiser) must be 256 (evaluate_repconc.py:80, run_warmup.py:90);
+ *     dsub = D/M must be one of 8,12,16,24,32,48,64,96 (the sizes for which the fp32
+ *     summation order of the torch-CPU oracle is pinned);
+ *   - fp32 arithmetic follows the reference bit for bit (no FMA contraction, IEEE division);
+ *     the fp64 Sinkhorn stage is evaluated with potentials and is specified
+ *     on its OUTPUT, the codes.
+ */
+#ifndef REPCONC_HIP_H
+#define REPCONC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_OK 0
+#define RC_EINVAL (-1)     /* bad argument (null pointer, negative size, …)            */
+#define RC_ESHAPE (-2)     /* unsupported K / dsub / M                                 */
+#define RC_EHIP (-3)       /* a HIP runtime call failed (see rc_last_hip_error)        */
+#define RC_EWORKSPACE (-4) /* workspace smaller than the matching *_ws_bytes()         */
+
+#define RC_CODE_U8 0
+#define RC_CODE_I64 1
+
+/* bits of the `flags` word written by the Sinkhorn entry points */
+#define RC_FLAG_NONFINITE 1 /* a row/column sum became 0, inf or NaN — the reference's   */
+                            /* "Sinkhorn Algorithm returns nan/inf values" warning,      */
+                            /* models/repconc/modeling_repconc.py:64-65                  */
+
+typedef struct rc_handle_s* rc_handle_t;
+typedef void* rc_stream_t;
+
+int rc_version(void);
+const char* rc_error_string(int code);
+int rc_create(rc_handle_t* out, int device);
+int rc_destroy(rc_handle_t h);
+int rc_last_hip_error(rc_handle_t h); /* hipError_t of the last RC_EHIP on this handle */
+int rc_num_cus(rc_handle_t h);
+
+/* ------------------------------------------------------------------ a-1 / a-5
+ * Nearest-centroid codes (index build).  Replaces RepCONC.quantize with use_constraint=False,
+ * models/repconc/modeling_repconc.py:49-52,66: code[b,m] = argmin_k sum_j (x[b,m*dsub+j]-C[m,k,j])^2,
+ * first minimum wins.  x: [B, ldx>=D] fp32 row-major; C: [M,K,dsub] fp32.
+ * Either output may be NULL: codes_u8 [B,M] (what evaluate_repconc.py:69 casts to) and
+ * codes_i64 [B,M] (what quantize returns). */
+int rc_pq_assign_nearest(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B,
+                         int D, int M, int K, uint8_t* codes_u8, int64_t* codes_i64,
+                         rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-1
+ * Distance table d[M,B,K] fp32 (modeling_repconc.py:50) and, if minmax != NULL, the per-m
+ * maximum (minmax[0..M)) and minimum (minmax[M..2M)) over (b,k) (:76-77).
+ * ws: rc_pq_dist_table_ws_bytes(B, M) bytes of scratch (block partials). */
+size_t rc_pq_dist_table_ws_bytes(int64_t B, int M);
+int rc_pq_dist_table(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
+                     int M, int K, float* d, float* minmax, void* ws, size_t ws_bytes,
+                     rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-2
+ * In place (d - mid)/amp with mid=(mx+mn)/2, amp=(mx-mid)+1e-5f per m
+ * (RepCONC.center_distance_for_constraint, modeling_repconc.py:81-84).  `minmax` holds the
+ * values AFTER the cross-rank all_reduce(MAX/MIN) of :78-80, which the host performs. */
+int rc_pq_centre(rc_handle_t h, float* d, const float* minmax, int64_t B, int M, int K,
+                 rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-3 / a-4, staged form
+ * Sinkhorn-Knopp of sinkhorn_algorithm (modeling_repconc.py:137-165) on L = -d/eps, evaluated
+ * with potentials: f[M,K], g[M,B] fp64.  One reference iteration (:153-163) = one rc_sk_pass +
+ * one rc_sk_update; the rank-sum of :157 happens between them (the host all-gathers `rows`).
+ *
+ *   rc_sk_pass(first=1):  rows[m,k] = sum_b exp(L[m,b,k])                      (:141,:155)
+ *   rc_sk_update(first=1): f = -log(sum_r rows_all[r])                         (:157-158)
+ *   rc_sk_pass(first=0):  w = exp(L + f_k + g_b); colsum_b = sum_k w;          (:162)
+ *                         rows[m,k] = sum_b w/colsum_b                         (:155)
+ *   rc_sk_update(first=0): g -= log(colsum);  f -= log(sum_r rows_all[r])
+ *   rc_sk_argmax:         code[b,m] = argmax_k (L[m,b,k] + f[m,k]), first maximum (:63,:66)
+ *
+ * T = sinkhorn_iterations needs: pass(first) , update(first), then T-1 x {pass, update}, then
+ * argmax — T+1 sweeps over d in total.  The constants /K, /B, the global normalisation of :152
+ * and the last column normalisation cancel in the argmax.
+ *
+ * rows:     [M,K] fp64, this rank's row sums (written by rc_sk_pass)
+ * rows_all: [G,M,K] fp64, every rank's `rows`, rank-major (G=1: pass `rows` itself)
+ * colsum:   [M,B] fp64 scratch written by pass(first=0), consumed by update(first=0)
+ * ws:       rc_sk_pass_ws_bytes(B, M, K) bytes (block partials)
+ * flags:    one int, OR-ed with RC_FLAG_* (caller zeroes it)
+ */
+size_t rc_sk_pass_ws_bytes(int64_t B, int M, int K);
+int rc_sk_pass(rc_handle_t h, const float* d, const double* f, const double* g, double* colsum,
+               double* rows, int64_t B, int M, int K, double eps, int first, void* ws,
+               size_t ws_bytes, rc_stream_t stream);
+int rc_sk_update(rc_handle_t h, const double* rows_all, int G, double* f, double* g,
+                 const double* colsum, int64_t B, int M, int K, int first, int* flags,
+                 rc_stream_t stream);
+int rc_sk_argmax(rc_handle_t h, const float* d, const double* f, int64_t B, int M, int K,
+                 double eps, uint8_t* codes_u8, int64_t* codes_i64, rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-1 … a-4, one call
+ * RepCONC.quantize with use_constraint=True on ONE rank (modeling_repconc.py:47-67,
+ * dist.is_initialized()==False): distance table -> centring -> `iters` Sinkhorn iterations ->
+ * argmax.  ws: rc_pq_assign_sinkhorn_ws_bytes(B, M, K) bytes. */
+size_t rc_pq_assign_sinkhorn_ws_bytes(int64_t B, int M, int K);
+int rc_pq_assign_sinkhorn(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B,
+                          int D, int M, int K, double eps, int iters, uint8_t* codes_u8,
+                          int64_t* codes_i64, int* flags, void* ws, size_t ws_bytes,
+                          rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-6
+ * decode (modeling_repconc.py:168-175): out[n, m*dsub:(m+1)*dsub] = C[m, codes[n,m], :], and
+ * its gradient w.r.t. C (autograd of the gather at :175): grad_C[m,codes[n,m],:] += grad_out[n,m,:].
+ * code_dtype: RC_CODE_U8 or RC_CODE_I64; codes are [n, M] row-major. */
+int rc_pq_decode(rc_handle_t h, const void* codes, int code_dtype, const float* C, int64_t n,
+                 int M, int K, int dsub, float* out, rc_stream_t stream);
+int rc_pq_decode_bwd(rc_handle_t h, const void* codes, int code_dtype, const float* grad_out,
+                     int64_t n, int M, int K, int dsub, float* grad_C, rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-8
+ * RepCONC.normalize_centrodis (modeling_repconc.py:112-116): C <- C / max(||C||_2, 1e-12). */
+int rc_normalize_centroids(rc_handle_t h, float* C, int M, int K, int dsub, rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-13
+ * hist[m,k] = #{n : codes[n,m]==k} — eval_balance's 256 `.sum().item()` round trips
+ * (models/repconc/finetune_repconc.py:588-592) for all sub-quantisers in one launch.
+ * hist: [M,K] int32, overwritten. */
+int rc_code_hist(rc_handle_t h, const void* codes, int code_dtype, int64_t n, int M, int K,
+                 int32_t* hist, rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-12 (centroid update)
+ * Lloyd sufficient statistics of the k-means inside Faiss `index.train`
+ * (train/run_warmup.py:113): sums[m,k,:] += x[n, m*dsub:(m+1)*dsub], counts[m,k] += 1 for
+ * k = codes[n,m].  sums: [M,K,dsub] fp64, counts: [M,K] int64; ACCUMULATED into (caller
+ * zeroes, so shards / ranks can be summed).  rc_kmeans_update: C = sums/counts where
+ * counts>0, unchanged otherwise. */
+int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const uint8_t* codes, int64_t n,
+                    int D, int M, int K, double* sums, int64_t* counts, rc_stream_t stream);
+int rc_kmeans_update(rc_handle_t h, const double* sums, const int64_t* counts, float* C, int M,
+                     int K, int dsub, rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-9 … a-11
+ * PQ asymmetric-distance (inner product) top-k over raw codes — what `index.search` of the
+ * faiss.IndexPQ / 1-list IndexIVFPQ does at models/repconc/evaluate_repconc.py:182 and
+ * models/jpq/finetune_jpq.py:176.  Per query: LUT[m][k] = <q_m, C[m,k]>, score(n) = sum_m
+ * LUT[m][codes[n,m]] (fp32, m ascending), the k largest scores sorted (score desc, id asc).
+ *
+ * codes: [N,M] uint8 (the index; stays resident, evaluate_repconc.py:89-98)
+ * q: [nq,D] fp32;  scores: [nq,k] fp32;  ids: [nq,k] int64 = row + id_offset, -1 and -inf
+ * score when fewer than k rows exist.  status_host semantics are reported through `status`
+ * (device int, caller zeroes): bit0 = some query collected fewer than k candidates,
+ * bit1 = candidate buffer overflowed; the host retries with another `sel_slack` (see
+ * repconc_amd.index).  ws: rc_adc_search_ws_bytes(N, M, K, nq, k) bytes. */
+size_t rc_adc_search_ws_bytes(int64_t N, int M, int K, int nq, int k);
+int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, const float* C,
+                  int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,
+                  float* scores, int64_t* ids, int* status, void* ws, size_t ws_bytes,
+                  rc_stream_t stream);
+/* the look-up tables alone (test hook): lut [nq,M,K] fp32 */
+int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K,
+               float* lut, rc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REPCONC_HIP_H */

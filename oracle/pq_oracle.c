@@ -1,0 +1,257 @@
+/*
+ * pq_oracle.c — plain-C (OpenMP) restatement of the RepCONC PQ hot path.  TEST INFRASTRUCTURE:
+ * used by tests/ as a second checker at sizes numpy is too slow for, and by bench.py's
+ * `cpu_baseline` leg (kind "port").  Never linked into or called by the product (repconc_amd).
+ *
+ * Parity: rows a-1…a-6 PINNED — tests/test_oracle_golden.py checks this library against the
+ * golden vectors generated from the reference (oracle/gen_golden.py).  ADC / k-means rows:
+ * PARITY UNPINNED (Faiss not available; see oracle/pq_oracle.py header).
+ *
+ * Build: oracle/Makefile  (gcc -O2 -fopenmp -ffp-contract=off -fno-fast-math: every fp32
+ * sub/mul/add of the distance table is rounded separately, as torch-CPU does).
+ * All citations: /root/reference/src/repconc/models/repconc/modeling_repconc.py unless noted.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define K 256
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* torch-CPU `sum(-1)` order over a contiguous fp32 row of length dsub. */
+static float rowsum_torch_order(const float* sq, int dsub) {
+    const int nv = dsub / 8, tail = dsub % 8, full = nv / 4;
+    float acc[4][8];
+    memset(acc, 0, sizeof(acc));
+    for (int i = 0; i < full; ++i)
+        for (int j = 0; j < 4; ++j)
+            for (int l = 0; l < 8; ++l) acc[j][l] = acc[j][l] + sq[8 * (4 * i + j) + l];
+    for (int v = 4 * full; v < nv; ++v)
+        for (int l = 0; l < 8; ++l) acc[0][l] = acc[0][l] + sq[8 * v + l];
+    float a[8];
+    for (int l = 0; l < 8; ++l) {
+        float t = acc[0][l] + acc[1][l];
+        t = t + acc[2][l];
+        a[l] = t + acc[3][l];
+    }
+    float r = 0.0f;
+    for (int j = 0; j < tail; ++j) r = r + sq[nv * 8 + j];
+    for (int l = 0; l < 8; ++l) r = r + a[l];
+    return r;
+}
+
+/* d[m][b][k] = sum_j (x[b][m*dsub+j] - C[m][k][j])^2.  :49-50 */
+void orc_dist_table(const float* x, int64_t ldx, const float* C, int64_t B, int M, int dsub, float* d) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int m = 0; m < M; ++m)
+        for (int64_t b = 0; b < B; ++b) {
+            const float* xr = x + b * ldx + (int64_t)m * dsub;
+            float sq[512];
+            for (int k = 0; k < K; ++k) {
+                const float* c = C + ((int64_t)m * K + k) * dsub;
+                for (int j = 0; j < dsub; ++j) {
+                    const float t = xr[j] - c[j];
+                    sq[j] = t * t;
+                }
+                d[((int64_t)m * B + b) * K + k] = rowsum_torch_order(sq, dsub);
+            }
+        }
+}
+
+/* per-m max (minmax[0..M)) and min (minmax[M..2M)).  :76-77 */
+void orc_minmax(const float* d, int64_t B, int M, float* minmax) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+        float mx = -INFINITY, mn = INFINITY;
+        const float* p = d + (int64_t)m * B * K;
+        for (int64_t i = 0; i < B * K; ++i) {
+            if (p[i] > mx) mx = p[i];
+            if (p[i] < mn) mn = p[i];
+        }
+        minmax[m] = mx;
+        minmax[M + m] = mn;
+    }
+}
+
+/* in place (d-mid)/amp.  :81-84 */
+void orc_centre(float* d, const float* minmax, int64_t B, int M) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+        const float mx = minmax[m], mn = minmax[M + m];
+        const float mid = (mx + mn) / 2.0f;
+        const float amp = (mx - mid) + 1e-5f;
+        float* p = d + (int64_t)m * B * K;
+        for (int64_t i = 0; i < B * K; ++i) p[i] = (p[i] - mid) / amp;
+    }
+}
+
+/* codes[b][m] = argmin_k d[m][b][k], first minimum.  :52,:66 */
+void orc_argmin(const float* d, int64_t B, int M, uint8_t* codes) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int m = 0; m < M; ++m)
+        for (int64_t b = 0; b < B; ++b) {
+            const float* p = d + ((int64_t)m * B + b) * K;
+            int bi = 0;
+            float best = p[0];
+            for (int k = 1; k < K; ++k)
+                if (p[k] < best) { best = p[k]; bi = k; }
+            codes[b * M + m] = (uint8_t)bi;
+        }
+}
+
+/* sinkhorn_algorithm in the reference's in-place Q form, single rank, :137-165, followed by the
+ * argmax of :63.  dc: centred distances [M][B][K] fp32.  Q scratch [K][B] fp64 per thread.
+ * Returns flags: bit0 NaN seen, bit1 Inf seen (:64-65). */
+int orc_sinkhorn_codes(const float* dc, int64_t B, int M, double eps, int iters, uint8_t* codes) {
+    int flags = 0;
+#pragma omp parallel for schedule(dynamic) reduction(| : flags)
+    for (int m = 0; m < M; ++m) {
+        double* Q = (double*)malloc(sizeof(double) * K * B);
+        double* col = (double*)malloc(sizeof(double) * B);
+        const float* dm = dc + (int64_t)m * B * K;
+        double tot = 0.0;
+        for (int k = 0; k < K; ++k)
+            for (int64_t b = 0; b < B; ++b) {
+                const double v = exp((-(double)dm[b * K + k]) / eps); /* :141 on out=-centred (:57) */
+                Q[(int64_t)k * B + b] = v;
+            }
+        for (int k = 0; k < K; ++k) {
+            double s = 0.0;
+            for (int64_t b = 0; b < B; ++b) s += Q[(int64_t)k * B + b];
+            tot += s; /* :148 */
+        }
+        for (int64_t i = 0; i < (int64_t)K * B; ++i) Q[i] /= tot; /* :152 */
+        for (int it = 0; it < iters; ++it) {
+            for (int k = 0; k < K; ++k) { /* :155-159 */
+                double* q = Q + (int64_t)k * B;
+                double s = 0.0;
+                for (int64_t b = 0; b < B; ++b) s += q[b];
+                for (int64_t b = 0; b < B; ++b) { q[b] /= s; q[b] /= K; }
+            }
+            for (int64_t b = 0; b < B; ++b) col[b] = 0.0; /* :162-163 */
+            for (int k = 0; k < K; ++k) {
+                const double* q = Q + (int64_t)k * B;
+                for (int64_t b = 0; b < B; ++b) col[b] += q[b];
+            }
+            for (int k = 0; k < K; ++k) {
+                double* q = Q + (int64_t)k * B;
+                for (int64_t b = 0; b < B; ++b) { q[b] /= col[b]; q[b] /= (double)B; }
+            }
+        }
+        for (int64_t b = 0; b < B; ++b) { /* :164 then :63 (argmax over k, first maximum) */
+            int bi = 0;
+            double best = Q[b] * (double)B;
+            if (isnan(best)) flags |= 1;
+            if (isinf(best)) flags |= 2;
+            for (int k = 1; k < K; ++k) {
+                const double v = Q[(int64_t)k * B + b] * (double)B;
+                if (isnan(v)) flags |= 1;
+                if (isinf(v)) flags |= 2;
+                if (v > best) { best = v; bi = k; }
+            }
+            codes[b * M + m] = (uint8_t)bi;
+        }
+        free(Q);
+        free(col);
+    }
+    return flags;
+}
+
+/* RepCONC.quantize on one rank (:47-67).  ws must hold M*B*K floats. */
+int orc_quantize(const float* x, int64_t ldx, const float* C, int64_t B, int M, int dsub, int use_constraint,
+                 double eps, int iters, uint8_t* codes, float* ws) {
+    orc_dist_table(x, ldx, C, B, M, dsub, ws);
+    if (!use_constraint) {
+        orc_argmin(ws, B, M, codes);
+        return 0;
+    }
+    float* mm = (float*)malloc(sizeof(float) * 2 * M);
+    orc_minmax(ws, B, M, mm);
+    orc_centre(ws, mm, B, M);
+    free(mm);
+    return orc_sinkhorn_codes(ws, B, M, eps, iters, codes);
+}
+
+/* decode :168-175 */
+void orc_decode(const uint8_t* codes, const float* C, int64_t n, int M, int dsub, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i)
+        for (int m = 0; m < M; ++m)
+            memcpy(out + (i * M + m) * dsub, C + ((int64_t)m * K + codes[i * M + m]) * dsub, sizeof(float) * dsub);
+}
+
+/* ---- Faiss IndexPQ(IP) search restated: per-query LUT, linear scan, size-k heap keeping the
+ * largest, output (score desc, id asc).  evaluate_repconc.py:182.  PARITY UNPINNED. */
+typedef struct { float s; int64_t id; } hit_t;
+static int hit_worse(hit_t a, hit_t b) { /* a ranks after b */
+    return a.s < b.s || (a.s == b.s && a.id > b.id);
+}
+static void heap_sift_down(hit_t* h, int n, int i) { /* min-heap on "better": root = worst kept */
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, w = i;
+        if (l < n && hit_worse(h[l], h[w])) w = l;
+        if (r < n && hit_worse(h[r], h[w])) w = r;
+        if (w == i) return;
+        hit_t t = h[i]; h[i] = h[w]; h[w] = t;
+        i = w;
+    }
+}
+static int hit_cmp_desc(const void* pa, const void* pb) {
+    const hit_t a = *(const hit_t*)pa, b = *(const hit_t*)pb;
+    if (hit_worse(a, b)) return 1;
+    if (hit_worse(b, a)) return -1;
+    return 0;
+}
+
+void orc_adc_search(const uint8_t* codes, int64_t N, int M, int dsub, const float* C, const float* q, int nq, int k,
+                    float* scores, int64_t* ids) {
+#pragma omp parallel
+    {
+        float* lut = (float*)malloc(sizeof(float) * M * K);
+        hit_t* heap = (hit_t*)malloc(sizeof(hit_t) * k);
+#pragma omp for schedule(dynamic)
+        for (int qi = 0; qi < nq; ++qi) {
+            for (int m = 0; m < M; ++m)
+                for (int kk = 0; kk < K; ++kk) {
+                    const float* qs = q + (int64_t)qi * M * dsub + m * dsub;
+                    const float* c = C + ((int64_t)m * K + kk) * dsub;
+                    float s = 0.f;
+                    for (int j = 0; j < dsub; ++j) s = s + qs[j] * c[j];
+                    lut[m * K + kk] = s;
+                }
+            int hn = 0;
+            for (int64_t n = 0; n < N; ++n) {
+                const uint8_t* cp = codes + n * M;
+                float s = 0.f;
+                for (int m = 0; m < M; ++m) s = s + lut[m * K + cp[m]];
+                hit_t h = {s, n};
+                if (hn < k) {
+                    heap[hn++] = h;
+                    if (hn == k)
+                        for (int i = k / 2 - 1; i >= 0; --i) heap_sift_down(heap, k, i);
+                } else if (hit_worse(heap[0], h)) {
+                    heap[0] = h;
+                    heap_sift_down(heap, k, 0);
+                }
+            }
+            qsort(heap, hn, sizeof(hit_t), hit_cmp_desc);
+            for (int j = 0; j < k; ++j) {
+                scores[(int64_t)qi * k + j] = j < hn ? heap[j].s : -INFINITY;
+                ids[(int64_t)qi * k + j] = j < hn ? heap[j].id : -1;
+            }
+        }
+        free(lut);
+        free(heap);
+    }
+}

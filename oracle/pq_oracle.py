@@ -1,0 +1,303 @@
+"""numpy restatement of the RepCONC PQ hot path.  TEST INFRASTRUCTURE ONLY.
+
+Parity status
+-------------
+* rows a-1 … a-8 of SURVEY.md §8 (distance table, centring, Sinkhorn, argmax/argmin,
+  decode, diagnostics): PINNED.  tests/test_oracle_golden.py checks every function here
+  against tests/golden/*.npz, which oracle/gen_golden.py produced by importing the
+  reference (`/root/reference/src/repconc/models/repconc/modeling_repconc.py`) in the
+  build container and running it on torch-CPU.
+* rows a-9 … a-12 (Faiss IndexPQ add/search, k-means warm-up): PARITY UNPINNED.  Faiss is
+  not vendored in the reference and not installed anywhere we can reach (no network); the
+  restatement follows Faiss 1.7.x's published behaviour and is
+  anchored on the reference's call sites plus the identity
+  ``sum_m LUT[m][code_m] == <q, decode(code)>`` that the reference's own `decode` pins.
+
+Every function cites the reference lines it restates (paths relative to
+/root/reference/src/repconc/).  Nothing here is imported by the product package.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+F64 = np.float64
+
+
+# --------------------------------------------------------------------------- a-1
+def _rowsum_torch_cpu_order(sq: np.ndarray) -> np.ndarray:
+    """Sum over the last axis in the order torch-CPU's vectorised `sum(-1)` uses for a
+    contiguous fp32 row of length dsub (bit-verified for dsub in {8,12,16,24,32,48,64,96};
+    SURVEY.md §8 a-1):  split the row into 8-wide vectors v0,v1,…; four accumulators
+    acc_j = sum_i v_{4i+j}; left-over vectors go to acc_0 in order; acc_0 += acc_1, acc_2,
+    acc_3; result = ((tail scalars summed from 0) + lane0) + lane1 … + lane7."""
+    dsub = sq.shape[-1]
+    nv, tail = dsub // 8, dsub % 8
+    lead = sq.shape[:-1]
+    acc = [np.zeros(lead + (8,), F32) for _ in range(4)]
+    full = nv // 4
+    for i in range(full):
+        for j in range(4):
+            acc[j] = acc[j] + sq[..., 8 * (4 * i + j): 8 * (4 * i + j) + 8]
+    for v in range(4 * full, nv):
+        acc[0] = acc[0] + sq[..., 8 * v: 8 * v + 8]
+    a = acc[0] + acc[1]
+    a = a + acc[2]
+    a = a + acc[3]
+    r = np.zeros(lead, F32)
+    for j in range(tail):
+        r = r + sq[..., nv * 8 + j]
+    for lane in range(8):
+        r = r + a[..., lane]
+    return r
+
+
+def dist_table(x: np.ndarray, centroids: np.ndarray, chunk: int = 256) -> np.ndarray:
+    """d[m,b,k] = sum_j (x[b, m*dsub+j] - C[m,k,j])**2, fp32, sub→round, square→round,
+    torch-CPU sum order.  models/repconc/modeling_repconc.py:49-50."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    C = np.ascontiguousarray(centroids, dtype=F32)
+    B, D = x.shape
+    M, K, dsub = C.shape
+    assert D == M * dsub
+    out = np.empty((M, B, K), F32)
+    xs = x.reshape(B, M, dsub)
+    for b0 in range(0, B, chunk):
+        xb = xs[b0:b0 + chunk].transpose(1, 0, 2)[:, :, None, :]      # [M,bc,1,dsub]
+        diff = xb - C[:, None, :, :]                                    # [M,bc,K,dsub]
+        out[:, b0:b0 + chunk, :] = _rowsum_torch_cpu_order(diff * diff)
+    return out
+
+
+# --------------------------------------------------------------------------- a-2
+def minmax_per_m(d: np.ndarray):
+    """per-m max / min over (b,k).  modeling_repconc.py:76-77."""
+    return d.max(axis=(1, 2)).astype(F32), d.min(axis=(1, 2)).astype(F32)
+
+
+def centre(d: np.ndarray, mx: np.ndarray, mn: np.ndarray) -> np.ndarray:
+    """(d - mid)/amp with mid=(mx+mn)/2, amp=(mx-mid)+1e-5, all fp32, IEEE division.
+    modeling_repconc.py:81-84 (mx/mn are the already all-reduced values of :78-80)."""
+    mx = mx.astype(F32)
+    mn = mn.astype(F32)
+    mid = (mx + mn) / F32(2)
+    amp = (mx - mid) + F32(1e-5)
+    assert np.all(amp > 0)                                              # :83
+    return ((d - mid[:, None, None]) / amp[:, None, None]).astype(F32)
+
+
+# --------------------------------------------------------------------------- a-3
+def sinkhorn_q(out_shards, epsilon: float, iters: int):
+    """fp64 Sinkhorn-Knopp in the reference's in-place Q form.  modeling_repconc.py:137-165.
+
+    `out_shards` is a list with one [M,K,B_r] fp64 array per simulated rank (a single
+    element = not distributed).  Cross-rank all_reduce(SUM) of :151 and :157 is restated
+    as a rank-ordered sum.  Returns the list of per-rank Q."""
+    G = len(out_shards)
+    Qs = [np.exp(o / epsilon) for o in out_shards]                       # :141
+    K = Qs[0].shape[1]
+    B = Qs[0].shape[2] * G                                              # :144,:150
+    tot = sum(q.sum(-1, keepdims=True).sum(-2, keepdims=True) for q in Qs)   # :148-151
+    for q in Qs:
+        q /= tot                                                        # :152
+    for _ in range(iters):                                              # :153
+        rows = sum(q.sum(axis=2, keepdims=True) for q in Qs)            # :155-157
+        for q in Qs:
+            q /= rows                                                   # :158
+            q /= K                                                      # :159
+            q /= q.sum(axis=1, keepdims=True)                           # :162
+            q /= B                                                      # :163
+    for q in Qs:
+        q *= B                                                          # :164
+    return Qs
+
+
+# ----------------------------------------------------------------- a-4 / a-5 (quantize)
+def quantize(x, centroids, use_constraint: bool, epsilon: float = 0.003, iters: int = 100,
+             shards: int = 1, return_intermediates: bool = False):
+    """codes int64 [B,M].  modeling_repconc.py:47-67.  `shards`>1 simulates the
+    dist.is_initialized() branch with equal row blocks per rank (:78-80,:149-157)."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    B = x.shape[0]
+    d = dist_table(x, centroids)
+    if not use_constraint:
+        codes = np.argmin(d, axis=-1)                                   # :52 first-min
+        return (codes.T.copy(), {"dist": d}) if return_intermediates else codes.T.copy()
+    mx, mn = minmax_per_m(d)                                            # global == max over ranks
+    dc = centre(d, mx, mn)                                              # :54
+    assert B % shards == 0
+    bl = B // shards
+    outs = [-(dc[:, r * bl:(r + 1) * bl, :].astype(F64)).transpose(0, 2, 1) for r in range(shards)]
+    Qs = sinkhorn_q(outs, epsilon, iters)                               # :57-62
+    Q = np.concatenate([q.transpose(0, 2, 1) for q in Qs], axis=1)     # M,B,K
+    codes = np.argmax(Q, axis=-1)                                       # :63 first-max
+    flags = int(np.isnan(Q).any()) | (int(np.isinf(Q).any()) << 1)      # :64-65
+    codes = codes.T.copy()                                              # :66
+    if return_intermediates:
+        return codes, {"dist": d, "mx": mx, "mn": mn, "centred": dc, "flags": flags}
+    return codes
+
+
+def sinkhorn_codes_logdomain(dc: np.ndarray, epsilon: float, iters: int) -> np.ndarray:
+    """Same codes as quantize(use_constraint=True) computed with potentials instead of the
+    in-place matrix (the formulation the HIP kernels use).  Used by the
+    tests as an independent cross-check of the algebra, not as the parity oracle."""
+    L = -(dc.astype(F64)) / epsilon                                     # [M,B,K]
+    M, B, K = L.shape
+    f = -np.log(np.exp(L).sum(axis=1))                                  # pass 0, g=0  [M,K]
+    g = np.zeros((M, B), F64)
+    for _ in range(iters - 1):
+        w = np.exp(L + f[:, None, :] + g[:, :, None])
+        c = w.sum(axis=2)
+        g = g - np.log(c)
+        f = f - np.log((w / c[:, :, None]).sum(axis=1))
+    return np.argmax(L + f[:, None, :], axis=-1).T.copy()
+
+
+# --------------------------------------------------------------------------- a-6
+def decode(codes: np.ndarray, centroids: np.ndarray) -> np.ndarray:
+    """out[b, m*dsub:(m+1)*dsub] = C[m, codes[b,m], :].  modeling_repconc.py:168-184."""
+    M, K, dsub = centroids.shape
+    n = codes.shape[0]
+    idx = codes.astype(np.int64)
+    return centroids[np.arange(M)[None, :], idx, :].reshape(n, M * dsub)
+
+
+def decode_bwd(codes: np.ndarray, grad_out: np.ndarray, M: int, K: int) -> np.ndarray:
+    """Gradient of decode w.r.t. the centroids: scatter-add of grad_out rows into
+    [M,K,dsub] (autograd of the advanced-index gather at modeling_repconc.py:175)."""
+    n, D = grad_out.shape
+    dsub = D // M
+    g = np.zeros((M, K, dsub), F32)
+    go = grad_out.reshape(n, M, dsub)
+    for m in range(M):
+        np.add.at(g[m], codes[:, m].astype(np.int64), go[:, m, :])
+    return g
+
+
+# --------------------------------------------------------------------------- a-8
+def normalize_centroids(centroids: np.ndarray) -> np.ndarray:
+    """C / max(||C||_2, 1e-12) over dsub (F.normalize).  modeling_repconc.py:112-116."""
+    n = np.sqrt((centroids.astype(F32) ** 2).sum(-1, keepdims=True)).astype(F32)
+    return (centroids / np.maximum(n, F32(1e-12))).astype(F32)
+
+
+# --------------------------------------------------------------------------- a-13
+def code_histogram(codes: np.ndarray, K: int = 256) -> np.ndarray:
+    """hist[m,k] = #{b : codes[b,m]==k} (the 256 `.sum().item()` calls of
+    models/repconc/finetune_repconc.py:590-592, for every sub-quantiser at once)."""
+    B, M = codes.shape
+    h = np.zeros((M, K), np.int32)
+    for m in range(M):
+        h[m] = np.bincount(codes[:, m].astype(np.int64), minlength=K)
+    return h
+
+
+def eval_balance(codes: np.ndarray, block_id: int = 0):
+    """finetune_repconc.py:580-597."""
+    col = codes[:, block_id]
+    n = len(col)
+    bal = [abs(1 - int((col == i).sum()) / (n / 256)) for i in range(256)]
+    return {"avg_imbalance": round(float(np.mean(bal)), 3),
+            "max_imbalance": round(float(np.max(bal)), 3)}
+
+
+def test_quantize(x, centroids, epsilon, iters, block_id: int = 0):
+    """finetune_repconc.py:600-613 (note: sqrt of the summed squares, then mean)."""
+    out = {}
+    for prefix, uc in (("w/o_conc", False), ("w/_conc", True)):
+        codes = quantize(x, centroids, uc, epsilon, iters)
+        q = decode(codes, centroids)
+        mse = np.sqrt(((q - x) ** 2).sum(-1)).mean()
+        out[f"{prefix}_mse"] = round(float(mse), 3)
+        out.update({f"{prefix}_{k}": v for k, v in eval_balance(codes, block_id).items()})
+    return out
+
+
+# ----------------------------------------------------------------- a-9 … a-11 (Faiss side)
+def adc_lut(q: np.ndarray, centroids: np.ndarray) -> np.ndarray:
+    """Inner-product look-up tables LUT[nq,M,K] = <q_m, C[m,k]> (Faiss IndexPQ search with
+    METRIC_INNER_PRODUCT, called at models/repconc/evaluate_repconc.py:182).  fp32, the dot
+    product accumulated j-ascending like Faiss's scalar `fvec_inner_product`.
+    PARITY UNPINNED (no Faiss to run)."""
+    nq, D = q.shape
+    M, K, dsub = centroids.shape
+    qs = q.reshape(nq, M, dsub).astype(F32)
+    lut = np.zeros((nq, M, K), F32)
+    for j in range(dsub):
+        lut = lut + qs[:, :, None, j] * centroids[None, :, :, j]
+    return lut
+
+
+def adc_scores(lut: np.ndarray, codes: np.ndarray) -> np.ndarray:
+    """score[q,n] = sum_m LUT[q,m,codes[n,m]], m-ascending fp32 accumulation from 0."""
+    nq, M, K = lut.shape
+    s = np.zeros((nq, codes.shape[0]), F32)
+    for m in range(M):
+        s = s + lut[:, m, :][:, codes[:, m].astype(np.int64)]
+    return s
+
+
+def topk_desc(scores: np.ndarray, k: int):
+    """Top-k per row, ordered (score descending, index ascending) — the deterministic
+    refinement of Faiss's 'results sorted by decreasing inner product'."""
+    nq, n = scores.shape
+    k = min(k, n)
+    order = np.lexsort((np.broadcast_to(np.arange(n), scores.shape), -scores.astype(F64)), axis=1)
+    idx = order[:, :k]
+    return np.take_along_axis(scores, idx, axis=1), idx.astype(np.int64)
+
+
+def adc_search(q, centroids, codes, k):
+    """evaluate_repconc.py:180-185 with a Faiss IndexPQ(IP) — brute force."""
+    return topk_desc(adc_scores(adc_lut(q, centroids), codes), k)
+
+
+# --------------------------------------------------------------------------- a-12
+def kmeans_stats(x: np.ndarray, codes: np.ndarray, M: int, K: int = 256):
+    """Per-(m,k) sufficient statistics of one Lloyd step: sum[M,K,dsub] fp64 (so the value
+    is order-independent to ~1e-16) and count[M,K].  Stands for the centroid-update half of
+    Faiss's k-means inside `index.train` (train/run_warmup.py:113)."""
+    B, D = x.shape
+    dsub = D // M
+    sums = np.zeros((M, K, dsub), F64)
+    cnt = np.zeros((M, K), np.int64)
+    xs = x.reshape(B, M, dsub).astype(F64)
+    for m in range(M):
+        np.add.at(sums[m], codes[:, m].astype(np.int64), xs[:, m, :])
+        cnt[m] = np.bincount(codes[:, m].astype(np.int64), minlength=K)
+    return sums, cnt
+
+
+def kmeans_update(sums, cnt, old_centroids):
+    """new C = sum/count where count>0, else keep the old centroid."""
+    new = old_centroids.astype(F32).copy()
+    nz = cnt > 0
+    new[nz] = (sums[nz] / cnt[nz][:, None]).astype(F32)
+    return new
+
+
+def lloyd(x, centroids, n_iter: int):
+    C = centroids.astype(F32).copy()
+    M, K, _ = C.shape
+    for _ in range(n_iter):
+        codes = quantize(x, C, False)
+        s, c = kmeans_stats(x, codes, M, K)
+        C = kmeans_update(s, c, C)
+    return C
+
+
+# --------------------------------------------------------------------------- metric
+def mrr_at_k(ranked_ids: np.ndarray, positives, k: int = 10) -> float:
+    """MRR@k as utils/eval_utils.py:136-190 computes it through pytrec_eval: truncate each
+    run to its top-k, reciprocal rank of the first doc with relevance>=1, mean over
+    queries, rounded to 5 dp.  `positives[i]` is the set of relevant ids for query i."""
+    rr = []
+    for row, pos in zip(ranked_ids, positives):
+        r = 0.0
+        for rank, did in enumerate(row[:k]):
+            if int(did) in pos:
+                r = 1.0 / (rank + 1)
+                break
+        rr.append(r)
+    return round(float(np.mean(rr)), 5)

@@ -1,0 +1,362 @@
+// PQ asymmetric-distance (inner-product) top-k search over raw uint8 codes.
+//
+// Reference: `index.search(query_embeds, topk)` on a faiss.IndexPQ(D, M, 8, METRIC_INNER_PRODUCT)
+// or its 1-list IVFPQ clone — models/repconc/evaluate_repconc.py:78-135,180-185 and
+// models/jpq/finetune_jpq.py:176.  Faiss is not vendored in the reference; the arithmetic restated
+// here is Faiss 1.7.x's published IndexPQ behaviour: per query an
+// inner-product table LUT[m][k] = <q_m, C[m,k]>, score(n) = sum_m LUT[m][code[n,m]] accumulated
+// m-ascending in fp32, the k largest returned in decreasing order (ties: lower id first).
+//
+// Pipeline for one batch of queries (all on one stream, no host round trip):
+//   1. adc_lut_kernel        LUT[nq][M][256] (fp32; 48 KiB per query at M=48)
+//   2. adc_scan_kernel<SAMPLE> scores of S <= 32768 evenly spread rows -> sample[nq][S]
+//   3. adc_threshold_kernel  per query: the r-th largest sample score (LDS radix select) = tau_q;
+//                            r is chosen so that ~ (r/S)*N >> k rows pass, i.e. the true top-k are
+//                            all >= tau_q with overwhelming probability (host checks the count)
+//   4. adc_scan_kernel<FILTER> full scan: rows with score >= tau_q are appended (wave-aggregated
+//                            atomics) to a per-query candidate list of 64-bit keys
+//   5. adc_select_kernel     per query: bitonic sort of the candidates in LDS, emit top-k
+//
+// The scan is the hot kernel.  A block keeps the LUTs of QT queries in LDS, interleaved
+// [m][k][QT] so ONE ds_read_b64 / b128 gather serves QT queries, and streams a tile of codes
+// (consecutive lanes = consecutive rows, 16-byte loads).  Blocks that share a code tile are
+// adjacent in the grid, so a tile is fetched from HBM about once per XCD and re-read from L2.
+#include "rc_common.h"
+
+#define ADC_THREADS 1024
+#define ADC_SAMPLE_MAX 32768
+#define ADC_CAND_CAP 16384
+#define ADC_TILE_DOCS 32768
+
+__device__ __forceinline__ unsigned adc_order_key(float s) {
+    const unsigned u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float adc_unorder_key(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// ------------------------------------------------------------------------------------------ 1. LUT
+// grid (nq, M), block 256 (= k).  j-ascending multiply then add, each rounded (no FMA).
+__global__ __launch_bounds__(RC_K) void adc_lut_kernel(const float* __restrict__ C, const float* __restrict__ q,
+                                                       int D, int M, float* __restrict__ lut) {
+    const int qi = blockIdx.x, m = blockIdx.y, k = threadIdx.x;
+    const int dsub = D / M;
+    const float* qs = q + (size_t)qi * D + m * dsub;  // wave-uniform
+    const float* c = C + ((size_t)m * RC_K + k) * dsub;
+    float s = 0.f;
+    for (int j = 0; j < dsub; ++j) s = s + qs[j] * c[j];
+    lut[((size_t)qi * M + m) * RC_K + k] = s;
+}
+
+// ------------------------------------------------------------------------------------------ 2/4. scan
+template <int QT> struct adc_vec;
+template <> struct adc_vec<1> { using type = float; };
+template <> struct adc_vec<2> { using type = float2; };
+template <> struct adc_vec<4> { using type = float4; };
+
+template <int QT>
+__device__ __forceinline__ void adc_acc(float (&s)[QT], const typename adc_vec<QT>::type& v) {
+    if constexpr (QT == 1) { s[0] = s[0] + v; }
+    if constexpr (QT == 2) { s[0] = s[0] + v.x; s[1] = s[1] + v.y; }
+    if constexpr (QT == 4) { s[0] = s[0] + v.x; s[1] = s[1] + v.y; s[2] = s[2] + v.z; s[3] = s[3] + v.w; }
+}
+
+enum { ADC_SAMPLE = 0, ADC_FILTER = 1 };
+
+// grid (query groups, doc tiles).  SAMPLE: row n_i = floor(i*N/S), i in the tile, dense output.
+// FILTER: rows of the tile, candidates with score >= thr[q] appended as keys
+// (ordered(score) << 32 | ~row), so a descending key sort is (score desc, row asc).
+template <int M, int QT, int MODE>
+__global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(const uint8_t* __restrict__ codes, int64_t N,
+                                                               const float* __restrict__ lut, int nq, int64_t S,
+                                                               float* __restrict__ sample,
+                                                               const float* __restrict__ thr,
+                                                               unsigned* __restrict__ cand_count,
+                                                               unsigned long long* __restrict__ cand) {
+    using V = typename adc_vec<QT>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V* tab = reinterpret_cast<V*>(smem);  // [M*256]
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * QT;
+    // stage the QT tables interleaved; queries past nq replicate the last valid one
+    for (int i = tid; i < M * RC_K; i += ADC_THREADS) {
+        float v[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int qi = (q0 + t < nq) ? q0 + t : nq - 1;
+            v[t] = lut[(size_t)qi * M * RC_K + i];
+        }
+        if constexpr (QT == 1) tab[i] = v[0];
+        if constexpr (QT == 2) tab[i] = make_float2(v[0], v[1]);
+        if constexpr (QT == 4) tab[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    float tq[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) tq[t] = (MODE == ADC_FILTER && q0 + t < nq) ? thr[q0 + t] : INFINITY;
+    __syncthreads();
+
+    const int64_t total = (MODE == ADC_SAMPLE) ? S : N;
+    const int64_t t0 = (int64_t)blockIdx.y * ADC_TILE_DOCS;
+    const int64_t t1 = (t0 + ADC_TILE_DOCS < total) ? t0 + ADC_TILE_DOCS : total;
+    constexpr int W = (M % 16 == 0) ? 16 : (M % 8 == 0) ? 8 : 4;  // load width in bytes
+    constexpr int NW = M / W;
+    for (int64_t i0 = t0; i0 < t1; i0 += ADC_THREADS) {   // wave-uniform trip count
+        const int64_t i = i0 + tid;
+        const bool live = i < t1;
+        const int64_t ii = live ? i : (t1 - 1);
+        int64_t n = ii;
+        if constexpr (MODE == ADC_SAMPLE) n = (int64_t)(((uint64_t)ii * (uint64_t)N) / (uint64_t)S);  // ii < 2^15, N < 2^32
+        const uint8_t* cp = codes + n * M;
+        unsigned w[M / 4];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            if constexpr (W == 16) {
+                const uint4 v = reinterpret_cast<const uint4*>(cp)[j];
+                w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+            } else if constexpr (W == 8) {
+                const uint2 v = reinterpret_cast<const uint2*>(cp)[j];
+                w[2 * j] = v.x; w[2 * j + 1] = v.y;
+            } else {
+                w[j] = reinterpret_cast<const unsigned*>(cp)[j];
+            }
+        }
+        float s[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) s[t] = 0.f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const unsigned c = (w[m >> 2] >> (8 * (m & 3))) & 0xFFu;
+            adc_acc<QT>(s, tab[m * RC_K + c]);
+        }
+        if constexpr (MODE == ADC_SAMPLE) {
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    if (q0 + t < nq) sample[(size_t)(q0 + t) * S + i] = s[t];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const bool pass = live && (s[t] >= tq[t]);
+                const unsigned long long mask = __ballot(pass);
+                if (mask) {  // wave-uniform
+                    const int lane = tid & 63;
+                    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                    unsigned base = 0;
+                    if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(cand_count + q0 + t, (unsigned)__popcll(mask));
+                    base = __shfl(base, (int)__builtin_ctzll(mask));
+                    const unsigned slot = base + rank;
+                    if (pass && slot < ADC_CAND_CAP)
+                        cand[(size_t)(q0 + t) * ADC_CAND_CAP + slot] =
+                            ((unsigned long long)adc_order_key(s[t]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 3. threshold
+// One block per query: r-th largest of S sample scores by an 8-bit-per-pass radix select on the
+// order-preserving key, everything in LDS.  r <= 0 or r > S: tau = -inf (keep every row).
+__global__ __launch_bounds__(1024) void adc_threshold_kernel(const float* __restrict__ sample, int64_t S, int r,
+                                                             float* __restrict__ thr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* keys = reinterpret_cast<unsigned*>(smem);  // [S]
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_rank;
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    if (r <= 0 || r > S) {
+        if (tid == 0) thr[qi] = -INFINITY;
+        return;
+    }
+    for (int64_t i = tid; i < S; i += 1024) keys[i] = adc_order_key(sample[(size_t)qi * S + i]);
+    if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)r; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = sel_prefix;
+        const unsigned himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int64_t i = tid; i < S; i += 1024) {
+            const unsigned k = keys[i];
+            if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned need = sel_rank, b = 255;
+            for (;; --b) {
+                if (hist[b] >= need) break;
+                need -= hist[b];
+                if (b == 0) break;
+            }
+            sel_prefix = prefix | (b << shift);
+            sel_rank = need;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) thr[qi] = adc_unorder_key(sel_prefix);
+}
+
+// ------------------------------------------------------------------------------------------ 5. select
+// One block per query.  Sort the candidate keys descending (bitonic, LDS), emit the first k.
+// status |= 1 if fewer than min(k,N) candidates were collected, |= 2 if the list overflowed.
+__global__ __launch_bounds__(1024) void adc_select_kernel(const unsigned long long* __restrict__ cand,
+                                                          const unsigned* __restrict__ cand_count, int64_t N, int k,
+                                                          int64_t id_offset, float* __restrict__ scores,
+                                                          int64_t* __restrict__ ids, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    const unsigned raw = cand_count[qi];
+    const int cnt = raw > ADC_CAND_CAP ? ADC_CAND_CAP : (int)raw;
+    const int64_t want = (k < N) ? k : N;
+    if (tid == 0) {
+        int st = 0;
+        if ((int64_t)cnt < want) st |= 1;
+        if (raw > ADC_CAND_CAP) st |= 2;
+        if (st) atomicOr(status, st);
+    }
+    int P = 1024;
+    while (P < cnt) P <<= 1;
+    for (int i = tid; i < P; i += 1024) keys[i] = (i < cnt) ? cand[(size_t)qi * ADC_CAND_CAP + i] : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int lo = ((t / stride) * (stride << 1)) + (t % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < k; j += 1024) {
+        float sc = -INFINITY;
+        int64_t id = -1;
+        if (j < cnt) {
+            const unsigned long long key = keys[j];
+            sc = adc_unorder_key((unsigned)(key >> 32));
+            id = (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) + id_offset;
+        }
+        scores[(size_t)qi * k + j] = sc;
+        ids[(size_t)qi * k + j] = id;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+struct adc_ws_layout {
+    size_t lut, sample, thr, cnt, cand, total;
+    int64_t S;
+};
+static adc_ws_layout adc_layout(int64_t N, int M, int nq) {
+    adc_ws_layout L;
+    L.S = N < ADC_SAMPLE_MAX ? N : ADC_SAMPLE_MAX;
+    size_t o = 0;
+    L.lut = o;    o += rc_align_up((size_t)nq * M * RC_K * sizeof(float), 256);
+    L.sample = o; o += rc_align_up((size_t)nq * (size_t)L.S * sizeof(float), 256);
+    L.thr = o;    o += rc_align_up((size_t)nq * sizeof(float), 256);
+    L.cnt = o;    o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
+    L.cand = o;   o += rc_align_up((size_t)nq * ADC_CAND_CAP * sizeof(unsigned long long), 256);
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t rc_adc_search_ws_bytes(int64_t N, int M, int K, int nq, int k) {
+    if (N <= 0 || M <= 0 || K != RC_K || nq <= 0 || k <= 0) return 0;
+    return adc_layout(N, M, nq).total;
+}
+
+static int adc_qt_for(int M) {
+    if (M <= 32) return 4;   // <= 128 KiB of tables
+    if (M <= 64) return 2;   // M=48: 96 KiB, M=64: 128 KiB
+    return 1;                // M=96: 96 KiB
+}
+
+template <int M, int QT>
+static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, const float* lut, int nq, int64_t S,
+                            float* sample, float* thr, unsigned* cnt, unsigned long long* cand, int r,
+                            hipStream_t s) {
+    const size_t lds = (size_t)M * RC_K * QT * sizeof(float);
+    const unsigned qg = (unsigned)((nq + QT - 1) / QT);
+    auto ksample = adc_scan_kernel<M, QT, ADC_SAMPLE>;
+    auto kfilter = adc_scan_kernel<M, QT, ADC_FILTER>;
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)ksample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kfilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ksample, dim3(qg, (unsigned)((S + ADC_TILE_DOCS - 1) / ADC_TILE_DOCS)), dim3(ADC_THREADS), lds, s,
+                       codes, N, lut, nq, S, sample, thr, cnt, cand);
+    RC_LAUNCH_CHECK(h);
+    const size_t tl = (size_t)S * sizeof(unsigned);
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)adc_threshold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tl));
+    hipLaunchKernelGGL(adc_threshold_kernel, dim3((unsigned)nq), dim3(1024), tl, s, sample, S, r, thr);
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(kfilter, dim3(qg, (unsigned)((N + ADC_TILE_DOCS - 1) / ADC_TILE_DOCS)), dim3(ADC_THREADS), lds, s,
+                       codes, N, lut, nq, S, sample, thr, cnt, cand);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+#define ADC_CASE(MM, QQ) \
+    case MM: rc = adc_launch_scans<MM, QQ>(h, codes, N, lut, nq, L.S, sample, thr, cnt, cand, r, s); break;
+
+extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K, float* lut,
+                          rc_stream_t stream) {
+    if (!h || !C || !q || !lut || nq < 0 || M <= 0 || D <= 0) return RC_EINVAL;
+    if (K != RC_K || D % M != 0) return RC_ESHAPE;
+    if (nq == 0) return RC_OK;
+    hipLaunchKernelGGL(adc_lut_kernel, dim3((unsigned)nq, (unsigned)M), dim3(RC_K), 0, (hipStream_t)stream, C, q, D, M,
+                       lut);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+extern "C" int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, const float* C, int D,
+                             const float* q, int nq, int k, int64_t id_offset, double sel_slack, float* scores,
+                             int64_t* ids, int* status, void* ws, size_t ws_bytes, rc_stream_t stream) {
+    if (!h || !codes || !C || !q || !scores || !ids || !status || N <= 0 || nq < 0 || k <= 0 || M <= 0 || D <= 0)
+        return RC_EINVAL;
+    if (K != RC_K || D % M != 0 || N > 0xFFFFFFFFll || k > ADC_CAND_CAP / 2) return RC_ESHAPE;
+    if (nq == 0) return RC_OK;
+    const adc_ws_layout L = adc_layout(N, M, nq);
+    if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
+    char* w = (char*)ws;
+    float* lut = (float*)(w + L.lut);
+    float* sample = (float*)(w + L.sample);
+    float* thr = (float*)(w + L.thr);
+    unsigned* cnt = (unsigned*)(w + L.cnt);
+    unsigned long long* cand = (unsigned long long*)(w + L.cand);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = rc_adc_lut(h, C, q, nq, D, M, K, lut, stream);
+    if (rc != RC_OK) return rc;
+    RC_HIP_CHECK(h, hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(unsigned), s));
+    // rank of the sample score used as the filter threshold
+    int r;
+    if (N <= ADC_CAND_CAP) {
+        r = 0;  // tau = -inf: every row is a candidate, the select kernel sorts them all
+    } else if (L.S == N) {
+        r = k;  // the sample is the whole index: tau is the exact k-th score
+    } else {
+        const double mu = (double)k * (double)L.S / (double)N;
+        r = (int)(mu + sel_slack * sqrt(mu + 1.0) + 4.0) + 1;
+        if (r > L.S) r = (int)L.S;
+    }
+    switch (M) {
+        ADC_CASE(8, 4) ADC_CASE(12, 4) ADC_CASE(16, 4) ADC_CASE(24, 4) ADC_CASE(32, 4)
+        ADC_CASE(48, 2) ADC_CASE(64, 2) ADC_CASE(96, 1)
+        default: return RC_ESHAPE;
+    }
+    if (rc != RC_OK) return rc;
+    (void)adc_qt_for;
+    const int P = ADC_CAND_CAP;
+    const size_t sl = (size_t)P * sizeof(unsigned long long);
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)adc_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)sl));
+    hipLaunchKernelGGL(adc_select_kernel, dim3((unsigned)nq), dim3(1024), sl, s, cand, cnt, N, k, id_offset, scores, ids,
+                       status);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}

@@ -1,0 +1,278 @@
+// Sub-vector vs centroid squared distances with the reference's exact fp32 rounding, the
+// per-sub-quantiser min/max + centring, and the fused nearest-code assignment.
+//
+// Reference: models/repconc/modeling_repconc.py:49-52 (distance table, argmin) and :73-85
+// (center_distance_for_constraint).  The oracle is torch-CPU, whose `.sum(-1)` over a
+// contiguous fp32 row adds in a fixed 8-lane / 4-accumulator order;
+// sqdist_exact() reproduces that order.  This file is compiled with -ffp-contract=off: every
+// sub, mul and add below is individually rounded, exactly like the reference's three tensor ops.
+#include "rc_common.h"
+
+// d = sum_j (x_j - c_j)^2 in torch-CPU order.  XA / CA are anything indexable ([]), so callers
+// can keep one operand in VGPRs and let the other come from scalar (wave-uniform) loads.
+template <int DSUB, typename XA, typename CA>
+__device__ __forceinline__ float sqdist_exact(const XA& x, const CA& c) {
+    constexpr int NV = DSUB / 8;    // 8-wide vectors in the row
+    constexpr int TAIL = DSUB % 8;  // trailing scalars
+    constexpr int FULL = NV / 4;    // rounds that feed all four accumulators
+    float sq[DSUB];
+#pragma unroll
+    for (int j = 0; j < DSUB; ++j) {
+        const float t = x[j] - c[j];
+        sq[j] = t * t;
+    }
+    float a[8];
+    if constexpr (FULL == 0) {
+        // fewer than four vectors: they all land in accumulator 0, in order; the other
+        // three accumulators stay +0 and adding them is exact.
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float s = sq[l];
+#pragma unroll
+            for (int v = 1; v < NV; ++v) s = s + sq[8 * v + l];
+            a[l] = s;
+        }
+    } else {
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                float s = sq[8 * q + l];
+#pragma unroll
+                for (int i = 1; i < FULL; ++i) s = s + sq[8 * (4 * i + q) + l];
+                acc[q][l] = s;
+            }
+#pragma unroll
+        for (int v = 4 * FULL; v < NV; ++v)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[0][l] = acc[0][l] + sq[8 * v + l];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) a[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+    }
+    float r;
+    if constexpr (TAIL == 0) {
+        r = a[0];  // (0 + lane0) is exact
+#pragma unroll
+        for (int l = 1; l < 8; ++l) r = r + a[l];
+    } else {
+        r = sq[NV * 8];
+#pragma unroll
+        for (int j = 1; j < TAIL; ++j) r = r + sq[NV * 8 + j];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) r = r + a[l];
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Distance table d[M,B,K].  Block = one sub-quantiser m x a strip of rows; thread k keeps
+// centroid C[m,k,:] in VGPRs; the row slice x[b, m*dsub..] is wave-uniform, so it arrives
+// through scalar loads.  Each wave stores 64 consecutive floats of d per row (coalesced), the
+// block 1 KiB.  Per-block (max,min) go to `mm_part` [M][gridDim.x][2].
+template <int DSUB>
+__global__ __launch_bounds__(RC_K) void dist_table_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ C, int64_t B,
+                                                          int rows_per_block, float* __restrict__ d,
+                                                          float* __restrict__ mm_part) {
+    const int m = blockIdx.y;
+    const int k = threadIdx.x;
+    const int M = gridDim.y;
+    float c[DSUB];
+    {
+        const float4* cp = reinterpret_cast<const float4*>(C + ((size_t)m * RC_K + k) * DSUB);
+#pragma unroll
+        for (int j = 0; j < DSUB / 4; ++j) {
+            const float4 v = cp[j];
+            c[4 * j] = v.x; c[4 * j + 1] = v.y; c[4 * j + 2] = v.z; c[4 * j + 3] = v.w;
+        }
+    }
+    const int64_t b0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t b1 = (b0 + rows_per_block < B) ? b0 + rows_per_block : B;
+    float mx = -INFINITY, mn = INFINITY;
+    float* drow = d + ((size_t)m * B + b0) * RC_K + k;
+    for (int64_t b = b0; b < b1; ++b) {
+        const float* xr = x + b * ldx + m * DSUB;  // wave-uniform address
+        const float s = sqdist_exact<DSUB>(xr, c);
+        *drow = s;
+        drow += RC_K;
+        mx = fmaxf(mx, s);
+        mn = fminf(mn, s);
+    }
+    if (mm_part) {
+        __shared__ float smx[RC_K / 64], smn[RC_K / 64];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, o));
+            mn = fminf(mn, __shfl_xor(mn, o));
+        }
+        if ((k & 63) == 0) { smx[k >> 6] = mx; smn[k >> 6] = mn; }
+        __syncthreads();
+        if (k == 0) {
+#pragma unroll
+            for (int w = 1; w < RC_K / 64; ++w) { mx = fmaxf(mx, smx[w]); mn = fminf(mn, smn[w]); }
+            float* o = mm_part + ((size_t)m * gridDim.x + blockIdx.x) * 2;
+            o[0] = mx;
+            o[1] = mn;
+        }
+    }
+    (void)M;
+}
+
+// minmax[m] = max over blocks, minmax[M+m] = min over blocks (max/min are order independent).
+__global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restrict__ mm_part, int nblk,
+                                                           int M, float* __restrict__ minmax) {
+    const int m = blockIdx.x;
+    float mx = -INFINITY, mn = INFINITY;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        mx = fmaxf(mx, mm_part[((size_t)m * nblk + i) * 2]);
+        mn = fminf(mn, mm_part[((size_t)m * nblk + i) * 2 + 1]);
+    }
+    __shared__ float smx[4], smn[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        mn = fminf(mn, __shfl_xor(mn, o));
+    }
+    if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; smn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mx = fmaxf(mx, smx[w]); mn = fminf(mn, smn[w]); }
+        minmax[m] = mx;
+        minmax[M + m] = mn;
+    }
+}
+
+// (d - mid)/amp in place; mid=(mx+mn)/2, amp=(mx-mid)+1e-5f, IEEE fp32 division
+// (modeling_repconc.py:81-84).  grid.y = m, grid-stride over the B*K entries of that m.
+__global__ __launch_bounds__(256) void centre_kernel(float* __restrict__ d, const float* __restrict__ minmax,
+                                                     int64_t per_m, int M) {
+    const int m = blockIdx.y;
+    const float mx = minmax[m], mn = minmax[M + m];
+    const float mid = (mx + mn) / 2.0f;
+    const float amp = (mx - mid) + 1e-5f;
+    float4* p = reinterpret_cast<float4*>(d + (size_t)m * per_m);
+    const int64_t n4 = per_m / 4;  // per_m = B*256 is a multiple of 4
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = p[i];
+        v.x = (v.x - mid) / amp;
+        v.y = (v.y - mid) / amp;
+        v.z = (v.z - mid) / amp;
+        v.w = (v.w - mid) / amp;
+        p[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Nearest code (index build): thread = one row b, loop over sub-quantisers and centroids.
+// The row slice lives in VGPRs; C[m,k,:] is wave-uniform (scalar loads); running (min, argmin)
+// needs no cross-lane traffic.  First minimum wins (strict <), as torch.argmin does.
+// Codes are staged in LDS and written as one contiguous, coalesced [rows, M] byte slab.
+template <int DSUB>
+__global__ __launch_bounds__(256) void assign_nearest_kernel(const float* __restrict__ x, int64_t ldx,
+                                                             const float* __restrict__ C, int64_t B,
+                                                             int M, uint8_t* __restrict__ codes_u8,
+                                                             int64_t* __restrict__ codes_i64) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];  // [256][M]
+    const int tid = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * 256 + tid;
+    const bool live = b < B;
+    const float* xrow = x + (live ? b : (B - 1)) * ldx;
+    for (int m = 0; m < M; ++m) {
+        float xs[DSUB];
+        const float4* xp = reinterpret_cast<const float4*>(xrow + m * DSUB);
+#pragma unroll
+        for (int j = 0; j < DSUB / 4; ++j) {
+            const float4 v = xp[j];
+            xs[4 * j] = v.x; xs[4 * j + 1] = v.y; xs[4 * j + 2] = v.z; xs[4 * j + 3] = v.w;
+        }
+        const float* cm = C + (size_t)m * RC_K * DSUB;
+        float best = INFINITY;
+        int bi = 0;
+#pragma unroll 2
+        for (int k = 0; k < RC_K; ++k) {
+            const float s = sqdist_exact<DSUB>(xs, cm + k * DSUB);
+            if (s < best) { best = s; bi = k; }
+        }
+        tile[tid * M + m] = (unsigned char)bi;
+    }
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int64_t rows = (B - row0 < 256) ? (B - row0) : 256;
+    const int64_t nbytes = rows * M;
+    if (codes_u8) {
+        unsigned char* dst = codes_u8 + row0 * M;  // row0*M is a multiple of 16 (256*M)
+        const int64_t n16 = nbytes / 16;
+        for (int64_t i = tid; i < n16; i += 256)
+            reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(tile)[i];
+        for (int64_t i = n16 * 16 + tid; i < nbytes; i += 256) dst[i] = tile[i];
+    }
+    if (codes_i64) {
+        int64_t* dst = codes_i64 + row0 * M;
+        for (int64_t i = tid; i < nbytes; i += 256) dst[i] = (int64_t)tile[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static int dist_rows_per_block(int64_t B) { return B >= 16384 ? 128 : 32; }
+
+extern "C" size_t rc_pq_dist_table_ws_bytes(int64_t B, int M) {
+    if (B <= 0 || M <= 0) return 0;
+    const int rpb = dist_rows_per_block(B);
+    const int64_t nblk = (B + rpb - 1) / rpb;
+    return rc_align_up((size_t)M * nblk * 2 * sizeof(float), 256);
+}
+
+extern "C" int rc_pq_dist_table(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B,
+                                int D, int M, int K, float* d, float* minmax, void* ws, size_t ws_bytes,
+                                rc_stream_t stream) {
+    if (!h || !x || !C || !d || B < 0 || M <= 0 || D <= 0 || ldx < D) return RC_EINVAL;
+    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
+    if (B == 0) return RC_OK;
+    if (minmax && (!ws || ws_bytes < rc_pq_dist_table_ws_bytes(B, M))) return RC_EWORKSPACE;
+    const int rpb = dist_rows_per_block(B);
+    const int64_t nblk = (B + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = minmax ? (float*)ws : nullptr;
+    dim3 grid((unsigned)nblk, (unsigned)M);
+    RC_DISPATCH_DSUB(D / M, hipLaunchKernelGGL(dist_table_kernel<DSUB>, grid, dim3(RC_K), 0, s, x, ldx, C, B, rpb, d, part));
+    RC_LAUNCH_CHECK(h);
+    if (minmax) {
+        hipLaunchKernelGGL(minmax_final_kernel, dim3(M), dim3(256), 0, s, part, (int)nblk, M, minmax);
+        RC_LAUNCH_CHECK(h);
+    }
+    return RC_OK;
+}
+
+extern "C" int rc_pq_centre(rc_handle_t h, float* d, const float* minmax, int64_t B, int M, int K,
+                            rc_stream_t stream) {
+    if (!h || !d || !minmax || B < 0 || M <= 0) return RC_EINVAL;
+    if (K != RC_K) return RC_ESHAPE;
+    if (B == 0) return RC_OK;
+    const int64_t per_m = B * RC_K;
+    int64_t gx = (per_m / 4 + 255) / 256;
+    const int64_t cap = (int64_t)h->num_cus * 8;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(centre_kernel, dim3((unsigned)gx, (unsigned)M), dim3(256), 0, (hipStream_t)stream, d,
+                       minmax, per_m, M);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+extern "C" int rc_pq_assign_nearest(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B,
+                                    int D, int M, int K, uint8_t* codes_u8, int64_t* codes_i64,
+                                    rc_stream_t stream) {
+    if (!h || !x || !C || B < 0 || M <= 0 || D <= 0 || ldx < D || (!codes_u8 && !codes_i64)) return RC_EINVAL;
+    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
+    if (((uintptr_t)x & 15) || (ldx % 4) != 0) return RC_EINVAL;  // float4 row loads
+    if (B == 0) return RC_OK;
+    const int64_t nblk = (B + 255) / 256;
+    const size_t lds = (size_t)256 * M;
+    hipStream_t s = (hipStream_t)stream;
+    RC_DISPATCH_DSUB(D / M, hipLaunchKernelGGL(assign_nearest_kernel<DSUB>, dim3((unsigned)nblk), dim3(256), lds, s, x, ldx,
+                                               C, B, M, codes_u8, codes_i64));
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}

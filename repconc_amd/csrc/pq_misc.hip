@@ -1,0 +1,279 @@
+// Handle management plus the small byte/gather kernels of the path: decode (+ its gradient),
+// centroid normalisation, code histogram, k-means sufficient statistics and centroid update.
+#include "rc_common.h"
+
+#include <new>
+
+// ------------------------------------------------------------------------------------------ handle
+extern "C" int rc_version(void) { return 100; }
+
+extern "C" const char* rc_error_string(int code) {
+    switch (code) {
+        case RC_OK: return "ok";
+        case RC_EINVAL: return "invalid argument";
+        case RC_ESHAPE: return "unsupported shape (K must be 256, D/M one of 8,12,16,24,32,48,64,96)";
+        case RC_EHIP: return "HIP runtime error";
+        case RC_EWORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int rc_create(rc_handle_t* out, int device) {
+    if (!out) return RC_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return RC_EHIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RC_EHIP;
+    rc_handle_t h = new (std::nothrow) rc_handle_s;
+    if (!h) return RC_EINVAL;
+    h->device = device;
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->last_hip_error = 0;
+    *out = h;
+    return RC_OK;
+}
+
+extern "C" int rc_destroy(rc_handle_t h) {
+    delete h;
+    return RC_OK;
+}
+
+extern "C" int rc_last_hip_error(rc_handle_t h) { return h ? h->last_hip_error : 0; }
+extern "C" int rc_num_cus(rc_handle_t h) { return h ? h->num_cus : 0; }
+
+// ------------------------------------------------------------------------------------------ decode
+template <typename CodeT>
+__device__ __forceinline__ int load_code(const void* codes, int64_t i) {
+    return (int)reinterpret_cast<const CodeT*>(codes)[i];
+}
+
+// out[n, m*dsub + j] = C[m, codes[n,m], j].  One thread per float4 of the output row, so the
+// stores are fully coalesced; the centroid table (<= 786 KB) stays in L2.
+// modeling_repconc.py:168-175.
+template <typename CodeT>
+__global__ __launch_bounds__(256) void decode_kernel(const void* __restrict__ codes, const float* __restrict__ C,
+                                                     int64_t n, int M, int dsub, float* __restrict__ out) {
+    const int D4 = (M * dsub) / 4;
+    const int q4 = dsub / 4;  // float4 per sub-vector
+    const int64_t total = n * D4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / D4;
+        const int c4 = (int)(i - row * D4);
+        const int m = c4 / q4, j4 = c4 - m * q4;
+        const int code = load_code<CodeT>(codes, row * M + m) & (RC_K - 1);
+        reinterpret_cast<float4*>(out)[i] =
+            reinterpret_cast<const float4*>(C)[((size_t)m * RC_K + code) * q4 + j4];
+    }
+}
+
+// grad_C[m, codes[n,m], j] += grad_out[n, m*dsub + j]  (fp32 atomics; the reference's
+// index_put(accumulate) backward is equally order-free).
+template <typename CodeT>
+__global__ __launch_bounds__(256) void decode_bwd_kernel(const void* __restrict__ codes,
+                                                         const float* __restrict__ go, int64_t n, int M,
+                                                         int dsub, float* __restrict__ gC) {
+    const int D = M * dsub;
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / D;
+        const int c = (int)(i - row * D);
+        const int m = c / dsub, j = c - m * dsub;
+        const int code = load_code<CodeT>(codes, row * M + m) & (RC_K - 1);
+        atomicAdd(gC + ((size_t)m * RC_K + code) * dsub + j, go[i]);
+    }
+}
+
+static unsigned grid_for(rc_handle_t h, int64_t work_items) {
+    int64_t g = (work_items + 255) / 256;
+    const int64_t cap = (int64_t)h->num_cus * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+extern "C" int rc_pq_decode(rc_handle_t h, const void* codes, int code_dtype, const float* C, int64_t n, int M,
+                            int K, int dsub, float* out, rc_stream_t stream) {
+    if (!h || !codes || !C || !out || n < 0 || M <= 0 || dsub <= 0) return RC_EINVAL;
+    if (K != RC_K || dsub % 4 != 0) return RC_ESHAPE;
+    if (n == 0) return RC_OK;
+    const unsigned g = grid_for(h, n * (M * dsub / 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (code_dtype == RC_CODE_U8)
+        hipLaunchKernelGGL(decode_kernel<uint8_t>, dim3(g), dim3(256), 0, s, codes, C, n, M, dsub, out);
+    else if (code_dtype == RC_CODE_I64)
+        hipLaunchKernelGGL(decode_kernel<int64_t>, dim3(g), dim3(256), 0, s, codes, C, n, M, dsub, out);
+    else
+        return RC_EINVAL;
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+extern "C" int rc_pq_decode_bwd(rc_handle_t h, const void* codes, int code_dtype, const float* grad_out,
+                                int64_t n, int M, int K, int dsub, float* grad_C, rc_stream_t stream) {
+    if (!h || !codes || !grad_out || !grad_C || n < 0 || M <= 0 || dsub <= 0) return RC_EINVAL;
+    if (K != RC_K) return RC_ESHAPE;
+    if (n == 0) return RC_OK;
+    const unsigned g = grid_for(h, n * M * dsub);
+    hipStream_t s = (hipStream_t)stream;
+    if (code_dtype == RC_CODE_U8)
+        hipLaunchKernelGGL(decode_bwd_kernel<uint8_t>, dim3(g), dim3(256), 0, s, codes, grad_out, n, M, dsub, grad_C);
+    else if (code_dtype == RC_CODE_I64)
+        hipLaunchKernelGGL(decode_bwd_kernel<int64_t>, dim3(g), dim3(256), 0, s, codes, grad_out, n, M, dsub, grad_C);
+    else
+        return RC_EINVAL;
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ normalise
+// C[m,k,:] /= max(||C[m,k,:]||_2, 1e-12)  — F.normalize(p=2, dim=-1), modeling_repconc.py:112-116.
+// Plain j-ascending sum of squares: torch's vectorised norm may round differently in the last
+// ulp, so this op is specified to 1e-6 relative (METRIC_CENTROID_COS is set by no shipped recipe).
+__global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ C, int64_t rows, int dsub) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float* p = C + r * dsub;
+    float s = 0.f;
+    for (int j = 0; j < dsub; ++j) s = s + p[j] * p[j];
+    const float nrm = fmaxf(sqrtf(s), 1e-12f);
+    for (int j = 0; j < dsub; ++j) p[j] = p[j] / nrm;
+}
+
+extern "C" int rc_normalize_centroids(rc_handle_t h, float* C, int M, int K, int dsub, rc_stream_t stream) {
+    if (!h || !C || M <= 0 || K <= 0 || dsub <= 0) return RC_EINVAL;
+    const int64_t rows = (int64_t)M * K;
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C,
+                       rows, dsub);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ histogram
+// hist[m][k] = #{n : codes[n,m] == k}.  Block = (row strip, group of 4 sub-quantisers); counts are
+// privatised in LDS (ds_add_u32) and flushed with one global atomic per non-empty bin.
+// finetune_repconc.py:588-592.
+#define HIST_MG 4
+template <typename CodeT>
+__global__ __launch_bounds__(256) void hist_kernel(const void* __restrict__ codes, int64_t n, int M,
+                                                   int rows_per_block, int32_t* __restrict__ hist) {
+    __shared__ int cnt[HIST_MG][RC_K];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HIST_MG * RC_K; i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int m0 = blockIdx.y * HIST_MG;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
+    for (int64_t r = r0 + tid; r < r1; r += 256) {
+#pragma unroll
+        for (int q = 0; q < HIST_MG; ++q)
+            if (m0 + q < M) atomicAdd(&cnt[q][load_code<CodeT>(codes, r * M + m0 + q) & (RC_K - 1)], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < HIST_MG * RC_K; i += 256) {
+        const int q = i / RC_K, k = i - q * RC_K;
+        const int c = cnt[q][k];
+        if (c && m0 + q < M) atomicAdd(hist + (size_t)(m0 + q) * RC_K + k, c);
+    }
+}
+
+extern "C" int rc_code_hist(rc_handle_t h, const void* codes, int code_dtype, int64_t n, int M, int K,
+                            int32_t* hist, rc_stream_t stream) {
+    if (!h || !codes || !hist || n < 0 || M <= 0) return RC_EINVAL;
+    if (K != RC_K) return RC_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    RC_HIP_CHECK(h, hipMemsetAsync(hist, 0, (size_t)M * RC_K * sizeof(int32_t), s));
+    if (n == 0) return RC_OK;
+    const int rpb = 4096;
+    dim3 grid((unsigned)((n + rpb - 1) / rpb), (unsigned)((M + HIST_MG - 1) / HIST_MG));
+    if (code_dtype == RC_CODE_U8)
+        hipLaunchKernelGGL(hist_kernel<uint8_t>, grid, dim3(256), 0, s, codes, n, M, rpb, hist);
+    else if (code_dtype == RC_CODE_I64)
+        hipLaunchKernelGGL(hist_kernel<int64_t>, grid, dim3(256), 0, s, codes, n, M, rpb, hist);
+    else
+        return RC_EINVAL;
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ k-means
+// Lloyd sufficient statistics for one sub-quantiser per block column: sums[m][k][:] (fp64) and
+// counts[m][k].  A block owns (row strip, m); the K x dsub fp64 accumulator is privatised in LDS
+// (K*dsub*8 = 32 KiB at dsub 16, 128 KiB at dsub 64; dsub 96 is processed in two halves) and
+// merged with fp64 global atomics.  fp64 makes the merge order irrelevant to ~1e-16, so per-rank
+// statistics can be summed in any order (train/run_warmup.py:113 runs this inside Faiss).
+__global__ __launch_bounds__(256) void kmeans_stats_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const uint8_t* __restrict__ codes, int64_t n, int M,
+                                                           int dsub, int j0, int jn, int rows_per_block,
+                                                           double* __restrict__ sums,
+                                                           unsigned long long* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) double acc[];  // [K][jn] then counts [K] (as u32)
+    unsigned* cnt = reinterpret_cast<unsigned*>(acc + (size_t)RC_K * jn);
+    const int tid = threadIdx.x;
+    const int m = blockIdx.y;
+    for (int i = tid; i < RC_K * jn; i += 256) acc[i] = 0.0;
+    for (int i = tid; i < RC_K; i += 256) cnt[i] = 0u;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
+    // jn consecutive lanes cooperate on one row: lane j adds x[row, m*dsub + j0 + j]
+    const int rows_in_flight = 256 / jn;
+    const int jr = tid % jn, rr = tid / jn;
+    if (rr < rows_in_flight) {
+        for (int64_t r = r0 + rr; r < r1; r += rows_in_flight) {
+            const int k = codes[r * M + m];
+            atomicAdd(&acc[(size_t)k * jn + jr], (double)x[r * ldx + m * dsub + j0 + jr]);
+            if (jr == 0 && j0 == 0) atomicAdd(&cnt[k], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < RC_K * jn; i += 256) {
+        const int k = i / jn, j = i - k * jn;
+        const double v = acc[i];
+        if (v != 0.0) atomicAdd(sums + ((size_t)m * RC_K + k) * dsub + j0 + j, v);
+    }
+    if (j0 == 0)
+        for (int i = tid; i < RC_K; i += 256)
+            if (cnt[i]) atomicAdd(counts + (size_t)m * RC_K + i, (unsigned long long)cnt[i]);
+}
+
+extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const uint8_t* codes, int64_t n, int D,
+                               int M, int K, double* sums, int64_t* counts, rc_stream_t stream) {
+    if (!h || !x || !codes || !sums || !counts || n < 0 || M <= 0 || D <= 0 || ldx < D) return RC_EINVAL;
+    if (K != RC_K || D % M != 0) return RC_ESHAPE;
+    const int dsub = D / M;
+    if (dsub > 256) return RC_ESHAPE;
+    if (n == 0) return RC_OK;
+    const int rpb = 8192;
+    dim3 grid((unsigned)((n + rpb - 1) / rpb), (unsigned)M);
+    const int jmax = 48;  // K*48*8 = 96 KiB of LDS per pass
+    for (int j0 = 0; j0 < dsub; j0 += jmax) {
+        const int jn = (dsub - j0 < jmax) ? dsub - j0 : jmax;
+        const size_t lds = (size_t)RC_K * jn * sizeof(double) + RC_K * sizeof(unsigned);
+        hipLaunchKernelGGL(kmeans_stats_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, ldx, codes, n, M, dsub,
+                           j0, jn, rpb, sums, reinterpret_cast<unsigned long long*>(counts));
+        RC_LAUNCH_CHECK(h);
+    }
+    return RC_OK;
+}
+
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const double* __restrict__ sums,
+                                                            const long long* __restrict__ counts,
+                                                            float* __restrict__ C, int64_t total, int dsub) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long c = counts[i / dsub];
+    if (c > 0) C[i] = (float)(sums[i] / (double)c);
+}
+
+extern "C" int rc_kmeans_update(rc_handle_t h, const double* sums, const int64_t* counts, float* C, int M, int K,
+                                int dsub, rc_stream_t stream) {
+    if (!h || !sums || !counts || !C || M <= 0 || dsub <= 0) return RC_EINVAL;
+    if (K != RC_K) return RC_ESHAPE;
+    const int64_t total = (int64_t)M * K * dsub;
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       sums, reinterpret_cast<const long long*>(counts), C, total, dsub);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}

@@ -1,0 +1,71 @@
+// Shared declarations for librepconc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/repconc_hip.h"
+
+struct rc_handle_s {
+    int device;
+    int num_cus;
+    int last_hip_error;
+};
+
+#define RC_K 256  // centroids per sub-quantiser (reference asserts MCQ_K == 256)
+
+#define RC_HIP_CHECK(h, expr)                                   \
+    do {                                                        \
+        hipError_t _e = (expr);                                 \
+        if (_e != hipSuccess) {                                 \
+            if (h) (h)->last_hip_error = (int)_e;               \
+            return RC_EHIP;                                     \
+        }                                                       \
+    } while (0)
+
+#define RC_LAUNCH_CHECK(h) RC_HIP_CHECK(h, hipGetLastError())
+
+static inline bool rc_dsub_supported(int dsub) {
+    return dsub == 8 || dsub == 12 || dsub == 16 || dsub == 24 || dsub == 32 || dsub == 48 ||
+           dsub == 64 || dsub == 96;
+}
+
+static inline size_t rc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// dispatch a template<int DSUB> callable over the supported sub-vector widths
+#define RC_DISPATCH_DSUB(dsub, ...)             \
+    switch (dsub) {                               \
+        case 8:  { constexpr int DSUB = 8;  __VA_ARGS__; } break;  \
+        case 12: { constexpr int DSUB = 12; __VA_ARGS__; } break;  \
+        case 16: { constexpr int DSUB = 16; __VA_ARGS__; } break;  \
+        case 24: { constexpr int DSUB = 24; __VA_ARGS__; } break;  \
+        case 32: { constexpr int DSUB = 32; __VA_ARGS__; } break;  \
+        case 48: { constexpr int DSUB = 48; __VA_ARGS__; } break;  \
+        case 64: { constexpr int DSUB = 64; __VA_ARGS__; } break;  \
+        case 96: { constexpr int DSUB = 96; __VA_ARGS__; } break;  \
+        default: return RC_ESHAPE;                \
+    }
+
+// ---- wave64 DPP helpers -------------------------------------------------------------------
+// rotate right by N lanes inside each row of 16 lanes (DPP row_ror:N, ctrl 0x120+N)
+template <int N>
+__device__ __forceinline__ int rc_dpp_row_ror(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ double rc_dpp_row_ror(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = rc_dpp_row_ror<N>(lo);
+    hi = rc_dpp_row_ror<N>(hi);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce (sum) of a double over each row of 16 lanes.  With power-of-two rotations lane i
+// computes ((x_i+x_{i+8})+(x_{i+4}+x_{i+12}))+…: the same balanced tree on every lane up to
+// commutation of each addition, so all 16 lanes end with identical bits.
+__device__ __forceinline__ double rc_row16_allreduce_sum(double v) {
+    v += rc_dpp_row_ror<8>(v);
+    v += rc_dpp_row_ror<4>(v);
+    v += rc_dpp_row_ror<2>(v);
+    v += rc_dpp_row_ror<1>(v);
+    return v;
+}

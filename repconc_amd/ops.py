@@ -1,0 +1,326 @@
+"""Tensor-level wrappers over the C ABI (include/repconc_hip.h).
+
+Every function takes CUDA(=HIP) torch tensors, launches on `torch.cuda.current_stream()` of the
+tensor's device and returns without synchronising.  torch is used for memory and streams only;
+all arithmetic happens in librepconc_hip.so.  CPU tensors are rejected: there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+K = 256
+SUPPORTED_DSUB = (8, 12, 16, 24, 32, 48, 64, 96)
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.RepconcHipError(
+                "repconc_amd runs on the GPU only (got a CPU tensor); the package has no CPU fallback")
+
+
+def _ctx(t: torch.Tensor):
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return _lib.load(), _lib.handle(dev), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), dev
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _rows_f32(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [B, D] with unit inner stride and 16-byte aligned rows (fp16/bf16 inputs are promoted
+    exactly like the reference's fp32 centroids promote them)."""
+    if x.dim() != 2:
+        raise ValueError("expected a [B, D] matrix")
+    if x.dtype != torch.float32:
+        x = x.float()
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        x = x.contiguous()
+    return x
+
+
+def _centroids(c: torch.Tensor) -> torch.Tensor:
+    if c.dim() != 3 or c.shape[1] != K:
+        raise ValueError("centroids must be [M, 256, dsub]")
+    c = c.detach()
+    if c.dtype != torch.float32 or not c.is_contiguous():
+        c = c.float().contiguous()
+    return c
+
+
+def _shape(x: torch.Tensor, c: torch.Tensor):
+    B, D = x.shape
+    M, _, dsub = c.shape
+    if D != M * dsub:
+        raise ValueError(f"embedding width {D} != M*dsub = {M}*{dsub}")
+    if dsub not in SUPPORTED_DSUB:
+        raise _lib.RepconcHipError(f"dsub={dsub} unsupported (one of {SUPPORTED_DSUB})")
+    return B, D, M, dsub
+
+
+def _code_dtype(codes: torch.Tensor) -> int:
+    if codes.dtype == torch.uint8:
+        return _lib.RC_CODE_U8
+    if codes.dtype == torch.int64:
+        return _lib.RC_CODE_I64
+    raise ValueError("codes must be uint8 or int64")
+
+
+# --------------------------------------------------------------------------- nearest codes
+def assign_nearest(x: torch.Tensor, centroids: torch.Tensor, dtype=torch.int64) -> torch.Tensor:
+    """argmin_k ||x_m - C[m,k]||^2 -> codes [B, M].  modeling_repconc.py:49-52,66."""
+    _need_cuda(x, centroids)
+    x, c = _rows_f32(x), _centroids(centroids)
+    B, D, M, _ = _shape(x, c)
+    lib, h, s, _ = _ctx(x)
+    codes = torch.empty((B, M), dtype=dtype, device=x.device)
+    if B == 0:
+        return codes
+    u8 = codes if dtype == torch.uint8 else None
+    i64 = codes if dtype == torch.int64 else None
+    if u8 is None and i64 is None:
+        raise ValueError("dtype must be torch.uint8 or torch.int64")
+    _lib.check(lib.rc_pq_assign_nearest(h, _p(x), x.stride(0), _p(c), B, D, M, K, _p(u8), _p(i64), s),
+               "rc_pq_assign_nearest", h)
+    return codes
+
+
+# --------------------------------------------------------------------------- distance table
+def dist_table(x: torch.Tensor, centroids: torch.Tensor, with_minmax: bool = True):
+    """d [M,B,K] fp32 (+ minmax [2M]: max then min per m).  modeling_repconc.py:50,76-77."""
+    _need_cuda(x, centroids)
+    x, c = _rows_f32(x), _centroids(centroids)
+    B, D, M, _ = _shape(x, c)
+    lib, h, s, _ = _ctx(x)
+    d = torch.empty((M, B, K), dtype=torch.float32, device=x.device)
+    mm = torch.empty((2 * M,), dtype=torch.float32, device=x.device) if with_minmax else None
+    wsb = lib.rc_pq_dist_table_ws_bytes(B, M)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.rc_pq_dist_table(h, _p(x), x.stride(0), _p(c), B, D, M, K, _p(d), _p(mm), _p(ws), wsb, s),
+               "rc_pq_dist_table", h)
+    return d, mm
+
+
+def centre_(d: torch.Tensor, minmax: torch.Tensor) -> torch.Tensor:
+    """In-place center_distance_for_constraint, modeling_repconc.py:81-84."""
+    _need_cuda(d, minmax)
+    M, B, _ = d.shape
+    lib, h, s, _ = _ctx(d)
+    _lib.check(lib.rc_pq_centre(h, _p(d), _p(minmax), B, M, K, s), "rc_pq_centre", h)
+    return d
+
+
+# --------------------------------------------------------------------------- Sinkhorn stages
+class SinkhornState:
+    """Device buffers of one rank's Sinkhorn solve over a centred table d [M,B,K]."""
+
+    def __init__(self, d: torch.Tensor):
+        _need_cuda(d)
+        self.d = d
+        self.M, self.B, _ = d.shape
+        dev = d.device
+        self.f = torch.empty((self.M, K), dtype=torch.float64, device=dev)
+        self.g = torch.zeros((self.M, self.B), dtype=torch.float64, device=dev)
+        self.colsum = torch.empty((self.M, self.B), dtype=torch.float64, device=dev)
+        self.rows = torch.empty((self.M, K), dtype=torch.float64, device=dev)
+        self.flags = torch.zeros((1,), dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        self._wsb = lib.rc_sk_pass_ws_bytes(self.B, self.M, K)
+        self._ws = torch.empty((max(self._wsb, 1),), dtype=torch.uint8, device=dev)
+
+    def sweep(self, eps: float, first: bool) -> torch.Tensor:
+        lib, h, s, _ = _ctx(self.d)
+        _lib.check(lib.rc_sk_pass(h, _p(self.d), _p(self.f), _p(self.g), _p(self.colsum), _p(self.rows), self.B,
+                                  self.M, K, float(eps), int(first), _p(self._ws), self._wsb, s), "rc_sk_pass", h)
+        return self.rows
+
+    def update(self, rows_all: torch.Tensor, first: bool):
+        G = 1 if rows_all.dim() == 2 else rows_all.shape[0]
+        lib, h, s, _ = _ctx(self.d)
+        _lib.check(lib.rc_sk_update(h, _p(rows_all), G, _p(self.f), _p(self.g), _p(self.colsum), self.B, self.M, K,
+                                    int(first), _p(self.flags), s), "rc_sk_update", h)
+
+    def argmax(self, eps: float, dtype=torch.int64) -> torch.Tensor:
+        lib, h, s, _ = _ctx(self.d)
+        codes = torch.empty((self.B, self.M), dtype=dtype, device=self.d.device)
+        u8 = codes if dtype == torch.uint8 else None
+        i64 = codes if dtype == torch.int64 else None
+        _lib.check(lib.rc_sk_argmax(h, _p(self.d), _p(self.f), self.B, self.M, K, float(eps), _p(u8), _p(i64), s),
+                   "rc_sk_argmax", h)
+        return codes
+
+
+def assign_sinkhorn(x: torch.Tensor, centroids: torch.Tensor, eps: float, iters: int,
+                    dtype=torch.int64) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Single-rank constrained codes [B,M] + flags (int32[1]).  modeling_repconc.py:47-67 with
+    dist.is_initialized()==False.  One C call: distance table, centring, `iters` Sinkhorn
+    iterations, argmax."""
+    _need_cuda(x, centroids)
+    x, c = _rows_f32(x), _centroids(centroids)
+    B, D, M, _ = _shape(x, c)
+    lib, h, s, _ = _ctx(x)
+    codes = torch.empty((B, M), dtype=dtype, device=x.device)
+    flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
+    if B == 0:
+        return codes, flags
+    wsb = lib.rc_pq_assign_sinkhorn_ws_bytes(B, M, K)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    u8 = codes if dtype == torch.uint8 else None
+    i64 = codes if dtype == torch.int64 else None
+    _lib.check(lib.rc_pq_assign_sinkhorn(h, _p(x), x.stride(0), _p(c), B, D, M, K, float(eps), int(iters),
+                                         _p(u8), _p(i64), _p(flags), _p(ws), wsb, s), "rc_pq_assign_sinkhorn", h)
+    return codes, flags
+
+
+# --------------------------------------------------------------------------- decode
+def decode_raw(codes: torch.Tensor, centroids: torch.Tensor) -> torch.Tensor:
+    _need_cuda(codes, centroids)
+    c = _centroids(centroids)
+    M, _, dsub = c.shape
+    if codes.dim() != 2 or codes.shape[1] != M:
+        raise ValueError("codes must be [n, M]")
+    codes = codes.contiguous()
+    n = codes.shape[0]
+    out = torch.empty((n, M * dsub), dtype=torch.float32, device=codes.device)
+    lib, h, s, _ = _ctx(codes)
+    _lib.check(lib.rc_pq_decode(h, _p(codes), _code_dtype(codes), _p(c), n, M, K, dsub, _p(out), s),
+               "rc_pq_decode", h)
+    return out
+
+
+class _DecodeFn(torch.autograd.Function):
+    """decode with the scatter-add gradient into the centroids (autograd of the gather at
+    modeling_repconc.py:175)."""
+
+    @staticmethod
+    def forward(ctx, codes, centroids):
+        ctx.save_for_backward(codes)
+        ctx.cshape = tuple(centroids.shape)
+        ctx.cdtype = centroids.dtype
+        return decode_raw(codes, centroids)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (codes,) = ctx.saved_tensors
+        M, _, dsub = ctx.cshape
+        go = grad_out.float().contiguous()
+        gC = torch.zeros(ctx.cshape, dtype=torch.float32, device=go.device)
+        codes = codes.contiguous()
+        lib, h, s, _ = _ctx(go)
+        _lib.check(lib.rc_pq_decode_bwd(h, _p(codes), _code_dtype(codes), _p(go), codes.shape[0], M, K, dsub,
+                                        _p(gC), s), "rc_pq_decode_bwd", h)
+        return None, gC.to(ctx.cdtype)
+
+
+def decode(codes: torch.Tensor, centroids: torch.Tensor) -> torch.Tensor:
+    if centroids.requires_grad and torch.is_grad_enabled():
+        return _DecodeFn.apply(codes, centroids)
+    return decode_raw(codes, centroids)
+
+
+# --------------------------------------------------------------------------- small ops
+def normalize_centroids_(centroids: torch.Tensor) -> torch.Tensor:
+    _need_cuda(centroids)
+    if centroids.dtype != torch.float32 or not centroids.is_contiguous():
+        raise ValueError("centroids must be contiguous fp32")
+    M, Kc, dsub = centroids.shape
+    lib, h, s, _ = _ctx(centroids)
+    _lib.check(lib.rc_normalize_centroids(h, _p(centroids), M, Kc, dsub, s), "rc_normalize_centroids", h)
+    return centroids
+
+
+def code_hist(codes: torch.Tensor) -> torch.Tensor:
+    """hist [M, 256] int32.  finetune_repconc.py:588-592 for every sub-quantiser."""
+    _need_cuda(codes)
+    codes = codes.contiguous()
+    n, M = codes.shape
+    hist = torch.empty((M, K), dtype=torch.int32, device=codes.device)
+    lib, h, s, _ = _ctx(codes)
+    _lib.check(lib.rc_code_hist(h, _p(codes), _code_dtype(codes), n, M, K, _p(hist), s), "rc_code_hist", h)
+    return hist
+
+
+def kmeans_stats(x: torch.Tensor, codes: torch.Tensor, sums: Optional[torch.Tensor] = None,
+                 counts: Optional[torch.Tensor] = None):
+    """Accumulate Lloyd sufficient statistics (sums [M,K,dsub] fp64, counts [M,K] int64)."""
+    _need_cuda(x, codes)
+    x = _rows_f32(x)
+    n, D = x.shape
+    M = codes.shape[1]
+    if codes.dtype != torch.uint8:
+        codes = codes.to(torch.uint8)
+    codes = codes.contiguous()
+    dsub = D // M
+    if sums is None:
+        sums = torch.zeros((M, K, dsub), dtype=torch.float64, device=x.device)
+    if counts is None:
+        counts = torch.zeros((M, K), dtype=torch.int64, device=x.device)
+    lib, h, s, _ = _ctx(x)
+    _lib.check(lib.rc_kmeans_stats(h, _p(x), x.stride(0), _p(codes), n, D, M, K, _p(sums), _p(counts), s),
+               "rc_kmeans_stats", h)
+    return sums, counts
+
+
+def kmeans_update_(sums: torch.Tensor, counts: torch.Tensor, centroids: torch.Tensor) -> torch.Tensor:
+    _need_cuda(sums, counts, centroids)
+    M, Kc, dsub = centroids.shape
+    lib, h, s, _ = _ctx(centroids)
+    _lib.check(lib.rc_kmeans_update(h, _p(sums), _p(counts), _p(centroids), M, Kc, dsub, s), "rc_kmeans_update", h)
+    return centroids
+
+
+# --------------------------------------------------------------------------- ADC search
+def adc_lut(centroids: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    _need_cuda(centroids, q)
+    c, q = _centroids(centroids), _rows_f32(q).contiguous()
+    M, _, dsub = c.shape
+    nq, D = q.shape
+    lut = torch.empty((nq, M, K), dtype=torch.float32, device=q.device)
+    lib, h, s, _ = _ctx(q)
+    _lib.check(lib.rc_adc_lut(h, _p(c), _p(q), nq, D, M, K, _p(lut), s), "rc_adc_lut", h)
+    return lut
+
+
+def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k: int, id_offset: int = 0,
+               sel_slack: float = 6.0, max_retries: int = 3):
+    """Top-k inner-product ADC search of `q` [nq,D] against uint8 `codes` [N,M].
+    Returns (scores [nq,k] fp32, ids [nq,k] int64), sorted (score desc, id asc).
+    evaluate_repconc.py:180-185 / finetune_jpq.py:176."""
+    _need_cuda(codes, centroids, q)
+    if codes.dtype != torch.uint8 or not codes.is_contiguous():
+        raise ValueError("index codes must be contiguous uint8 [N, M]")
+    c, q = _centroids(centroids), _rows_f32(q).contiguous()
+    N, M = codes.shape
+    nq, D = q.shape
+    if D != M * c.shape[2]:
+        raise ValueError("query width does not match the centroid table")
+    lib, h, s, _ = _ctx(q)
+    scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+    if nq == 0:
+        return scores, ids
+    if N == 0:
+        return scores.fill_(float("-inf")), ids.fill_(-1)
+    wsb = lib.rc_adc_search_ws_bytes(N, M, K, nq, k)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
+    status = torch.zeros((1,), dtype=torch.int32, device=q.device)
+    slack = float(sel_slack)
+    for _ in range(max_retries + 1):
+        status.zero_()
+        _lib.check(lib.rc_adc_search(h, _p(codes), N, M, K, _p(c), D, _p(q), nq, int(k), int(id_offset), slack,
+                                     _p(scores), _p(ids), _p(status), _p(ws), wsb, s), "rc_adc_search", h)
+        st = int(status.item())
+        if st == 0:
+            return scores, ids
+        # bit0: too few candidates (threshold too high) -> widen; bit1: overflow -> tighten
+        slack = slack * 3.0 + 2.0 if (st & 1) else max(slack / 3.0, 0.0)
+    raise _lib.RepconcHipError(f"ADC candidate selection did not converge (status {st}); "
+                               "the index probably holds thousands of identical codes")

@@ -1,0 +1,117 @@
+"""Batch-sharded constrained assignment: the `dist.is_initialized()` branch of RepCONC.quantize.
+
+Reference: models/repconc/modeling_repconc.py:78-80 (all_reduce MAX/MIN of the per-m distance
+range) and :149-157 (all_reduce SUM of the total and, every iteration, of the row sums).  Each
+rank holds an equal row block of the batch (the recipes use --dataloader_drop_last); the
+uniform-assignment constraint is over the GLOBAL batch.
+
+MI355X mapping (SURVEY.md §5 "Distributed comm backend"): per Sinkhorn iteration every rank
+contributes its [M,256] fp64 row sums (98 KB at M=48); they are ALL-GATHERED and summed locally
+in rank order, so every rank computes bit-identical potentials and the codes cannot diverge
+between ranks.  The global total of :148-152 cancels in the argmax and needs no collective.
+Collectives go through torch.distributed (backend "nccl" = RCCL over xGMI) on the same stream
+as the kernels.
+
+The driver below is written against two small interfaces so the same choreography runs
+  * on GPUs with the HIP kernels (`HipStages`, the product path),
+  * as G virtual shards inside one process (`VirtualComm`, used on single-GPU boxes), and
+  * under gloo on CPU in the test-suite, where tests inject a numpy stand-in for the stages.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+# ----------------------------------------------------------------------------- communicators
+class TorchDistComm:
+    """One rank of a torch.distributed process group."""
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def allreduce_minmax_(self, minmax: torch.Tensor, M: int):
+        dist.all_reduce(minmax[:M], op=dist.ReduceOp.MAX, group=self.group)    # :79
+        dist.all_reduce(minmax[M:], op=dist.ReduceOp.MIN, group=self.group)    # :80
+
+    def allgather(self, t: torch.Tensor) -> torch.Tensor:
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
+        return out
+
+
+class SingleComm:
+    world, rank = 1, 0
+
+    def allreduce_minmax_(self, minmax, M):
+        pass
+
+    def allgather(self, t):
+        return t.unsqueeze(0)
+
+
+# ----------------------------------------------------------------------------- HIP stages
+class HipStages:
+    """The product implementation of the per-rank stages (librepconc_hip.so)."""
+
+    def dist_table(self, x, centroids):
+        from . import ops
+        return ops.dist_table(x, centroids, with_minmax=True)
+
+    def centre_(self, d, minmax):
+        from . import ops
+        return ops.centre_(d, minmax)
+
+    def state(self, d):
+        from . import ops
+        return ops.SinkhornState(d)
+
+
+# ----------------------------------------------------------------------------- driver
+def assign_sinkhorn_sharded(x_local, centroids, eps: float, iters: int, comm, stages=None,
+                            dtype=torch.int64):
+    """Constrained codes for this rank's rows.  Returns (codes [B_local, M], flags)."""
+    stages = stages or HipStages()
+    M = centroids.shape[0]
+    d, minmax = stages.dist_table(x_local, centroids)
+    comm.allreduce_minmax_(minmax, M)
+    stages.centre_(d, minmax)
+    st = stages.state(d)
+    rows = st.sweep(eps, first=True)
+    st.update(comm.allgather(rows), first=True)
+    for _ in range(1, iters):
+        rows = st.sweep(eps, first=False)
+        st.update(comm.allgather(rows), first=False)
+    return st.argmax(eps, dtype), st.flags
+
+
+def assign_sinkhorn_virtual(x_shards: Sequence, centroids, eps: float, iters: int, stages=None,
+                            dtype=torch.int64) -> List:
+    """Run G shards of one batch in lock-step inside ONE process: the same stage calls and the
+    same rank-ordered reduction as `assign_sinkhorn_sharded`, with the collectives replaced by
+    local max/min/stack.  Used where only one device is visible (RCCL refuses two ranks on one
+    GPU) and by the `sharded == unsharded` parity tests."""
+    stages = stages or HipStages()
+    M = centroids.shape[0]
+    tabs = [stages.dist_table(x, centroids) for x in x_shards]
+    mm = tabs[0][1].clone()
+    for _, other in tabs[1:]:
+        mm[:M] = torch.maximum(mm[:M], other[:M])
+        mm[M:] = torch.minimum(mm[M:], other[M:])
+    states = []
+    for d, _ in tabs:
+        stages.centre_(d, mm)
+        states.append(stages.state(d))
+    first = True
+    for _ in range(iters):
+        rows_all = torch.stack([st.sweep(eps, first=first).clone() for st in states], dim=0)
+        for st in states:
+            st.update(rows_all, first=first)
+        first = False
+    return [st.argmax(eps, dtype) for st in states], [st.flags for st in states]

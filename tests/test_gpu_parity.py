@@ -1,0 +1,363 @@
+"""Parity of the HIP path (through the C ABI) with the reference's golden vectors and the oracle.
+Bit-exact for codes and for the fp32 distance / centring stage."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_cases, load_case
+from oracle import c_oracle, pq_oracle, synth
+
+pytestmark = pytest.mark.gpu
+EPS, ITERS = 0.003, 100
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_nearest_codes_bit_exact(name):
+    from repconc_amd import ops
+    g, x, C = load_case(name)
+    for dt in (torch.uint8, torch.int64):
+        codes = ops.assign_nearest(_t(x), _t(C), dt)
+        assert codes.dtype == dt
+        assert np.array_equal(codes.cpu().numpy().astype(np.uint8), g["codes_nearest"])
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_constrained_codes_bit_exact(name):
+    from repconc_amd import ops
+    g, x, C = load_case(name)
+    codes, flags = ops.assign_sinkhorn(_t(x), _t(C), EPS, ITERS)
+    assert int(flags.item()) == 0
+    got = codes.cpu().numpy().astype(np.uint8)
+    assert int((got != g["codes_constrained"]).sum()) == 0
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_fp32_stage_bitwise(name):
+    from repconc_amd import ops
+    g, x, C = load_case(name)
+    d, mm = ops.dist_table(_t(x), _t(C))
+    M = d.shape[0]
+    idx = g["samp_idx"]
+    dn = d.cpu().numpy()
+    assert np.array_equal(dn[idx[:, 0], idx[:, 1], idx[:, 2]].view(np.uint32), g["samp_dist_bits"])
+    mmn = mm.cpu().numpy()
+    assert np.array_equal(mmn[:M].view(np.uint32), g["mx_bits"])
+    assert np.array_equal(mmn[M:].view(np.uint32), g["mn_bits"])
+    ops.centre_(d, mm)
+    dn = d.cpu().numpy()
+    assert np.array_equal(dn[idx[:, 0], idx[:, 1], idx[:, 2]].view(np.uint32), g["samp_centred_bits"])
+    # whole table against the C oracle, every bit
+    ref = c_oracle.dist_table(x, C)
+    c_oracle.centre_(ref, c_oracle.minmax(ref))
+    assert np.array_equal(dn.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,shards", [("m8_b2048_sample", 2), ("m8_b2048_sample", 4), ("m48_b1024_sample", 2),
+                                         ("m48_b1024_sample", 4), ("m48_b6144_sample", 8)])
+def test_virtual_shards_equal_unsharded(name, shards):
+    """The collective choreography (rank-ordered sum of all-gathered row sums) on G virtual ranks."""
+    from repconc_amd.sharded import assign_sinkhorn_virtual
+    g, x, C = load_case(name)
+    B = x.shape[0]
+    bl = B // shards
+    xs = [_t(x[r * bl:(r + 1) * bl]) for r in range(shards)]
+    codes, flags = assign_sinkhorn_virtual(xs, _t(C), EPS, ITERS)
+    got = torch.cat(codes, 0).cpu().numpy().astype(np.uint8)
+    assert all(int(f.item()) == 0 for f in flags)
+    assert np.array_equal(got, g["codes_constrained"])
+
+
+def test_strided_and_half_inputs():
+    from repconc_amd import ops
+    g, x, C = load_case("m48_b1024_sample")
+    wide = torch.zeros((1024, 1024), dtype=torch.float32, device=DEV)
+    wide[:, :768] = _t(x)
+    codes = ops.assign_nearest(wide[:, :768], _t(C), torch.uint8)           # ldx = 1024
+    assert np.array_equal(codes.cpu().numpy(), g["codes_nearest"])
+    xh = _t(x).half()                                                       # promoted to fp32 like the reference
+    want = pq_oracle.quantize(xh.float().cpu().numpy(), C, False).astype(np.uint8)
+    assert np.array_equal(ops.assign_nearest(xh, _t(C), torch.uint8).cpu().numpy(), want)
+
+
+def test_empty_and_tiny_batches():
+    from repconc_amd import ops
+    _, x, C = load_case("m48_b1024_sample")
+    assert ops.assign_nearest(_t(x[:0]), _t(C)).shape == (0, 48)
+    codes, _ = ops.assign_sinkhorn(_t(x[:0]), _t(C), EPS, ITERS)
+    assert codes.shape == (0, 48)
+    for B in (1, 3, 100):                                                   # B < K: every code distinct
+        want, _ = c_oracle.quantize(x[:B], C, True, EPS, ITERS)
+        got, fl = ops.assign_sinkhorn(_t(x[:B]), _t(C), EPS, ITERS, torch.uint8)
+        assert np.array_equal(got.cpu().numpy(), want)
+        assert np.array_equal(ops.assign_nearest(_t(x[:B]), _t(C), torch.uint8).cpu().numpy(),
+                              c_oracle.quantize(x[:B], C, False)[0])
+
+
+@pytest.mark.parametrize("iters", [1, 2, 7])
+def test_iteration_count_is_part_of_the_spec(iters):
+    from repconc_amd import ops
+    _, x, C = load_case("m8_b300_gauss")
+    want, _ = c_oracle.quantize(x, C, True, EPS, iters)
+    got, _ = ops.assign_sinkhorn(_t(x), _t(C), EPS, iters, torch.uint8)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_other_epsilon():
+    from repconc_amd import ops
+    _, x, C = load_case("m24_b1024_sample")
+    for eps in (0.01, 0.05):
+        want, _ = c_oracle.quantize(x, C, True, eps, 30)
+        got, _ = ops.assign_sinkhorn(_t(x), _t(C), eps, 30, torch.uint8)
+        assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_decode_forward_backward():
+    from repconc_amd import ops
+    g, x, C = load_case("m48_b1024_sample")
+    codes = _t(g["codes_constrained"])
+    out = ops.decode(codes, _t(C))
+    assert zlib.crc32(out.cpu().numpy().tobytes()) == int(g["decode_crc"])
+    out64 = ops.decode(codes.long(), _t(C))
+    assert torch.equal(out, out64)
+    Cp = _t(C).clone().requires_grad_(True)
+    go = _t(synth.gaussian(5, (1024, 768)))
+    ops.decode(codes.long(), Cp).backward(go)
+    want = pq_oracle.decode_bwd(g["codes_constrained"], go.cpu().numpy(), 48, 256)
+    np.testing.assert_allclose(Cp.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # numpy variant of the module-level decode
+    from repconc_amd.models.repconc import decode
+    assert zlib.crc32(np.ascontiguousarray(decode(g["codes_constrained"], C)).tobytes()) == int(g["decode_crc"])
+
+
+def test_histogram_and_balance():
+    from repconc_amd import ops
+    g, _, _ = load_case("m48_b6144_sample")
+    for arr in (g["codes_constrained"], g["codes_nearest"]):
+        h = ops.code_hist(_t(arr)).cpu().numpy()
+        assert np.array_equal(h, pq_oracle.code_histogram(arr))
+        h64 = ops.code_hist(_t(arr).long()).cpu().numpy()
+        assert np.array_equal(h64, h)
+
+
+def test_kmeans_stats_and_update():
+    from repconc_amd import ops
+    for name in ("m48_b1024_sample", "m8_b2048_sample", "m96_b512_blend"):
+        g, x, C = load_case(name)
+        M = C.shape[0]
+        codes = g["codes_nearest"]
+        sums, cnt = ops.kmeans_stats(_t(x), _t(codes))
+        ws, wc = pq_oracle.kmeans_stats(x, codes, M)
+        assert np.array_equal(cnt.cpu().numpy(), wc)
+        np.testing.assert_allclose(sums.cpu().numpy(), ws, rtol=1e-12, atol=1e-12)
+        newC = ops.kmeans_update_(sums, cnt, _t(C).clone()).cpu().numpy()
+        want = pq_oracle.kmeans_update(ws, wc, C)
+        np.testing.assert_allclose(newC, want, rtol=1e-6, atol=1e-7)
+        # shard-sum of statistics == statistics of the whole (the all-gather path of §8e)
+        h = x.shape[0] // 2
+        s2, c2 = ops.kmeans_stats(_t(x[:h]), _t(codes[:h]))
+        s2, c2 = ops.kmeans_stats(_t(x[h:]), _t(codes[h:]), s2, c2)
+        assert torch.equal(c2, cnt)
+        np.testing.assert_allclose(s2.cpu().numpy(), ws, rtol=1e-12, atol=1e-12)
+
+
+def test_normalize_centroids():
+    from repconc_amd import ops
+    C = synth.gaussian(3, (48, 256, 16))
+    got = ops.normalize_centroids_(_t(C).clone()).cpu().numpy()
+    np.testing.assert_allclose(got, pq_oracle.normalize_centroids(C), rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------- ADC
+def _adc_case(M, N, nq, seed=0):
+    C = synth.gaussian(seed + 1, (M, 256, 768 // M))
+    codes = synth.uniform_codes(seed + 2, N, M)
+    q = synth.gaussian(seed + 3, (nq, 768))
+    return C, codes, q
+
+
+def test_adc_lut_bitwise():
+    from repconc_amd import ops
+    C, _, q = _adc_case(48, 10, 7)
+    lut = ops.adc_lut(_t(C), _t(q)).cpu().numpy()
+    assert np.array_equal(lut.view(np.uint32), pq_oracle.adc_lut(q, C).view(np.uint32))
+
+
+@pytest.mark.parametrize("M,N,nq,k", [(48, 20000, 16, 100), (48, 50000, 5, 1000), (96, 40000, 3, 10),
+                                      (24, 70000, 9, 200), (8, 3000, 4, 50), (64, 33000, 2, 10),
+                                      (48, 500, 3, 1000), (12, 100000, 3, 10), (16, 5000, 1, 1), (32, 17000, 6, 64)])
+def test_adc_search_matches_oracle_exactly(M, N, nq, k):
+    from repconc_amd import ops
+    C, codes, q = _adc_case(M, N, nq, seed=M + N)
+    scores, ids = ops.adc_search(_t(codes), _t(C), _t(q), k)
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    assert np.array_equal(ids.cpu().numpy(), wi)
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+def test_adc_golden_fixture_and_duplicates():
+    from repconc_amd import ops
+    g = np.load(os.path.join(GOLDEN, "adc_m48_n20000.npz"))
+    C = synth.gaussian(777, (48, 256, 16))
+    codes = synth.uniform_codes(778, 20000, 48)
+    q = synth.gaussian(779, (16, 768))
+    scores, ids = ops.adc_search(_t(codes), _t(C), _t(q), 100)
+    np.testing.assert_allclose(scores.cpu().numpy(), g["top_scores"], rtol=0, atol=2e-4)
+    # duplicated rows: equal scores must come back in ascending id order
+    dup = np.concatenate([codes[:5000]] * 4, 0)
+    s2, i2 = ops.adc_search(_t(dup), _t(C), _t(q), 64, id_offset=1000)
+    ws, wi = c_oracle.adc_search(dup, C, q, 64)
+    assert np.array_equal(i2.cpu().numpy(), wi + 1000)
+
+
+def test_adc_large_index_properties():
+    """BASELINE-size index (8.84M x 48): top-k must be sorted, contain planted winners, and agree
+    with an exact rescoring of the returned ids."""
+    from repconc_amd import ops
+    N, M, nq, k = 8841823, 48, 8, 1000
+    C = _t(synth.gaussian(11, (M, 256, 16)))
+    gen = torch.Generator(device=DEV).manual_seed(12)
+    codes = torch.randint(0, 256, (N, M), dtype=torch.uint8, device=DEV, generator=gen)
+    q = _t(synth.gaussian(13, (nq, 768)))
+    lut = ops.adc_lut(C, q)                                   # [nq, M, 256]
+    best = lut.argmax(dim=2).to(torch.uint8)                  # per query the best code per m
+    plant = torch.tensor([17, 4_000_000, N - 1], device=DEV)
+    for r in range(3):
+        codes[plant[r]] = best[r]
+    scores, ids = ops.adc_search(codes, C, q, k)
+    assert bool((scores[:, :-1] >= scores[:, 1:]).all())
+    for r in range(3):
+        assert int(ids[r, 0]) == int(plant[r])
+    # exact rescoring of what came back
+    rows = codes[ids.reshape(-1)].long().reshape(nq, k, M)
+    re = torch.zeros((nq, k), dtype=torch.float32, device=DEV)
+    for m in range(M):
+        re = re + torch.gather(lut[:, m, :], 1, rows[:, :, m])
+    assert torch.equal(re, scores)
+    # nothing outside the result beats the k-th score (checked on a 1M-row slice)
+    sl = codes[1_000_000:2_000_000].long()
+    s = torch.zeros((nq, sl.shape[0]), dtype=torch.float32, device=DEV)
+    for m in range(M):
+        s = s + lut[:, m, :][:, sl[:, m]]
+    kth = scores[:, -1:]
+    inside = ((ids >= 1_000_000) & (ids < 2_000_000)).sum(1)
+    assert torch.equal((s >= kth).sum(1) >= inside, torch.ones(nq, dtype=torch.bool, device=DEV))
+    assert bool(((s > kth).sum(1) <= inside).all())
+
+
+# ------------------------------------------------------------------------------------------- model API
+class _TableEncoder(torch.nn.Module):
+    def __init__(self, table):
+        super().__init__()
+        self.register_buffer("table", table)
+        from types import SimpleNamespace
+        self.config = SimpleNamespace(hidden_size=table.shape[1])
+
+    def forward(self, input_ids, attention_mask):
+        return self.table[input_ids[:, 0]]
+
+
+def test_repconc_module_forward_and_quantize():
+    from types import SimpleNamespace
+    from repconc_amd.models.repconc import RepCONC
+    g = np.load(os.path.join(GOLDEN, "forward_m48_b256.npz"))
+    table = torch.from_numpy(synth.clustered_embeddings(4242, 256))
+    C = synth.sample_centroids(4243, table.numpy(), 48)
+    cfg = SimpleNamespace(MCQ_M=48, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_IP")
+    model = RepCONC(cfg, _TableEncoder(table), False, EPS, ITERS).to(DEV)
+    assert set(k for k in model.state_dict() if not k.startswith("dense_encoder")) == {"rotation", "centroids"}
+    with torch.no_grad():
+        model.centroids.copy_(_t(C))
+        model.rotation.copy_(_t(g["rotation"]))
+    ids = torch.arange(256, device=DEV)[:, None].repeat(1, 4)
+    out = model(ids, torch.ones_like(ids), return_code=True, return_quantized_embedding=True)
+    np.testing.assert_allclose(out.continuous_embeds.cpu().numpy(), g["ip_continuous"], rtol=1e-4, atol=1e-4)
+    assert out.discrete_codes.dtype == torch.int64 and out.discrete_codes.shape == (256, 48)
+    assert torch.equal(out.quantized_embeds, model.decode(out.discrete_codes))
+    # on the reference's exact continuous embeddings the codes are the reference's codes
+    cont = _t(g["ip_continuous"])
+    assert np.array_equal(model.quantize(cont).cpu().numpy().astype(np.uint8), g["ip_codes"])
+    assert zlib.crc32(model.decode(_t(g["ip_codes"]).long()).detach().cpu().numpy().tobytes()) == int(g["ip_quantized_crc"])
+    # passing discrete codes skips quantisation; gradient reaches the centroids
+    out2 = model(ids, torch.ones_like(ids), discrete_codes=out.discrete_codes, return_quantized_embedding=True)
+    out2.quantized_embeds.sum().backward()
+    assert model.centroids.grad is not None and float(model.centroids.grad.abs().sum()) > 0
+    # constrained mode toggled at run time (finetune_repconc.py:603-612)
+    model.use_constraint = True
+    cc = model.quantize(cont)
+    want, _ = c_oracle.quantize(g["ip_continuous"], C, True, EPS, ITERS)
+    assert np.array_equal(cc.cpu().numpy().astype(np.uint8), want)
+    # COS variant: per-sub-vector normalisation happens before quantisation
+    cfg2 = SimpleNamespace(MCQ_M=48, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_CENTROID_COS")
+    m2 = RepCONC(cfg2, _TableEncoder(table), False, EPS, ITERS).to(DEV)
+    n = m2.centroids.detach().norm(dim=-1)
+    assert torch.allclose(n, torch.ones_like(n), atol=1e-5)
+    with torch.no_grad():
+        m2.centroids.copy_(_t(C))
+    codes = m2.quantize(_t(g["cos_continuous"]))
+    assert np.array_equal(codes.cpu().numpy().astype(np.uint8), g["cos_codes"])
+
+
+def test_sinkhorn_algorithm_and_centring_api():
+    from repconc_amd.models.repconc import RepCONC, sinkhorn_algorithm
+    _, x, C = load_case("m8_b300_gauss")
+    d = pq_oracle.dist_table(x, C)
+    dc = RepCONC.center_distance_for_constraint(_t(d))
+    want = pq_oracle.centre(d, *pq_oracle.minmax_per_m(d))
+    assert np.array_equal(dc.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    Q = sinkhorn_algorithm(-dc.double().transpose(1, 2), 0.003, 100, False)          # [M,K,B]
+    ref = pq_oracle.sinkhorn_q([-(want.astype(np.float64)).transpose(0, 2, 1)], 0.003, 100)[0]
+    assert Q.shape == ref.shape
+    assert np.array_equal(Q.argmax(1).cpu().numpy(), ref.argmax(1))
+    np.testing.assert_allclose(Q.sum(1).cpu().numpy(), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(Q.cpu().numpy(), ref, rtol=1e-6, atol=1e-12)
+
+
+def test_index_build_and_search_api():
+    from types import SimpleNamespace
+    from repconc_amd.models.repconc import evaluate_repconc as ev
+    C, codes, q = _adc_case(48, 30000, 12, seed=5)
+    model = SimpleNamespace(config=SimpleNamespace(hidden_size=768, MCQ_M=48, MCQ_K=256),
+                            centroids=torch.nn.Parameter(_t(C)))
+    index = ev.initialize_index(model)
+    ev.add_docs(index, codes[:10000])
+    ev.add_docs(index, codes[10000:])
+    assert index.ntotal == 30000 and index.pq.code_size == 48 and index.pq.M == 48
+    assert np.array_equal(index.codes.cpu().numpy(), codes)
+    index = ev.load_index_to_gpu(ev.from_pq_to_ivfpq(index))
+    corpus_ids = np.arange(30000)[::-1].copy() + 7
+    qids = np.arange(12)
+    s, ids = ev.batch_search(qids, q, corpus_ids, index, 10, batch_size=5)
+    ws, wi = c_oracle.adc_search(codes, C, q, 10)
+    assert np.array_equal(ids, corpus_ids[wi]) and np.array_equal(s.view(np.uint32), ws.view(np.uint32))
+    # torch-in/torch-out search (JPQ path) and centroid refresh without touching the codes
+    s2, i2 = index.search(_t(q), 10)
+    assert s2.is_cuda and np.array_equal(i2.cpu().numpy(), wi)
+    index.set_centroids(C * 2)
+    s3, _ = index.search(q, 10)
+    np.testing.assert_allclose(s3, ws * 2, rtol=1e-6)
+
+
+def test_mrr_parity_planted_relevance():
+    """MRR@10 of the HIP search == MRR@10 of the brute-force oracle on a planted-relevance task."""
+    from repconc_amd import ops
+    M, N, nq = 48, 60000, 64
+    x = synth.clustered_embeddings(21, N)
+    C = synth.sample_centroids(22, x[:4096], M)
+    codes = ops.assign_nearest(_t(x), _t(C), torch.uint8)
+    assert np.array_equal(codes.cpu().numpy()[:2048], c_oracle.quantize(x[:2048], C, False)[0])
+    rng = np.random.default_rng(23)
+    pos = rng.integers(0, N, nq)
+    q = x[pos] + 0.3 * synth.gaussian(24, (nq, 768))
+    _, ids = ops.adc_search(codes, _t(C), _t(q), 10)
+    _, wi = c_oracle.adc_search(codes.cpu().numpy(), C, q, 10)
+    positives = [{int(p)} for p in pos]
+    got, want = pq_oracle.mrr_at_k(ids.cpu().numpy(), positives), pq_oracle.mrr_at_k(wi, positives)
+    assert abs(got - want) <= 0.001 and got == want

@@ -1,0 +1,113 @@
+"""The oracle pinned against the reference's outputs (tests/golden, made by oracle/gen_golden.py).
+CPU only.  numpy restatement on the small cases, C restatement on every case."""
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_case
+from oracle import c_oracle, pq_oracle
+
+EPS, ITERS = 0.003, 100
+SMALL = [c for c in golden_cases() if "b6144" not in c]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_c_oracle_codes_bit_exact(name):
+    g, x, C = load_case(name)
+    near, _ = c_oracle.quantize(x, C, False)
+    assert np.array_equal(near, g["codes_nearest"])
+    con, flags = c_oracle.quantize(x, C, True, EPS, ITERS)
+    assert flags == 0
+    assert np.array_equal(con, g["codes_constrained"])
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_c_oracle_fp32_stage_bitwise(name):
+    g, x, C = load_case(name)
+    d = c_oracle.dist_table(x, C)
+    idx = g["samp_idx"]
+    assert np.array_equal(d[idx[:, 0], idx[:, 1], idx[:, 2]].view(np.uint32), g["samp_dist_bits"])
+    mm = c_oracle.minmax(d)
+    M = d.shape[0]
+    assert np.array_equal(mm[:M].view(np.uint32), g["mx_bits"])
+    assert np.array_equal(mm[M:].view(np.uint32), g["mn_bits"])
+    c_oracle.centre_(d, mm)
+    assert np.array_equal(d[idx[:, 0], idx[:, 1], idx[:, 2]].view(np.uint32), g["samp_centred_bits"])
+
+
+@pytest.mark.parametrize("name", ["m8_b300_gauss", "m64_b512_sample", "m96_b512_blend", "m48_b1000_ragged"])
+def test_numpy_oracle_matches_reference(name):
+    g, x, C = load_case(name)
+    codes, im = pq_oracle.quantize(x, C, True, EPS, ITERS, return_intermediates=True)
+    assert np.array_equal(codes.astype(np.uint8), g["codes_constrained"])
+    assert im["flags"] == 0
+    idx = g["samp_idx"]
+    assert np.array_equal(im["dist"][idx[:, 0], idx[:, 1], idx[:, 2]].view(np.uint32), g["samp_dist_bits"])
+    assert np.array_equal(im["centred"][idx[:, 0], idx[:, 1], idx[:, 2]].view(np.uint32), g["samp_centred_bits"])
+    assert np.array_equal(im["mx"].view(np.uint32), g["mx_bits"])
+    assert np.array_equal(pq_oracle.quantize(x, C, False).astype(np.uint8), g["codes_nearest"])
+    dec = pq_oracle.decode(g["codes_constrained"], C)
+    assert zlib.crc32(np.ascontiguousarray(dec).tobytes()) == int(g["decode_crc"])
+    assert zlib.crc32(c_oracle.decode(g["codes_constrained"], C).tobytes()) == int(g["decode_crc"])
+
+
+@pytest.mark.parametrize("name,shards", [("m8_b2048_sample", 2), ("m8_b2048_sample", 4)])
+def test_numpy_oracle_sharded_equals_unsharded(name, shards):
+    """The reference's own gloo run (shard{2,4}_equal in the fixture) says sharded == unsharded;
+    the oracle's simulated ranks must say the same."""
+    g, x, C = load_case(name)
+    assert int(g[f"shard{shards}_equal"]) == 1
+    codes = pq_oracle.quantize(x, C, True, EPS, ITERS, shards=shards)
+    assert np.array_equal(codes.astype(np.uint8), g["codes_constrained"])
+
+
+def test_logdomain_restatement_gives_reference_codes():
+    """The potential form the HIP kernels use is algebraically the reference's matrix form."""
+    g, x, C = load_case("m8_b300_gauss")
+    d = pq_oracle.dist_table(x, C)
+    dc = pq_oracle.centre(d, *pq_oracle.minmax_per_m(d))
+    codes = pq_oracle.sinkhorn_codes_logdomain(dc, EPS, ITERS)
+    assert np.array_equal(codes.astype(np.uint8), g["codes_constrained"])
+
+
+def test_sinkhorn_uniform_cost_gives_uniform_plan():
+    out = [np.zeros((2, 256, 512))]
+    Q = pq_oracle.sinkhorn_q(out, 0.05, 3)[0]
+    assert np.allclose(Q, 1.0 / 256) and np.allclose(Q.sum(1), 1.0)
+
+
+def test_balance_of_constrained_codes():
+    g, _, _ = load_case("m48_b6144_sample")
+    h = pq_oracle.code_histogram(g["codes_constrained"])
+    assert h.sum() == 6144 * 48
+    assert h.min() >= 14 and h.max() <= 34          # ideal 24 per centroid
+    hn = pq_oracle.code_histogram(g["codes_nearest"])
+    assert hn.max() > 100                           # unconstrained codes are badly unbalanced
+
+
+def test_adc_identity_against_reference_decode():
+    """sum_m LUT[m][code] == <q, decode(code)> (decode pinned by the reference): the brute-force
+    fixture built on the reference's decode must be reproduced by the LUT oracle."""
+    import os
+    from conftest import GOLDEN
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, "adc_m48_n20000.npz"))
+    M, N, nq, k = int(g["M"]), int(g["N"]), int(g["nq"]), int(g["k"])
+    C = synth.gaussian(777, (M, 256, 768 // M))
+    codes = synth.uniform_codes(778, N, M)
+    q = synth.gaussian(779, (nq, 768))
+    assert zlib.crc32(np.ascontiguousarray(pq_oracle.decode(codes, C)).tobytes()) == int(g["recon_crc"])
+    scores, ids = pq_oracle.adc_search(q, C, codes, k)
+    np.testing.assert_allclose(scores, g["top_scores"], rtol=0, atol=2e-4)
+    # identical sets except for swaps among near-equal scores at the boundary
+    for r in range(nq):
+        assert len(set(ids[r].tolist()) & set(g["top_ids"][r].tolist())) >= k - 2
+    cs, ci = c_oracle.adc_search(codes, C, q, k)
+    assert np.array_equal(ci, ids) and np.array_equal(cs.view(np.uint32), scores.view(np.uint32))
+
+
+def test_mrr_at_k():
+    ranked = np.array([[5, 3, 9], [1, 2, 3], [7, 8, 9]])
+    assert pq_oracle.mrr_at_k(ranked, [{3}, {1}, {4}], 10) == round((0.5 + 1.0 + 0.0) / 3, 5)
+    assert pq_oracle.mrr_at_k(ranked, [{9}, {1}, {4}], 2) == round((0.0 + 1.0 + 0.0) / 3, 5)
