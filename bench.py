@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the RepCONC PQ hot path on MI355X (BASELINE.json metric:
+"constrained-cluster assignments/sec + ADC queries/sec, 8.8M x 768d M=48 K=256").
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one constrained (Sinkhorn, eps=0.003, 100 iterations) code assignment of one training
+batch of B_global = 49152 document embeddings (4096 queries x (1 positive + 11 negatives),
+examples/sentence-bert/repconc/7_run_conc_train.sh:18-22) at D=768, M=48, K=256 — SURVEY.md §8d
+workload B, BASELINE.json configs[1].  180 such batches = the 8.84M-passage corpus.  The batch is
+resident in HBM (fp32, synthetic N(0,1)) before the timed region.  With N ranks, rank r owns rows
+[r*B/N, (r+1)*B/N) and the row sums are all-gathered every iteration (strong scaling of a step).
+
+`value` = constrained assignments (document vectors) per second, whole job.  The ADC leg (second
+half of the metric) is reported in the `adc` object of the same JSON line: PQ inner-product top-1000
+search of 1200-query batches over a resident 8,841,823 x 48-byte index; with N ranks the index is
+replicated and the queries are split (the reference's co.shard=False, evaluate_repconc.py:131-134).
+
+`roofline` is for the dominant kernel, the Sinkhorn sweep (sk_pass_kernel<false>): algorithmic
+bytes per launch = B_local*M*K*4 (one fp32 read of the K centred distances of every (vector,
+sub-quantiser)) divided by its average launch duration, measured with HIP events
+recorded around every launch inside the timed region (rc_profile_*, on the launch stream).
+`cpu_baseline` times the oracle's C port of the reference algorithm on the host cores (rank 0,
+N=1 only) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+D, M, K = 768, 48, 256
+B_GLOBAL = 49152
+EPS, ITERS = 0.003, 100
+N_CORPUS = 8841823
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-adc", action="store_true", help="skip the ADC leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--adc-batches", type=int, default=2)
+    ap.add_argument("--adc-k", type=int, default=1000)
+    ap.add_argument("--batch", type=int, default=B_GLOBAL, help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed PMC summary (profiles/pmc_summary.json), else None."""
+    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        return json.load(open(p))[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from repconc_amd import _lib, ops
+    from repconc_amd.sharded import SingleComm, TorchDistComm, assign_sinkhorn_sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        comm = TorchDistComm()
+    else:
+        comm = SingleComm()
+    lib, h = _lib.load(), _lib.handle(local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------------ constrained assignment
+    B = args.batch
+    assert B % world == 0
+    bl = B // world
+    n_pool = 3                                              # distinct batches cycled through
+    rng = np.random.default_rng(20220)
+    pool = []
+    for i in range(n_pool):
+        xb = rng.standard_normal((B, D), dtype=np.float32)
+        if i == 0:
+            cent = np.ascontiguousarray(
+                xb[np.random.default_rng(20221).permutation(B)[:K]].reshape(K, M, D // M).transpose(1, 0, 2))
+        pool.append(torch.from_numpy(xb[rank * bl:(rank + 1) * bl]).to(dev))
+    C = torch.from_numpy(cent).to(dev)
+
+    def step(i):
+        x = pool[i % n_pool]
+        if world == 1:
+            return ops.assign_sinkhorn(x, C, EPS, ITERS, torch.uint8)
+        return assign_sinkhorn_sharded(x, C, EPS, ITERS, comm, dtype=torch.uint8)
+
+    for i in range(args.warmup):
+        codes, flags = step(i)
+    barrier()
+    import ctypes
+    lib.rc_profile_enable(h, 1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        codes, flags = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.rc_profile_enable(h, 0)
+    n_l, ms_l = ctypes.c_int(0), ctypes.c_double(0.0)
+    lib.rc_profile_collect(h, _lib.PROF_SK_PASS, ctypes.byref(n_l), ctypes.byref(ms_l))
+    dt = max_over_ranks(dt)
+    assert int(flags.item()) == 0, "Sinkhorn produced non-finite sums"
+    value = args.steps * B / dt
+    sweep_ms = ms_l.value / max(n_l.value, 1)
+    alg_bytes = bl * M * K * 4
+    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if n_l.value else 0.0
+    roofline = {"kernel": "sk_pass_kernel<false> (Sinkhorn sweep)", "bound": "hbm", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic("sk_pass_kernel"), "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(sweep_ms, 4), "launches_timed": n_l.value}
+
+    # balance sanity of the last batch (every centroid gets ~B/K of the global batch)
+    hist = ops.code_hist(codes)
+    if world > 1:
+        dist.all_reduce(hist)
+    ideal = B / K
+    imb = float((hist.float() / ideal - 1).abs().max().item())
+
+    out = {
+        "metric": "constrained_cluster_assignments_per_sec", "value": round(value, 1), "unit": "vectors/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "SURVEY 8d-B / BASELINE configs[1] shape: constrained PQ assignment of "
+                               "49152x768 batches (180 = 8.84M corpus), M=48 K=256 eps=0.003 T=100",
+                   "global_batch": B, "rows_per_gpu": bl, "D": D, "M": M, "K": K, "sk_iters": ITERS,
+                   "parallelism": f"batch-sharded x{world}, all-gather of [M,K] f64 row sums per iteration"},
+        "sub_assignments_per_sec": round(value * M, 1),
+        "max_code_imbalance": round(imb, 4),
+        "roofline": roofline,
+    }
+
+    # ------------------------------------------------------------------ ADC search leg
+    if not args.no_adc:
+        del pool
+        torch.cuda.empty_cache()
+        gen = torch.Generator(device=dev).manual_seed(20222)
+        index_codes = torch.randint(0, 256, (N_CORPUS, M), dtype=torch.uint8, device=dev, generator=gen)
+        nq_batch = 1200
+        q_all = torch.from_numpy(np.random.default_rng(20223).standard_normal((nq_batch * args.adc_batches, D),
+                                                                             dtype=np.float32)).to(dev)
+        per_rank = nq_batch // world
+        k = args.adc_k
+
+        def search(bi):
+            q = q_all[bi * nq_batch + rank * per_rank: bi * nq_batch + (rank + 1) * per_rank]
+            return ops.adc_search(index_codes, C, q, k)
+
+        search(0)
+        barrier()
+        lib.rc_profile_enable(h, 1)
+        t0 = time.perf_counter()
+        for bi in range(args.adc_batches):
+            sc, ids = search(bi)
+        barrier()
+        adt = max_over_ranks(time.perf_counter() - t0)
+        lib.rc_profile_enable(h, 0)
+        lib.rc_profile_collect(h, _lib.PROF_ADC_SCAN, ctypes.byref(n_l), ctypes.byref(ms_l))
+        qps = args.adc_batches * per_rank * world / adt
+        scan_ms = ms_l.value / max(n_l.value, 1)
+        adc_alg = per_rank * N_CORPUS * M          # N*M code bytes per query
+        adc_ach = adc_alg / (scan_ms * 1e-3) / 1e9 if n_l.value else 0.0
+        out["adc"] = {
+            "metric": "adc_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "k": k,
+            "index": f"{N_CORPUS} x {M} B uint8 uniform codes, resident", "query_batch": nq_batch,
+            "batches": args.adc_batches, "ms_per_batch": round(adt / args.adc_batches * 1e3, 2),
+            "parallelism": f"index replicated, queries split x{world}",
+            "roofline": {"kernel": "adc_scan_kernel<48,2,FILTER>", "bound": "hbm", "achieved": round(adc_ach, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(adc_ach / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("adc_scan_kernel"), "algorithmic_bytes_per_launch": adc_alg,
+                         "avg_launch_ms": round(scan_ms, 3), "launches_timed": n_l.value,
+                         "note": "algorithmic bytes = N*M per query; blocks share code tiles through L2, so "
+                                 "frac > 1 is possible — the physical limit is the LDS gather rate"},
+        }
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
+    if world == 1 and not args.no_cpu:
+        from oracle import c_oracle
+        cores = c_oracle.num_threads()
+        Bs = 4096
+        xs = np.random.default_rng(20224).standard_normal((Bs, D), dtype=np.float32)
+        t0 = time.perf_counter()
+        cpu_codes, _ = c_oracle.quantize(xs, cent, True, EPS, ITERS)
+        cdt = time.perf_counter() - t0
+        got, _ = ops.assign_sinkhorn(torch.from_numpy(xs).to(dev), C, EPS, ITERS, torch.uint8)
+        agree = bool(np.array_equal(got.cpu().numpy(), cpu_codes))
+        out["cpu_baseline"] = {
+            "value": round(Bs / cdt, 1), "unit": "vectors/s", "cores": cores, "kind": "port",
+            "sample": f"one {Bs}x768 batch, M=48, eps=0.003, 100 iterations: oracle/pq_oracle.c (OpenMP C port of the "
+                      f"reference's fp32 distance table + in-place fp64 Sinkhorn), {cdt:.1f} s; GPU codes identical: {agree}",
+            "cpu": _cpu_model(),
+        }
+        out["speedup_vs_cpu_baseline"] = round(value / (Bs / cdt), 1)
+        if not args.no_adc:
+            nq_c = min(2 * cores, 128)
+            n_c = 2_000_000                                   # bounded index slice, cost is linear in N
+            sl = index_codes[:n_c].cpu().numpy()
+            qc = q_all[:nq_c].cpu().numpy()
+            t0 = time.perf_counter()
+            c_oracle.adc_search(sl, cent, qc, k)
+            adt_c = time.perf_counter() - t0
+            qps_c = nq_c / adt_c * (n_c / N_CORPUS)
+            out["adc"]["cpu_baseline"] = {
+                "value": round(qps_c, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+                "sample": f"{nq_c} queries over the first {n_c} rows of the index ({adt_c:.1f} s), rate scaled by "
+                          f"{n_c}/{N_CORPUS} to the full index; oracle/pq_oracle.c orc_adc_search (Faiss-style LUT + "
+                          "linear scan + size-k heap, one query per thread)"}
+            out["adc"]["speedup_vs_cpu_baseline"] = round(out["adc"]["value"] / qps_c, 1)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

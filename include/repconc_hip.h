@@ -56,6 +56,15 @@ int rc_destroy(rc_handle_t h);
 int rc_last_hip_error(rc_handle_t h); /* hipError_t of the last RC_EHIP on this handle */
 int rc_num_cus(rc_handle_t h);
 
+/* ------------------------------------------------------------------ measurement hook
+ * With profiling enabled every launch of a hot kernel is bracketed by a pair of hipEvents recorded
+ * on the launch stream.  rc_profile_collect() waits for the recorded events of one kernel class,
+ * returns the number of launches and the summed device time in milliseconds, and clears them.
+ * Classes: 0 = Sinkhorn sweep (sk_pass_kernel), 1 = ADC filter scan, 2 = nearest assignment,
+ * 3 = distance table.  bench.py's `roofline.achieved` comes from this. */
+int rc_profile_enable(rc_handle_t h, int on);
+int rc_profile_collect(rc_handle_t h, int kernel_class, int* launches, double* total_ms);
+
 /* ------------------------------------------------------------------ a-1 / a-5
  * Nearest-centroid codes (index build).  Replaces RepCONC.quantize with use_constraint=False,
  * models/repconc/modeling_repconc.py:49-52,66: code[b,m] = argmin_k sum_j (x[b,m*dsub+j]-C[m,k,j])^2,

@@ -111,60 +111,77 @@ void orc_argmin(const float* d, int64_t B, int M, uint8_t* codes) {
 }
 
 /* sinkhorn_algorithm in the reference's in-place Q form, single rank, :137-165, followed by the
- * argmax of :63.  dc: centred distances [M][B][K] fp32.  Q scratch [K][B] fp64 per thread.
+ * argmax of :63.  dc: centred distances [M][B][K] fp32.  Q: [M][K][B] fp64 (the reference's
+ * layout), every loop nest parallel over (m, row) or (m, column block) so all host cores work.
  * Returns flags: bit0 NaN seen, bit1 Inf seen (:64-65). */
+#define CB 256 /* column block */
 int orc_sinkhorn_codes(const float* dc, int64_t B, int M, double eps, int iters, uint8_t* codes) {
     int flags = 0;
-#pragma omp parallel for schedule(dynamic) reduction(| : flags)
-    for (int m = 0; m < M; ++m) {
-        double* Q = (double*)malloc(sizeof(double) * K * B);
-        double* col = (double*)malloc(sizeof(double) * B);
-        const float* dm = dc + (int64_t)m * B * K;
-        double tot = 0.0;
-        for (int k = 0; k < K; ++k)
-            for (int64_t b = 0; b < B; ++b) {
-                const double v = exp((-(double)dm[b * K + k]) / eps); /* :141 on out=-centred (:57) */
-                Q[(int64_t)k * B + b] = v;
-            }
+    double* Q = (double*)malloc(sizeof(double) * (size_t)M * K * B);
+    double* rowsum = (double*)malloc(sizeof(double) * (size_t)M * K);
+    const int64_t nblk = (B + CB - 1) / CB;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int m = 0; m < M; ++m)
         for (int k = 0; k < K; ++k) {
+            double* q = Q + ((int64_t)m * K + k) * B;
+            const float* dm = dc + (int64_t)m * B * K + k;
             double s = 0.0;
-            for (int64_t b = 0; b < B; ++b) s += Q[(int64_t)k * B + b];
-            tot += s; /* :148 */
+            for (int64_t b = 0; b < B; ++b) {
+                q[b] = exp((-(double)dm[b * K]) / eps); /* :141 on out=-centred (:57) */
+                s += q[b];
+            }
+            rowsum[m * K + k] = s;
         }
-        for (int64_t i = 0; i < (int64_t)K * B; ++i) Q[i] /= tot; /* :152 */
-        for (int it = 0; it < iters; ++it) {
-            for (int k = 0; k < K; ++k) { /* :155-159 */
-                double* q = Q + (int64_t)k * B;
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) { /* :148,:152 */
+        double tot = 0.0;
+        for (int k = 0; k < K; ++k) tot += rowsum[m * K + k];
+        double* q = Q + (int64_t)m * K * B;
+        for (int64_t i = 0; i < (int64_t)K * B; ++i) q[i] /= tot;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int m = 0; m < M; ++m) /* :155-159 */
+            for (int k = 0; k < K; ++k) {
+                double* q = Q + ((int64_t)m * K + k) * B;
                 double s = 0.0;
                 for (int64_t b = 0; b < B; ++b) s += q[b];
                 for (int64_t b = 0; b < B; ++b) { q[b] /= s; q[b] /= K; }
             }
-            for (int64_t b = 0; b < B; ++b) col[b] = 0.0; /* :162-163 */
-            for (int k = 0; k < K; ++k) {
-                const double* q = Q + (int64_t)k * B;
-                for (int64_t b = 0; b < B; ++b) col[b] += q[b];
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int m = 0; m < M; ++m) /* :162-163 */
+            for (int64_t blk = 0; blk < nblk; ++blk) {
+                const int64_t b0 = blk * CB, b1 = (b0 + CB < B) ? b0 + CB : B;
+                double col[CB];
+                for (int64_t b = b0; b < b1; ++b) col[b - b0] = 0.0;
+                for (int k = 0; k < K; ++k) {
+                    const double* q = Q + ((int64_t)m * K + k) * B;
+                    for (int64_t b = b0; b < b1; ++b) col[b - b0] += q[b];
+                }
+                for (int k = 0; k < K; ++k) {
+                    double* q = Q + ((int64_t)m * K + k) * B;
+                    for (int64_t b = b0; b < b1; ++b) { q[b] /= col[b - b0]; q[b] /= (double)B; }
+                }
             }
-            for (int k = 0; k < K; ++k) {
-                double* q = Q + (int64_t)k * B;
-                for (int64_t b = 0; b < B; ++b) { q[b] /= col[b]; q[b] /= (double)B; }
-            }
-        }
+    }
+#pragma omp parallel for collapse(2) schedule(static) reduction(| : flags)
+    for (int m = 0; m < M; ++m)
         for (int64_t b = 0; b < B; ++b) { /* :164 then :63 (argmax over k, first maximum) */
+            const double* q = Q + (int64_t)m * K * B + b;
             int bi = 0;
-            double best = Q[b] * (double)B;
+            double best = q[0] * (double)B;
             if (isnan(best)) flags |= 1;
             if (isinf(best)) flags |= 2;
             for (int k = 1; k < K; ++k) {
-                const double v = Q[(int64_t)k * B + b] * (double)B;
+                const double v = q[(int64_t)k * B] * (double)B;
                 if (isnan(v)) flags |= 1;
                 if (isinf(v)) flags |= 2;
                 if (v > best) { best = v; bi = k; }
             }
             codes[b * M + m] = (uint8_t)bi;
         }
-        free(Q);
-        free(col);
-    }
+    free(Q);
+    free(rowsum);
     return flags;
 }
 

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librepconc_hip.so")
 RC_OK, RC_EINVAL, RC_ESHAPE, RC_EHIP, RC_EWORKSPACE = 0, -1, -2, -3, -4
 RC_CODE_U8, RC_CODE_I64 = 0, 1
 RC_FLAG_NONFINITE = 1
+PROF_SK_PASS, PROF_ADC_SCAN, PROF_ASSIGN_NEAREST, PROF_DIST_TABLE = 0, 1, 2, 3
 
 _vp, _i, _i64, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double
 
@@ -26,6 +27,8 @@ PROTOTYPES = {
     "rc_destroy": (_i, [_vp]),
     "rc_last_hip_error": (_i, [_vp]),
     "rc_num_cus": (_i, [_vp]),
+    "rc_profile_enable": (_i, [_vp, _i]),
+    "rc_profile_collect": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_d)]),
     "rc_pq_assign_nearest": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "rc_pq_dist_table_ws_bytes": (_sz, [_i64, _i]),
     "rc_pq_dist_table": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -64,6 +67,9 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        # torch bundles its own HIP runtime; it must be the one the process loads first, or two
+        # copies of libamdhip64 end up initialised side by side and every HIP call here fails.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RepconcHipError(
                 f"{LIB_PATH} not found — build it with `python -m repconc_amd.build` "

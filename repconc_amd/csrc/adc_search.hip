@@ -294,8 +294,10 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, cons
                                         (int)tl));
     hipLaunchKernelGGL(adc_threshold_kernel, dim3((unsigned)nq), dim3(1024), tl, s, sample, S, r, thr);
     RC_LAUNCH_CHECK(h);
+    rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
     hipLaunchKernelGGL(kfilter, dim3(qg, (unsigned)((N + ADC_TILE_DOCS - 1) / ADC_TILE_DOCS)), dim3(ADC_THREADS), lds, s,
                        codes, N, lut, nq, S, sample, thr, cnt, cand);
+    rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }

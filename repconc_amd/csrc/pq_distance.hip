@@ -236,7 +236,9 @@ extern "C" int rc_pq_dist_table(rc_handle_t h, const float* x, int64_t ldx, cons
     hipStream_t s = (hipStream_t)stream;
     float* part = minmax ? (float*)ws : nullptr;
     dim3 grid((unsigned)nblk, (unsigned)M);
+    rc_prof_mark(h, RC_PROF_DIST_TABLE, s);
     RC_DISPATCH_DSUB(D / M, hipLaunchKernelGGL(dist_table_kernel<DSUB>, grid, dim3(RC_K), 0, s, x, ldx, C, B, rpb, d, part));
+    rc_prof_mark(h, RC_PROF_DIST_TABLE, s);
     RC_LAUNCH_CHECK(h);
     if (minmax) {
         hipLaunchKernelGGL(minmax_final_kernel, dim3(M), dim3(256), 0, s, part, (int)nblk, M, minmax);
@@ -271,8 +273,10 @@ extern "C" int rc_pq_assign_nearest(rc_handle_t h, const float* x, int64_t ldx, 
     const int64_t nblk = (B + 255) / 256;
     const size_t lds = (size_t)256 * M;
     hipStream_t s = (hipStream_t)stream;
+    rc_prof_mark(h, RC_PROF_ASSIGN_NEAREST, s);
     RC_DISPATCH_DSUB(D / M, hipLaunchKernelGGL(assign_nearest_kernel<DSUB>, dim3((unsigned)nblk), dim3(256), lds, s, x, ldx,
                                                C, B, M, codes_u8, codes_i64));
+    rc_prof_mark(h, RC_PROF_ASSIGN_NEAREST, s);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }

@@ -29,12 +29,50 @@ extern "C" int rc_create(rc_handle_t* out, int device) {
     h->device = device;
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->last_hip_error = 0;
+    h->profile_on = 0;
     *out = h;
     return RC_OK;
 }
 
 extern "C" int rc_destroy(rc_handle_t h) {
+    if (h)
+        for (auto& v : h->prof_ev)
+            for (hipEvent_t e : v) (void)hipEventDestroy(e);
     delete h;
+    return RC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ profiling
+extern "C" int rc_profile_enable(rc_handle_t h, int on) {
+    if (!h) return RC_EINVAL;
+    h->profile_on = on ? 1 : 0;
+    return RC_OK;
+}
+
+void rc_prof_mark(rc_handle_t h, int slot, hipStream_t s) {
+    if (!h || !h->profile_on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    h->prof_ev[slot].push_back(e);
+}
+
+extern "C" int rc_profile_collect(rc_handle_t h, int kernel_class, int* launches, double* total_ms) {
+    if (!h || !launches || !total_ms || kernel_class < 0 || kernel_class >= RC_PROF_NSLOT) return RC_EINVAL;
+    auto& v = h->prof_ev[kernel_class];
+    int n = 0;
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < v.size(); i += 2) {
+        float ms = 0.f;
+        RC_HIP_CHECK(h, hipEventSynchronize(v[i + 1]));
+        RC_HIP_CHECK(h, hipEventElapsedTime(&ms, v[i], v[i + 1]));
+        tot += ms;
+        ++n;
+    }
+    for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    v.clear();
+    *launches = n;
+    *total_ms = tot;
     return RC_OK;
 }
 

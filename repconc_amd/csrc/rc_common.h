@@ -6,11 +6,22 @@
 
 #include "../../include/repconc_hip.h"
 
+#include <vector>
+
+// kernel classes that can be bracketed with HIP events (rc_profile_*)
+enum { RC_PROF_SK_PASS = 0, RC_PROF_ADC_SCAN = 1, RC_PROF_ASSIGN_NEAREST = 2, RC_PROF_DIST_TABLE = 3, RC_PROF_NSLOT = 4 };
+
 struct rc_handle_s {
     int device;
     int num_cus;
     int last_hip_error;
+    int profile_on;
+    std::vector<hipEvent_t> prof_ev[RC_PROF_NSLOT];  // start, stop, start, stop, ...
 };
+
+// Record a start / stop event around one launch of a profiled kernel class (no-ops unless
+// rc_profile_enable(h, 1)).  Events are recorded on the stream the kernel is launched on.
+void rc_prof_mark(rc_handle_t h, int slot, hipStream_t s);
 
 #define RC_K 256  // centroids per sub-quantiser (reference asserts MCQ_K == 256)
 

@@ -241,10 +241,13 @@ extern "C" int rc_sk_pass(rc_handle_t h, const float* d, const double* f, const 
     double* part = (double*)ws;
     const double ninv = -1.0 / eps;
     dim3 grid((unsigned)nblk, (unsigned)M);
-    if (first)
+    if (first) {
         hipLaunchKernelGGL(sk_pass_kernel<true>, grid, dim3(SK_THREADS), 0, s, d, f, g, colsum, part, B, cpb, ninv);
-    else
+    } else {
+        rc_prof_mark(h, RC_PROF_SK_PASS, s);
         hipLaunchKernelGGL(sk_pass_kernel<false>, grid, dim3(SK_THREADS), 0, s, d, f, g, colsum, part, B, cpb, ninv);
+        rc_prof_mark(h, RC_PROF_SK_PASS, s);
+    }
     RC_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(sk_reduce_part_kernel, dim3(M), dim3(RC_K), 0, s, part, (int)nblk, rows);
     RC_LAUNCH_CHECK(h);
@@ -315,6 +318,14 @@ extern "C" int rc_pq_assign_sinkhorn(rc_handle_t h, const float* x, int64_t ldx,
         return RC_EINVAL;
     if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
     if (B == 0) return RC_OK;
+    if (B == 1) {
+        // One column: the first row normalisation (:158) makes every entry Q_k/Q_k = 1 exactly, so the
+        // reference's argmax is a K-way exact tie and returns index 0 for every sub-quantiser.
+        hipStream_t s1 = (hipStream_t)stream;
+        if (codes_u8) RC_HIP_CHECK(h, hipMemsetAsync(codes_u8, 0, (size_t)M, s1));
+        if (codes_i64) RC_HIP_CHECK(h, hipMemsetAsync(codes_i64, 0, (size_t)M * sizeof(int64_t), s1));
+        return RC_OK;
+    }
     const sk_ws_layout L = sk_layout(B, M);
     if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
     char* w = (char*)ws;

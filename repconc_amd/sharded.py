@@ -74,11 +74,21 @@ class HipStages:
 
 
 # ----------------------------------------------------------------------------- driver
+def _single_column_codes(x_local, M, dtype):
+    """Global batch of ONE row: the first row normalisation (modeling_repconc.py:158) turns every
+    entry into Q/Q = 1 exactly, the argmax is a K-way exact tie and torch returns index 0."""
+    dev = x_local.device
+    return (torch.zeros((x_local.shape[0], M), dtype=dtype, device=dev),
+            torch.zeros((1,), dtype=torch.int32, device=dev))
+
+
 def assign_sinkhorn_sharded(x_local, centroids, eps: float, iters: int, comm, stages=None,
                             dtype=torch.int64):
     """Constrained codes for this rank's rows.  Returns (codes [B_local, M], flags)."""
     stages = stages or HipStages()
     M = centroids.shape[0]
+    if comm.world * x_local.shape[0] == 1:
+        return _single_column_codes(x_local, M, dtype)
     d, minmax = stages.dist_table(x_local, centroids)
     comm.allreduce_minmax_(minmax, M)
     stages.centre_(d, minmax)
@@ -99,6 +109,9 @@ def assign_sinkhorn_virtual(x_shards: Sequence, centroids, eps: float, iters: in
     GPU) and by the `sharded == unsharded` parity tests."""
     stages = stages or HipStages()
     M = centroids.shape[0]
+    if sum(x.shape[0] for x in x_shards) == 1:
+        outs = [_single_column_codes(x, M, dtype) for x in x_shards]
+        return [o[0] for o in outs], [o[1] for o in outs]
     tabs = [stages.dist_table(x, centroids) for x in x_shards]
     mm = tabs[0][1].clone()
     for _, other in tabs[1:]:
