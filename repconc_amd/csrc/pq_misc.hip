@@ -2,6 +2,8 @@
 // centroid normalisation, code histogram, k-means sufficient statistics and centroid update.
 #include "rc_common.h"
 
+#include <math.h>
+
 #include <new>
 
 // ------------------------------------------------------------------------------------------ handle
@@ -30,16 +32,38 @@ extern "C" int rc_create(rc_handle_t* out, int device) {
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->last_hip_error = 0;
     h->profile_on = 0;
+    h->exp2_tab[0] = h->exp2_tab[1] = nullptr;
     *out = h;
     return RC_OK;
 }
 
 extern "C" int rc_destroy(rc_handle_t h) {
-    if (h)
+    if (h) {
         for (auto& v : h->prof_ev)
             for (hipEvent_t e : v) (void)hipEventDestroy(e);
+        for (double* t : h->exp2_tab)
+            if (t) (void)hipFree(t);
+    }
     delete h;
     return RC_OK;
+}
+
+// 2^(j/N) correctly rounded to double via long-double exp2l (64-bit significand), uploaded once.
+const double* rc_exp2_table(rc_handle_t h, int tb) {
+    if (!h || (tb != 8 && tb != 11)) return nullptr;
+    const int slot = (tb == 8) ? 0 : 1;
+    if (h->exp2_tab[slot]) return h->exp2_tab[slot];
+    const int N = 1 << tb;
+    std::vector<double> host(N);
+    for (int j = 0; j < N; ++j) host[j] = (double)exp2l((long double)j / (long double)N);
+    double* dev = nullptr;
+    if (hipMalloc(&dev, sizeof(double) * N) != hipSuccess) return nullptr;
+    if (hipMemcpy(dev, host.data(), sizeof(double) * N, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(dev);
+        return nullptr;
+    }
+    h->exp2_tab[slot] = dev;
+    return dev;
 }
 
 // ------------------------------------------------------------------------------------------ profiling

@@ -17,7 +17,11 @@ struct rc_handle_s {
     int last_hip_error;
     int profile_on;
     std::vector<hipEvent_t> prof_ev[RC_PROF_NSLOT];  // start, stop, start, stop, ...
+    double* exp2_tab[2];                             // device tables 2^(j/N): [0] N=256, [1] N=2048
 };
+
+// device pointer to the table 2^(j/2^tb), j < 2^tb (tb = 8 or 11), created on first use
+const double* rc_exp2_table(rc_handle_t h, int tb);
 
 // Record a start / stop event around one launch of a profiled kernel class (no-ops unless
 // rc_profile_enable(h, 1)).  Events are recorded on the stream the kernel is launched on.
