@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--adc-batches", type=int, default=2)
     ap.add_argument("--adc-k", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=B_GLOBAL, help=argparse.SUPPRESS)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="development: run the N>1 code path (RCCL collectives, staged sweeps) with one rank")
     return ap.parse_args()
 
 
@@ -68,6 +70,11 @@ def pmc_traffic(kernel):
 
 def main():
     args = parse()
+    # Only the JSON line may appear on stdout: libraries loaded below (RCCL prints a version banner) write to
+    # fd 1 from C, so fd 1 is pointed at stderr for the duration and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from repconc_amd import _lib, ops
@@ -81,21 +88,23 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         comm = TorchDistComm()
     else:
         comm = SingleComm()
     lib, h = _lib.load(), _lib.handle(local_rank)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(v):
-        if world == 1:
+        if not use_dist:
             return v
         t = torch.tensor([v], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -118,7 +127,7 @@ def main():
 
     def step(i):
         x = pool[i % n_pool]
-        if world == 1:
+        if not use_dist:
             return ops.assign_sinkhorn(x, C, EPS, ITERS, torch.uint8)
         return assign_sinkhorn_sharded(x, C, EPS, ITERS, comm, dtype=torch.uint8)
 
@@ -148,7 +157,7 @@ def main():
 
     # balance sanity of the last batch (every centroid gets ~B/K of the global batch)
     hist = ops.code_hist(codes)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(hist)
     ideal = B / K
     imb = float((hist.float() / ideal - 1).abs().max().item())
@@ -244,10 +253,12 @@ def main():
                           "linear scan + size-k heap, one query per thread)"}
             out["adc"]["speedup_vs_cpu_baseline"] = round(out["adc"]["value"] / qps_c, 1)
 
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 def _cpu_model():

@@ -60,7 +60,7 @@ int rc_num_cus(rc_handle_t h);
  * With profiling enabled every launch of a hot kernel is bracketed by a pair of hipEvents recorded
  * on the launch stream.  rc_profile_collect() waits for the recorded events of one kernel class,
  * returns the number of launches and the summed device time in milliseconds, and clears them.
- * Classes: 0 = Sinkhorn sweep (sk_pass_kernel), 1 = ADC filter scan, 2 = nearest assignment,
+ * Classes: 0 = Sinkhorn sweep (sk_sweep_kernel, t >= 1), 1 = ADC filter scan, 2 = nearest assignment,
  * 3 = distance table.  bench.py's `roofline.achieved` comes from this. */
 int rc_profile_enable(rc_handle_t h, int on);
 int rc_profile_collect(rc_handle_t h, int kernel_class, int* launches, double* total_ms);
@@ -92,36 +92,33 @@ int rc_pq_centre(rc_handle_t h, float* d, const float* minmax, int64_t B, int M,
                  rc_stream_t stream);
 
 /* ------------------------------------------------------------------ a-3 / a-4, staged form
- * Sinkhorn-Knopp of sinkhorn_algorithm (modeling_repconc.py:137-165) on L = -d/eps, evaluated
- * with potentials: f[M,K], g[M,B] fp64.  One reference iteration (:153-163) = one rc_sk_pass +
- * one rc_sk_update; the rank-sum of :157 happens between them (the host all-gathers `rows`).
+ * Sinkhorn-Knopp of sinkhorn_algorithm (modeling_repconc.py:137-165) on L = -d/eps, evaluated with
+ * potentials f[M,K], g[M,B] (fp64) instead of the in-place matrix Q.  One launch per sweep over d:
  *
- *   rc_sk_pass(first=1):  rows[m,k] = sum_b exp(L[m,b,k])                      (:141,:155)
- *   rc_sk_update(first=1): f = -log(sum_r rows_all[r])                         (:157-158)
- *   rc_sk_pass(first=0):  w = exp(L + f_k + g_b); colsum_b = sum_k w;          (:162)
- *                         rows[m,k] = sum_b w/colsum_b                         (:155)
- *   rc_sk_update(first=0): g -= log(colsum);  f -= log(sum_r rows_all[r])
- *   rc_sk_argmax:         code[b,m] = argmax_k (L[m,b,k] + f[m,k]), first maximum (:63,:66)
+ *   rc_sk_sweep(t = 0):   rows[m,k] = sum_b exp(L[m,b,k])                                  (:141,:155)
+ *   rc_sk_sweep(t >= 1):  f -= log(sum_r rows_prev[r])   (f = 0 before t = 1)              (:157-158)
+ *                         g -= log(colsum of sweep t-1)  (g = 0 in sweep 1)                (:162)
+ *                         w = exp(L + f_k + g_b); colsum_b = sum_k w; rows[m,k] = sum_b w/colsum_b
+ *   rc_sk_argmax(t = T):  f -= log(sum_r rows_prev[r]);  code[b,m] = argmax_k (L + f), first max (:63,:66)
  *
- * T = sinkhorn_iterations needs: pass(first) , update(first), then T-1 x {pass, update}, then
- * argmax — T+1 sweeps over d in total.  The constants /K, /B, the global normalisation of :152
- * and the last column normalisation cancel in the argmax.
+ * T = sinkhorn_iterations is: sweeps t = 0 … T-1, then rc_sk_argmax(t = T) — T+1 reads of d.  Between two
+ * sweeps the host all-gathers `rows_out` of every rank into `rows_prev` [G,M,K] (rank-major; the rank sum of
+ * :157 is taken inside the next launch in rank order; on one rank pass rows_out itself, G = 1).  The
+ * constants /K, /B, the global normalisation of :152 and the last column normalisation cancel in the argmax.
  *
- * rows:     [M,K] fp64, this rank's row sums (written by rc_sk_pass)
- * rows_all: [G,M,K] fp64, every rank's `rows`, rank-major (G=1: pass `rows` itself)
- * colsum:   [M,B] fp64 scratch written by pass(first=0), consumed by update(first=0)
- * ws:       rc_sk_pass_ws_bytes(B, M, K) bytes (block partials)
- * flags:    one int, OR-ed with RC_FLAG_* (caller zeroes it)
+ * f2:       [2,M,K] fp64, potentials double-buffered by sweep parity (owned by the solve, no init needed)
+ * g,colsum: [M,B] fp64 (no init needed)
+ * rows_out: [M,K] fp64, this rank's row sums of the sweep
+ * ws:       rc_sk_ws_bytes(B, M, K) bytes (block partials + arrival counters; sweep 0 resets the counters)
+ * flags:    one int, OR-ed with RC_FLAG_* (caller zeroes it before sweep 0)
  */
-size_t rc_sk_pass_ws_bytes(int64_t B, int M, int K);
-int rc_sk_pass(rc_handle_t h, const float* d, const double* f, const double* g, double* colsum,
-               double* rows, int64_t B, int M, int K, double eps, int first, void* ws,
-               size_t ws_bytes, rc_stream_t stream);
-int rc_sk_update(rc_handle_t h, const double* rows_all, int G, double* f, double* g,
-                 const double* colsum, int64_t B, int M, int K, int first, int* flags,
+size_t rc_sk_ws_bytes(int64_t B, int M, int K);
+int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_prev, int G, double* f2, double* g,
+                double* colsum, double* rows_out, int64_t B, int M, int K, double eps, int t, int* flags,
+                void* ws, size_t ws_bytes, rc_stream_t stream);
+int rc_sk_argmax(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2, int64_t B,
+                 int M, int K, double eps, int t, uint8_t* codes_u8, int64_t* codes_i64, int* flags,
                  rc_stream_t stream);
-int rc_sk_argmax(rc_handle_t h, const float* d, const double* f, int64_t B, int M, int K,
-                 double eps, uint8_t* codes_u8, int64_t* codes_i64, rc_stream_t stream);
 
 /* ------------------------------------------------------------------ a-1 … a-4, one call
  * RepCONC.quantize with use_constraint=True on ONE rank (modeling_repconc.py:47-67,

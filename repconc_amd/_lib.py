@@ -33,10 +33,9 @@ PROTOTYPES = {
     "rc_pq_dist_table_ws_bytes": (_sz, [_i64, _i]),
     "rc_pq_dist_table": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rc_pq_centre": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
-    "rc_sk_pass_ws_bytes": (_sz, [_i64, _i, _i]),
-    "rc_sk_pass": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _d, _i, _vp, _sz, _vp]),
-    "rc_sk_update": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
-    "rc_sk_argmax": (_i, [_vp, _vp, _vp, _i64, _i, _i, _d, _vp, _vp, _vp]),
+    "rc_sk_ws_bytes": (_sz, [_i64, _i, _i]),
+    "rc_sk_sweep": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _d, _i, _vp, _vp, _sz, _vp]),
+    "rc_sk_argmax": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "rc_pq_assign_sinkhorn_ws_bytes": (_sz, [_i64, _i, _i]),
     "rc_pq_assign_sinkhorn": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_pq_decode": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),

@@ -151,10 +151,11 @@ def sinkhorn_algorithm(out: Tensor, epsilon: float, sinkhorn_iterations: int, us
         raise NotImplementedError("sinkhorn_algorithm: the cost matrix must be exactly representable in fp32")
     comm = TorchDistComm() if (use_distrib_train and dist.get_world_size() > 1) else SingleComm()
     st = ops.SinkhornState(d)
-    st.update(comm.allgather(st.sweep(epsilon, first=True)), first=True)
-    for _ in range(1, sinkhorn_iterations):
-        st.update(comm.allgather(st.sweep(epsilon, first=False)), first=False)
-    return torch.softmax(out / epsilon + st.f[:, :, None], dim=1)
+    rows = st.sweep(epsilon, 0, None)
+    for t in range(1, sinkhorn_iterations):
+        rows = st.sweep(epsilon, t, comm.allgather(rows))
+    f = st.potentials(sinkhorn_iterations, comm.allgather(rows))
+    return torch.softmax(out / epsilon + f[:, :, None], dim=1)
 
 
 def decode(codes: Union[np.ndarray, Tensor], centroids: Union[np.ndarray, Tensor]):

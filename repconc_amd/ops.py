@@ -120,42 +120,64 @@ def centre_(d: torch.Tensor, minmax: torch.Tensor) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- Sinkhorn stages
 class SinkhornState:
-    """Device buffers of one rank's Sinkhorn solve over a centred table d [M,B,K]."""
+    """Device buffers of one rank's Sinkhorn solve over a centred table d [M,B,K] (staged C ABI).
+
+        rows = st.sweep(eps, 0, None)                    # sweep 0
+        for t in 1 .. T-1:  rows = st.sweep(eps, t, gathered(rows))
+        codes = st.argmax(eps, T, gathered(rows))
+
+    `gathered(rows)` is the [G,M,K] stack of every rank's row sums (G = 1: rows.unsqueeze(0))."""
 
     def __init__(self, d: torch.Tensor):
         _need_cuda(d)
         self.d = d
         self.M, self.B, _ = d.shape
         dev = d.device
-        self.f = torch.empty((self.M, K), dtype=torch.float64, device=dev)
-        self.g = torch.zeros((self.M, self.B), dtype=torch.float64, device=dev)
+        self.f2 = torch.empty((2, self.M, K), dtype=torch.float64, device=dev)
+        self.g = torch.empty((self.M, self.B), dtype=torch.float64, device=dev)
         self.colsum = torch.empty((self.M, self.B), dtype=torch.float64, device=dev)
-        self.rows = torch.empty((self.M, K), dtype=torch.float64, device=dev)
+        self._rows = torch.empty((2, self.M, K), dtype=torch.float64, device=dev)
         self.flags = torch.zeros((1,), dtype=torch.int32, device=dev)
         lib = _lib.load()
-        self._wsb = lib.rc_sk_pass_ws_bytes(self.B, self.M, K)
+        self._wsb = lib.rc_sk_ws_bytes(self.B, self.M, K)
         self._ws = torch.empty((max(self._wsb, 1),), dtype=torch.uint8, device=dev)
 
-    def sweep(self, eps: float, first: bool) -> torch.Tensor:
-        lib, h, s, _ = _ctx(self.d)
-        _lib.check(lib.rc_sk_pass(h, _p(self.d), _p(self.f), _p(self.g), _p(self.colsum), _p(self.rows), self.B,
-                                  self.M, K, float(eps), int(first), _p(self._ws), self._wsb, s), "rc_sk_pass", h)
-        return self.rows
+    @staticmethod
+    def _gathered(rows_prev):
+        if rows_prev is None:
+            return None, 0
+        if rows_prev.dim() == 2:
+            rows_prev = rows_prev.unsqueeze(0)
+        return rows_prev.contiguous(), rows_prev.shape[0]
 
-    def update(self, rows_all: torch.Tensor, first: bool):
-        G = 1 if rows_all.dim() == 2 else rows_all.shape[0]
+    def sweep(self, eps: float, t: int, rows_prev: Optional[torch.Tensor]) -> torch.Tensor:
+        """Sweep t; returns this rank's row sums [M,K] (a buffer that stays valid until sweep t+2)."""
         lib, h, s, _ = _ctx(self.d)
-        _lib.check(lib.rc_sk_update(h, _p(rows_all), G, _p(self.f), _p(self.g), _p(self.colsum), self.B, self.M, K,
-                                    int(first), _p(self.flags), s), "rc_sk_update", h)
+        rp, G = self._gathered(rows_prev)
+        out = self._rows[t & 1]
+        _lib.check(lib.rc_sk_sweep(h, _p(self.d), _p(rp), G, _p(self.f2), _p(self.g), _p(self.colsum), _p(out),
+                                   self.B, self.M, K, float(eps), int(t), _p(self.flags), _p(self._ws), self._wsb, s),
+                   "rc_sk_sweep", h)
+        return out
 
-    def argmax(self, eps: float, dtype=torch.int64) -> torch.Tensor:
+    def argmax(self, eps: float, t: int, rows_prev: torch.Tensor, dtype=torch.int64) -> torch.Tensor:
         lib, h, s, _ = _ctx(self.d)
+        rp, G = self._gathered(rows_prev)
         codes = torch.empty((self.B, self.M), dtype=dtype, device=self.d.device)
         u8 = codes if dtype == torch.uint8 else None
         i64 = codes if dtype == torch.int64 else None
-        _lib.check(lib.rc_sk_argmax(h, _p(self.d), _p(self.f), self.B, self.M, K, float(eps), _p(u8), _p(i64), s),
-                   "rc_sk_argmax", h)
+        _lib.check(lib.rc_sk_argmax(h, _p(self.d), _p(rp), G, _p(self.f2), self.B, self.M, K, float(eps), int(t),
+                                    _p(u8), _p(i64), _p(self.flags), s), "rc_sk_argmax", h)
         return codes
+
+    def potentials(self, t: int, rows_prev: torch.Tensor) -> torch.Tensor:
+        """f [M,K] after t row normalisations (what rc_sk_argmax(t) uses); bookkeeping on [M,K] only."""
+        rp, _ = self._gathered(rows_prev)
+        tot = rp[0].clone()
+        for r in range(1, rp.shape[0]):
+            tot = tot + rp[r]
+        prev = torch.zeros_like(tot) if t == 1 else self.f2[(t - 1) & 1]
+        return prev - torch.log(tot)
 
 
 def assign_sinkhorn(x: torch.Tensor, centroids: torch.Tensor, eps: float, iters: int,

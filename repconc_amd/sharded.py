@@ -93,12 +93,10 @@ def assign_sinkhorn_sharded(x_local, centroids, eps: float, iters: int, comm, st
     comm.allreduce_minmax_(minmax, M)
     stages.centre_(d, minmax)
     st = stages.state(d)
-    rows = st.sweep(eps, first=True)
-    st.update(comm.allgather(rows), first=True)
-    for _ in range(1, iters):
-        rows = st.sweep(eps, first=False)
-        st.update(comm.allgather(rows), first=False)
-    return st.argmax(eps, dtype), st.flags
+    rows = st.sweep(eps, 0, None)
+    for t in range(1, iters):
+        rows = st.sweep(eps, t, comm.allgather(rows))
+    return st.argmax(eps, iters, comm.allgather(rows), dtype), st.flags
 
 
 def assign_sinkhorn_virtual(x_shards: Sequence, centroids, eps: float, iters: int, stages=None,
@@ -121,10 +119,7 @@ def assign_sinkhorn_virtual(x_shards: Sequence, centroids, eps: float, iters: in
     for d, _ in tabs:
         stages.centre_(d, mm)
         states.append(stages.state(d))
-    first = True
-    for _ in range(iters):
-        rows_all = torch.stack([st.sweep(eps, first=first).clone() for st in states], dim=0)
-        for st in states:
-            st.update(rows_all, first=first)
-        first = False
-    return [st.argmax(eps, dtype) for st in states], [st.flags for st in states]
+    gathered = None
+    for t in range(iters):
+        gathered = torch.stack([st.sweep(eps, t, gathered) for st in states], dim=0)
+    return [st.argmax(eps, iters, gathered, dtype) for st in states], [st.flags for st in states]

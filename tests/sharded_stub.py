@@ -18,29 +18,29 @@ class _State:
         self.colsum = None
         self.flags = torch.zeros(1, dtype=torch.int32)
 
-    def sweep(self, eps, first):
+    @staticmethod
+    def _ranksum(rows_prev):
+        rp = rows_prev if rows_prev.dim() == 3 else rows_prev.unsqueeze(0)
+        tot = np.zeros(tuple(rp.shape[1:]))
+        for r in range(rp.shape[0]):                                            # rank order
+            tot = tot + rp[r].numpy()
+        return tot
+
+    def sweep(self, eps, t, rows_prev):
         if self.L is None:
             self.L = -(self.d.numpy().astype(np.float64)) / eps
-        if first:
-            rows = np.exp(self.L).sum(axis=1)                                   # [M,K]
-        else:
-            w = np.exp(self.L + self.f[:, None, :] + self.g[:, :, None])
-            self.colsum = w.sum(axis=2)
-            rows = (w / self.colsum[:, :, None]).sum(axis=1)
-        return torch.from_numpy(rows)
-
-    def update(self, rows_all, first):
-        tot = np.zeros_like(self.f)
-        for r in range(rows_all.shape[0]):                                      # rank order
-            tot = tot + rows_all[r].numpy()
-        if first:
-            self.f = -np.log(tot)
-        else:
+        if t == 0:
+            return torch.from_numpy(np.exp(self.L).sum(axis=1))                # [M,K]
+        self.f = (self.f if t > 1 else 0.0) - np.log(self._ranksum(rows_prev))
+        if t > 1:
             self.g = self.g - np.log(self.colsum)
-            self.f = self.f - np.log(tot)
+        w = np.exp(self.L + self.f[:, None, :] + self.g[:, :, None])
+        self.colsum = w.sum(axis=2)
+        return torch.from_numpy((w / self.colsum[:, :, None]).sum(axis=1))
 
-    def argmax(self, eps, dtype=torch.int64):
-        return torch.from_numpy(np.argmax(self.L + self.f[:, None, :], axis=-1).T.copy()).to(dtype)
+    def argmax(self, eps, t, rows_prev, dtype=torch.int64):
+        f = (self.f if t > 1 else 0.0) - np.log(self._ranksum(rows_prev))
+        return torch.from_numpy(np.argmax(self.L + f[:, None, :], axis=-1).T.copy()).to(dtype)
 
 
 class NumpyStages:

@@ -33,7 +33,7 @@ def test_size_helpers_need_no_gpu():
     assert d_bytes < ws < d_bytes * 1.05          # the distance table dominates the workspace
     assert lib.rc_pq_assign_sinkhorn_ws_bytes(B, M, 128) == 0   # K must be 256
     assert lib.rc_adc_search_ws_bytes(8841823, 48, 256, 1200, 1000) > 1200 * 48 * 256 * 4
-    assert lib.rc_sk_pass_ws_bytes(6144, 48, 256) % 256 == 0
+    assert lib.rc_sk_ws_bytes(6144, 48, 256) % 256 == 0
 
 
 def test_cpu_tensors_are_rejected_loudly():

@@ -375,3 +375,69 @@ def test_mrr_parity_planted_relevance():
     positives = [{int(p)} for p in pos]
     got, want = pq_oracle.mrr_at_k(ids.cpu().numpy(), positives), pq_oracle.mrr_at_k(wi, positives)
     assert abs(got - want) <= 0.001 and got == want
+
+
+def test_diagnostics_match_oracle():
+    """eval_balance / test_quantize (finetune_repconc.py:580-613) against the oracle's restatement."""
+    from types import SimpleNamespace
+    from repconc_amd.diagnostics import eval_balance, test_quantize as hip_test_quantize
+    from repconc_amd.models.repconc import RepCONC
+    g, x, C = load_case("m48_b1024_sample")
+    for arr in (g["codes_constrained"], g["codes_nearest"]):
+        for blk in (0, 17):
+            assert eval_balance(_t(arr), False, blk) == pq_oracle.eval_balance(arr, blk)
+    cfg = SimpleNamespace(MCQ_M=48, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_IP")
+    model = RepCONC(cfg, _TableEncoder(torch.zeros(1, 768)), True, EPS, ITERS).to(DEV)
+    with torch.no_grad():
+        model.centroids.copy_(_t(C))
+    got = hip_test_quantize(_t(x), model, -1)
+    want = pq_oracle.test_quantize(x, C, EPS, ITERS)
+    assert got == want and model.use_constraint is True
+
+
+def test_warmup_opq_pq():
+    """train/run_warmup.py:85-132 restated: PQ k-means lowers the reconstruction error monotonically-ish, OPQ
+    does not make it worse, the returned index holds the nearest codes of the rotated corpus."""
+    from types import SimpleNamespace
+    from repconc_amd.models.repconc import RepCONC
+    from repconc_amd.train.run_warmup import train_pq, warmup_from_embeds
+    rng = np.random.default_rng(5)
+    N, M = 20000, 48
+    mix = rng.standard_normal((768, 768), dtype=np.float32) / np.sqrt(768)
+    x = (synth.clustered_embeddings(6, N) @ mix).astype(np.float32)          # correlated dimensions: OPQ helps
+    xt = _t(x)
+    _, mse0 = train_pq(xt, M, 0)
+    _, mse5 = train_pq(xt, M, 5)
+    _, mse15 = train_pq(xt, M, 15)
+    assert mse15 <= mse5 < mse0
+    # one Lloyd step against the oracle's restatement
+    C0 = synth.sample_centroids(7, x, M)
+    codes = pq_oracle.quantize(x[:4096], C0, False)
+    s, c = pq_oracle.kmeans_stats(x[:4096], codes, M)
+    want = pq_oracle.kmeans_update(s, c, C0)
+    sums, cnt = ops_kmeans(xt[:4096], _t(codes.astype(np.uint8)))
+    from repconc_amd import ops
+    got = ops.kmeans_update_(sums, cnt, _t(C0).clone()).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
+    cfg = SimpleNamespace(MCQ_M=M, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_IP")
+    model = RepCONC(cfg, _TableEncoder(torch.zeros(1, 768)), False, None, None).to(DEV)
+    model, index = warmup_from_embeds(x, model, opq_iters=6, pq_iters=10)
+    R = model.rotation.detach()
+    assert torch.allclose(R @ R.T, torch.eye(768, device=DEV), atol=1e-4), float((R @ R.T - torch.eye(768, device=DEV)).abs().max())
+    assert index.index.ntotal == N
+    xr = (xt @ R.T).contiguous()
+    codes = index.index.codes
+    assert torch.equal(codes, ops.assign_nearest(xr, model.centroids, torch.uint8))
+    mse_opq = float(((ops.decode_raw(codes, model.centroids) - xr) ** 2).sum(-1).mean())
+    assert mse_opq < mse15 * 1.02
+    # rotated search == plain ADC on rotated queries
+    q = x[:5]
+    s1, i1 = index.search(q, 10)
+    s2, i2 = index.index.search((xt[:5] @ R.T).cpu().numpy(), 10)
+    assert np.array_equal(i1, i2)
+    assert all(int(i1[r, 0]) == r or s1[r, 0] >= s1[r, 1] for r in range(5))
+
+
+def ops_kmeans(x, codes):
+    from repconc_amd import ops
+    return ops.kmeans_stats(x, codes)
