@@ -168,18 +168,22 @@ __global__ __launch_bounds__(256) void centre_kernel(float* __restrict__ d, cons
 // Nearest code (index build): thread = one row b, loop over sub-quantisers and centroids.
 // The row slice lives in VGPRs; C[m,k,:] is wave-uniform (scalar loads); running (min, argmin)
 // needs no cross-lane traffic.  First minimum wins (strict <), as torch.argmin does.
-// Codes are staged in LDS and written as one contiguous, coalesced [rows, M] byte slab.
+// grid = (row blocks, m-chunks): blockIdx.y owns the sub-quantisers [y*mc, (y+1)*mc).  For a large
+// corpus there is one chunk (mc = M) and the codes go out as one contiguous, coalesced [rows, M] byte slab
+// staged in LDS; small batches split M so that the grid still fills 256 CUs.
 template <int DSUB>
 __global__ __launch_bounds__(256) void assign_nearest_kernel(const float* __restrict__ x, int64_t ldx,
                                                              const float* __restrict__ C, int64_t B,
-                                                             int M, uint8_t* __restrict__ codes_u8,
+                                                             int M, int mc, uint8_t* __restrict__ codes_u8,
                                                              int64_t* __restrict__ codes_i64) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];  // [256][M]
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];  // [256][mc]
     const int tid = threadIdx.x;
     const int64_t b = (int64_t)blockIdx.x * 256 + tid;
     const bool live = b < B;
     const float* xrow = x + (live ? b : (B - 1)) * ldx;
-    for (int m = 0; m < M; ++m) {
+    const int m0 = blockIdx.y * mc;
+    for (int mi = 0; mi < mc; ++mi) {
+        const int m = m0 + mi;
         float xs[DSUB];
         const float4* xp = reinterpret_cast<const float4*>(xrow + m * DSUB);
 #pragma unroll
@@ -195,22 +199,30 @@ __global__ __launch_bounds__(256) void assign_nearest_kernel(const float* __rest
             const float s = sqdist_exact<DSUB>(xs, cm + k * DSUB);
             if (s < best) { best = s; bi = k; }
         }
-        tile[tid * M + m] = (unsigned char)bi;
+        tile[tid * mc + mi] = (unsigned char)bi;
     }
     __syncthreads();
     const int64_t row0 = (int64_t)blockIdx.x * 256;
     const int64_t rows = (B - row0 < 256) ? (B - row0) : 256;
-    const int64_t nbytes = rows * M;
-    if (codes_u8) {
-        unsigned char* dst = codes_u8 + row0 * M;  // row0*M is a multiple of 16 (256*M)
-        const int64_t n16 = nbytes / 16;
-        for (int64_t i = tid; i < n16; i += 256)
-            reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(tile)[i];
-        for (int64_t i = n16 * 16 + tid; i < nbytes; i += 256) dst[i] = tile[i];
-    }
-    if (codes_i64) {
-        int64_t* dst = codes_i64 + row0 * M;
-        for (int64_t i = tid; i < nbytes; i += 256) dst[i] = (int64_t)tile[i];
+    if (mc == M) {
+        const int64_t nbytes = rows * M;
+        if (codes_u8) {
+            unsigned char* dst = codes_u8 + row0 * M;  // row0*M is a multiple of 16 (256*M)
+            const int64_t n16 = nbytes / 16;
+            for (int64_t i = tid; i < n16; i += 256)
+                reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(tile)[i];
+            for (int64_t i = n16 * 16 + tid; i < nbytes; i += 256) dst[i] = tile[i];
+        }
+        if (codes_i64) {
+            int64_t* dst = codes_i64 + row0 * M;
+            for (int64_t i = tid; i < nbytes; i += 256) dst[i] = (int64_t)tile[i];
+        }
+    } else if (live) {
+        for (int mi = 0; mi < mc; ++mi) {
+            const unsigned char c = tile[tid * mc + mi];
+            if (codes_u8) codes_u8[b * M + m0 + mi] = c;
+            if (codes_i64) codes_i64[b * M + m0 + mi] = (int64_t)c;
+        }
     }
 }
 
@@ -271,11 +283,16 @@ extern "C" int rc_pq_assign_nearest(rc_handle_t h, const float* x, int64_t ldx, 
     if (((uintptr_t)x & 15) || (ldx % 4) != 0) return RC_EINVAL;  // float4 row loads
     if (B == 0) return RC_OK;
     const int64_t nblk = (B + 255) / 256;
-    const size_t lds = (size_t)256 * M;
+    // m-chunks: the smallest split of M (a divisor) that gives the grid >= ~8 blocks per CU
+    int chunks = 1;
+    for (int c = 1; c <= M; ++c)
+        if (M % c == 0) { chunks = c; if (nblk * c >= (int64_t)h->num_cus * 8) break; }
+    const int mc = M / chunks;
+    const size_t lds = (size_t)256 * mc;
     hipStream_t s = (hipStream_t)stream;
     rc_prof_mark(h, RC_PROF_ASSIGN_NEAREST, s);
-    RC_DISPATCH_DSUB(D / M, hipLaunchKernelGGL(assign_nearest_kernel<DSUB>, dim3((unsigned)nblk), dim3(256), lds, s, x, ldx,
-                                               C, B, M, codes_u8, codes_i64));
+    RC_DISPATCH_DSUB(D / M, hipLaunchKernelGGL(assign_nearest_kernel<DSUB>, dim3((unsigned)nblk, (unsigned)chunks), dim3(256),
+                                               lds, s, x, ldx, C, B, M, mc, codes_u8, codes_i64));
     rc_prof_mark(h, RC_PROF_ASSIGN_NEAREST, s);
     RC_LAUNCH_CHECK(h);
     return RC_OK;

@@ -1,0 +1,47 @@
+"""ADC search over a ROW-SHARDED index: every rank holds rows [offset, offset + n_local) of the
+code matrix, searches its shard, and the per-rank top-k lists are all-gathered and merged with the same order
+as the single-index search, (score descending, id ascending).  The reference only replicates the index on every
+GPU (`co.shard = False`, models/repconc/evaluate_repconc.py:131-134 — also available here: give every rank the
+whole index and a slice of the queries); sharding is what makes an index larger than one GPU searchable and
+divides the scan time by the number of ranks.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.distributed as dist
+
+from .index import PQIndex
+
+
+def merge_topk(scores_parts: torch.Tensor, ids_parts: torch.Tensor, k: int):
+    """scores_parts / ids_parts: [G, nq, k] per-shard results (ids global, -1 = empty).  Returns the merged
+    [nq, k] lists.  Two stable sorts on G*k items per query — bookkeeping, not the scan."""
+    G, nq, kk = scores_parts.shape
+    s = scores_parts.permute(1, 0, 2).reshape(nq, G * kk)
+    i = ids_parts.permute(1, 0, 2).reshape(nq, G * kk)
+    big = torch.where(i < 0, torch.full_like(i, torch.iinfo(torch.int64).max), i)
+    order = torch.argsort(big, dim=1, stable=True)                 # id ascending
+    s, i = torch.gather(s, 1, order), torch.gather(i, 1, order)
+    order = torch.argsort(s, dim=1, descending=True, stable=True)  # then score descending, ties keep id order
+    return torch.gather(s, 1, order)[:, :k].contiguous(), torch.gather(i, 1, order)[:, :k].contiguous()
+
+
+def sharded_search(index: PQIndex, q: torch.Tensor, k: int, group=None):
+    """`index` holds this rank's rows with `index.id_offset` = global id of its first row."""
+    scores, ids = index.search(q, k)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return scores, ids
+    G = dist.get_world_size(group)
+    all_s = torch.empty((G,) + tuple(scores.shape), dtype=scores.dtype, device=scores.device)
+    all_i = torch.empty((G,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+    dist.all_gather_into_tensor(all_s.view(-1), scores.contiguous().view(-1), group=group)
+    dist.all_gather_into_tensor(all_i.view(-1), ids.contiguous().view(-1), group=group)
+    return merge_topk(all_s, all_i, k)
+
+
+def search_virtual_shards(shards: Sequence[PQIndex], q: torch.Tensor, k: int):
+    """The same merge with the shards held by one process (single-GPU boxes, tests)."""
+    parts = [sh.search(q, k) for sh in shards]
+    return merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)

@@ -441,3 +441,93 @@ def test_warmup_opq_pq():
 def ops_kmeans(x, codes):
     from repconc_amd import ops
     return ops.kmeans_stats(x, codes)
+
+
+# ------------------------------------------------------------------------------------------- BASELINE sizes
+def test_full_batch_properties_49152_m48():
+    """BASELINE configs[1]/[2] shape (one 49 152 x 768 training batch, M = 48): size-independent properties.
+    (a) 8 virtual ranks of 6144 rows (the 8-GPU recipe) give the codes of the single-rank solve,
+    (b) every centroid of every sub-quantiser receives its share of the batch (the constraint),
+    (c) the result is identical run to run, (d) decode(quantize) beats random codes by a wide margin but is
+    worse than the unconstrained nearest codes (the MSE ordering the reference logs in test_quantize)."""
+    from repconc_amd import ops
+    from repconc_amd.sharded import assign_sinkhorn_virtual
+    B, M = 49152, 48
+    x = _t(synth.gaussian(20220, (B, 768)))
+    C = x[torch.from_numpy(np.random.default_rng(20221).permutation(B)[:256].copy()).to(DEV)]
+    C = C.reshape(256, M, 16).transpose(0, 1).contiguous()
+    codes, flags = ops.assign_sinkhorn(x, C, EPS, ITERS, torch.uint8)
+    assert int(flags.item()) == 0
+    codes2, _ = ops.assign_sinkhorn(x, C, EPS, ITERS, torch.uint8)
+    assert torch.equal(codes, codes2)                                               # (c)
+    hist = ops.code_hist(codes).float()
+    assert float((hist / (B / 256) - 1).abs().max()) < 0.15                         # (b) ideal 192 per centroid
+    near = ops.assign_nearest(x, C, torch.uint8)
+    hn = ops.code_hist(near).float()
+    assert float((hn / (B / 256) - 1).abs().max()) > 1.0                            # nearest codes are unbalanced
+    shards, fl = assign_sinkhorn_virtual([x[r * 6144:(r + 1) * 6144] for r in range(8)], C, EPS, ITERS,
+                                         dtype=torch.uint8)
+    assert torch.equal(torch.cat(shards, 0), codes)                                 # (a)
+    mse_c = float(((ops.decode_raw(codes, C) - x) ** 2).sum(-1).mean())
+    mse_n = float(((ops.decode_raw(near, C) - x) ** 2).sum(-1).mean())
+    rnd = torch.randint(0, 256, (B, M), dtype=torch.uint8, device=DEV)
+    mse_r = float(((ops.decode_raw(rnd, C) - x) ** 2).sum(-1).mean())
+    assert mse_n < mse_c < 0.8 * mse_r                                              # (d)
+    # a slice of the batch against the C oracle's nearest codes (exact) — the constrained codes of a slice are a
+    # different problem, so only the unconstrained path can be sliced
+    assert np.array_equal(near[:2048].cpu().numpy(), c_oracle.quantize(x[:2048].cpu().numpy(), C.cpu().numpy(), False)[0])
+
+
+@pytest.mark.parametrize("M", [24, 96, 8])
+def test_other_config_shapes_constrained(M):
+    """BASELINE configs[3] (M = 96), [4] (M = 24) and [0] (M = 8) sub-vector widths on a 4096-row batch vs the oracle."""
+    from repconc_amd import ops
+    B = 4096
+    x = synth.clustered_embeddings(300 + M, B)
+    C = synth.sample_centroids(301 + M, x, M)
+    want, fl = c_oracle.quantize(x, C, True, EPS, ITERS)
+    got, flags = ops.assign_sinkhorn(_t(x), _t(C), EPS, ITERS, torch.uint8)
+    assert fl == 0 and int(flags.item()) == 0
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(ops.assign_nearest(_t(x), _t(C), torch.uint8).cpu().numpy(), c_oracle.quantize(x, C, False)[0])
+
+
+def test_row_sharded_index_search_equals_whole_index():
+    from repconc_amd.index import PQIndex
+    from repconc_amd.sharded_search import search_virtual_shards
+    C, codes, q = _adc_case(48, 90001, 7, seed=31)
+    codes[50000:50040] = codes[10:50]                      # duplicates straddling shard boundaries -> score ties
+    whole = PQIndex(768, 48, device=DEV)
+    whole.set_centroids(C)
+    whole.add_codes(codes)
+    bounds = [0, 30000, 30001, 65536, 90001]
+    shards = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        sh = PQIndex(768, 48, device=DEV)
+        sh.set_centroids(C)
+        sh.add_codes(codes[a:b])
+        sh.id_offset = a
+        shards.append(sh)
+    for k in (10, 300):
+        ws, wi = whole.search(_t(q), k)
+        gs, gi = search_virtual_shards(shards, _t(q), k)
+        assert torch.equal(wi, gi) and torch.equal(ws, gs)
+
+
+def test_faiss_indexpq_file_round_trip(tmp_path):
+    from repconc_amd.faiss_io import read_index, write_index
+    from repconc_amd.index import PQIndex
+    C, codes, q = _adc_case(24, 12345, 3, seed=77)
+    idx = PQIndex(768, 24, device=DEV)
+    idx.set_centroids(C)
+    idx.add_codes(codes)
+    p = str(tmp_path / "index")
+    write_index(idx, p)
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"IxPq" and len(raw) == 4 + 33 + 24 + 8 + 24 * 256 * 32 * 4 + 8 + 12345 * 24 + 9
+    back = read_index(p, device=DEV)
+    assert back.ntotal == 12345 and back.pq.M == 24 and torch.equal(back.codes, idx.codes)
+    assert torch.equal(back.pq.centroids, idx.pq.centroids)
+    s1, i1 = idx.search(q, 20)
+    s2, i2 = back.search(q, 20)
+    assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
