@@ -152,7 +152,7 @@ def main():
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if n_l.value else 0.0
     roofline = {"kernel": "sk_pass_kernel<false> (Sinkhorn sweep)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic("sk_pass_kernel"), "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic": pmc_traffic("sk_sweep_kernel"), "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(sweep_ms, 4), "launches_timed": n_l.value}
 
     # balance sanity of the last batch (every centroid gets ~B/K of the global batch)
@@ -211,12 +211,13 @@ def main():
             "index": f"{N_CORPUS} x {M} B uint8 uniform codes, resident", "query_batch": nq_batch,
             "batches": args.adc_batches, "ms_per_batch": round(adt / args.adc_batches * 1e3, 2),
             "parallelism": f"index replicated, queries split x{world}",
-            "roofline": {"kernel": "adc_scan_kernel<48,2,FILTER>", "bound": "hbm", "achieved": round(adc_ach, 1),
+            "roofline": {"kernel": "adc_screen_kernel<48,8> (8-bit screening scan)", "bound": "hbm", "achieved": round(adc_ach, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(adc_ach / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("adc_scan_kernel"), "algorithmic_bytes_per_launch": adc_alg,
+                         "traffic": pmc_traffic("adc_screen_kernel"), "algorithmic_bytes_per_launch": adc_alg,
                          "avg_launch_ms": round(scan_ms, 3), "launches_timed": n_l.value,
-                         "note": "algorithmic bytes = N*M per query; blocks share code tiles through L2, so "
-                                 "frac > 1 is possible — the physical limit is the LDS gather rate"},
+                         "note": "algorithmic bytes = N*M code bytes per query (SURVEY 8d); 8 queries share every code "
+                                 "read and tiles are re-read from L2, so frac > 1 — the physical limits are the LDS "
+                                 "gather rate and the VALU byte accumulation (DESIGN.md §4)"},
         }
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)

@@ -13,8 +13,16 @@
 //   3. adc_threshold_kernel  per query: the r-th largest sample score (LDS radix select) = tau_q;
 //                            r is chosen so that ~ (r/S)*N >> k rows pass, i.e. the true top-k are
 //                            all >= tau_q with overwhelming probability (host checks the count)
-//   4. adc_scan_kernel<FILTER> full scan: rows with score >= tau_q are appended (wave-aggregated
-//                            atomics) to a per-query candidate list of 64-bit keys
+//   4. full scan, rows with score >= tau_q are appended (wave-aggregated atomics) to a per-query candidate
+//      list of 64-bit keys.  Two implementations with IDENTICAL output:
+//        a. adc_scan_kernel<FILTER>: exact fp32 scores for every row (small indexes);
+//        b. integer screening (N >= 2^18): adc_qlut_kernel quantises each query's tables to 8 bits with a
+//           common step Delta_q (l = floor((LUT - min_m)/Delta_q)); adc_screen_kernel sums the bytes of 8
+//           queries per LDS gather (one ds_read_b64 serves 8 queries instead of 2) and keeps every row with
+//           S_int >= T_q, where T_q = ceil((tau_q - sum_m min_m)/Delta_q) - (M+2) is a RIGOROUS lower bound
+//           (sum of the M floor errors < M, plus float rounding), so no row with exact score >= tau_q is ever
+//           lost; adc_rescore_kernel then computes the exact fp32 score of the survivors (~1.7x the final
+//           candidates) and applies the exact test.  The candidate set, hence the result, is the same as (a).
 //   5. adc_select_kernel     per query: bitonic sort of the candidates in LDS, emit top-k
 //
 // The scan is the hot kernel.  A block keeps the LUTs of QT queries in LDS, interleaved
@@ -22,6 +30,10 @@
 // (consecutive lanes = consecutive rows, 16-byte loads).  Blocks that share a code tile are
 // adjacent in the grid, so a tile is fetched from HBM about once per XCD and re-read from L2.
 #include "rc_common.h"
+
+#include <limits.h>
+
+#include <type_traits>
 
 #define ADC_THREADS 1024
 #define ADC_SAMPLE_MAX 32768
@@ -247,11 +259,216 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(const unsigned long lo
     }
 }
 
+// ------------------------------------------------------------------------------------------ 4b. screening
+#define ADC_SCREEN_MIN_N (1 << 18)
+#define ADC_ID_CAP 32768
+
+// One block per query: per-m minimum, the common step Delta = max_m(range_m)/255, the integer threshold and
+// the byte tables, written interleaved [group][m][c][QS] (group = query / QS) so the screen kernel copies one
+// contiguous slab per block.
+__global__ __launch_bounds__(RC_K) void adc_qlut_kernel(const float* __restrict__ lut, const float* __restrict__ thr,
+                                                        int M, int QS, uint8_t* __restrict__ qlut,
+                                                        int* __restrict__ tint) {
+    __shared__ float lo_m[128];
+    __shared__ float red_lo[4], red_hi[4];
+    __shared__ float s_delta;
+    const int qi = blockIdx.x, c = threadIdx.x;
+    const float* lq = lut + (size_t)qi * M * RC_K;
+    float maxrange = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float v = lq[m * RC_K + c];
+        float lo = v, hi = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if ((c & 63) == 0) { red_lo[c >> 6] = lo; red_hi[c >> 6] = hi; }
+        __syncthreads();
+        lo = fminf(fminf(red_lo[0], red_lo[1]), fminf(red_lo[2], red_lo[3]));
+        hi = fmaxf(fmaxf(red_hi[0], red_hi[1]), fmaxf(red_hi[2], red_hi[3]));
+        if (c == 0) lo_m[m] = lo;
+        maxrange = fmaxf(maxrange, hi - lo);
+        __syncthreads();
+    }
+    if (c == 0) {
+        float delta = maxrange / 255.0f;
+        if (!(delta > 0.f)) delta = 1.0f;
+        s_delta = delta;
+        double A = 0.0;
+        for (int m = 0; m < M; ++m) A += (double)lo_m[m];
+        const float t = thr[qi];
+        int T;
+        if (t == -INFINITY) {
+            T = INT_MIN;
+        } else {
+            const double v = ceil(((double)t - A) / (double)delta) - (double)(M + 2);
+            T = v < -2.0e9 ? INT_MIN : (v > 2.0e9 ? INT_MAX : (int)v);
+        }
+        tint[qi] = T;
+    }
+    __syncthreads();
+    const float delta = s_delta;
+    uint8_t* dst = qlut + (size_t)(qi / QS) * M * RC_K * QS + (qi % QS);
+    for (int m = 0; m < M; ++m) {
+        const float v = (lq[m * RC_K + c] - lo_m[m]) / delta;
+        int l = (int)floorf(v);
+        l = l < 0 ? 0 : (l > 255 ? 255 : l);
+        dst[((size_t)m * RC_K + c) * QS] = (uint8_t)l;
+    }
+}
+
+// grid (query groups of QS, doc tiles).  LDS: [M][256] entries of QS bytes (uint2 for QS = 8, uint for 4).
+template <int M, int QS>
+__global__ __launch_bounds__(ADC_THREADS) void adc_screen_kernel(const uint8_t* __restrict__ codes, int64_t N,
+                                                                 const uint8_t* __restrict__ qlut,
+                                                                 const int* __restrict__ tint, int nq,
+                                                                 unsigned* __restrict__ id_count,
+                                                                 unsigned* __restrict__ ids) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using E = typename std::conditional<QS == 8, uint2, unsigned>::type;
+    E* tab = reinterpret_cast<E*>(smem);
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * QS;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(qlut + (size_t)blockIdx.x * M * RC_K * QS);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < M * RC_K * QS / 16; i += ADC_THREADS) dst[i] = src[i];
+    }
+    int tq[QS];
+#pragma unroll
+    for (int t = 0; t < QS; ++t) tq[t] = (q0 + t < nq) ? tint[q0 + t] : INT_MAX;
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.y * ADC_TILE_DOCS;
+    const int64_t t1 = (t0 + ADC_TILE_DOCS < N) ? t0 + ADC_TILE_DOCS : N;
+    constexpr int W = (M % 16 == 0) ? 16 : (M % 8 == 0) ? 8 : 4;
+    constexpr int NW = M / W;
+    // the row of the NEXT trip is loaded before the current one is scored (register double buffer), so the
+    // code loads (L2 latency) overlap the 48 gathers of the current row
+    auto load_row = [&](int64_t n, unsigned (&dst)[M / 4]) {
+        const uint8_t* cp = codes + (n < t1 ? n : (t1 - 1)) * M;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            if constexpr (W == 16) {
+                const uint4 v = reinterpret_cast<const uint4*>(cp)[j];
+                dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w;
+            } else if constexpr (W == 8) {
+                const uint2 v = reinterpret_cast<const uint2*>(cp)[j];
+                dst[2 * j] = v.x; dst[2 * j + 1] = v.y;
+            } else {
+                dst[j] = reinterpret_cast<const unsigned*>(cp)[j];
+            }
+        }
+    };
+    unsigned w[M / 4], wn[M / 4];
+    load_row(t0 + tid, w);
+    for (int64_t i0 = t0; i0 < t1; i0 += ADC_THREADS) {
+        const int64_t n = i0 + tid;
+        const bool live = n < t1;
+        load_row(n + ADC_THREADS, wn);
+        // Byte accumulation in packed 16-bit fields: one v_perm_b32 spreads bytes (0,2) of a gathered word into
+        // the two halves of a dword, another bytes (1,3); plain 32-bit adds then accumulate two queries at
+        // once (a field never exceeds 96*255 < 2^16, so no carry crosses).  4 full-rate VALU ops per 4 queries —
+        // v_dot4_u32_u8 with a one-hot mask does one query per instruction at half rate (PMC: VALU-bound at
+        // 11.5 instr/gather, 4 cycles each).
+        unsigned pe[QS / 4], po[QS / 4];
+#pragma unroll
+        for (int u = 0; u < QS / 4; ++u) pe[u] = po[u] = 0u;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const unsigned c = (w[m >> 2] >> (8 * (m & 3))) & 0xFFu;
+            const E v = tab[m * RC_K + c];
+            if constexpr (QS == 8) {
+                pe[0] += __builtin_amdgcn_perm(0u, v.x, 0x0C020C00u);
+                po[0] += __builtin_amdgcn_perm(0u, v.x, 0x0C030C01u);
+                pe[1] += __builtin_amdgcn_perm(0u, v.y, 0x0C020C00u);
+                po[1] += __builtin_amdgcn_perm(0u, v.y, 0x0C030C01u);
+            } else {
+                pe[0] += __builtin_amdgcn_perm(0u, v, 0x0C020C00u);
+                po[0] += __builtin_amdgcn_perm(0u, v, 0x0C030C01u);
+            }
+        }
+        int acc[QS];   // query t = 4u + j: byte j of word u -> (j even ? pe : po)[u], field j/2
+#pragma unroll
+        for (int u = 0; u < QS / 4; ++u) {
+            acc[4 * u + 0] = (int)(pe[u] & 0xFFFFu);
+            acc[4 * u + 1] = (int)(po[u] & 0xFFFFu);
+            acc[4 * u + 2] = (int)(pe[u] >> 16);
+            acc[4 * u + 3] = (int)(po[u] >> 16);
+        }
+#pragma unroll
+        for (int t = 0; t < QS; ++t) {
+            const bool pass = live && (acc[t] >= tq[t]);
+            const unsigned long long mask = __ballot(pass);
+            if (mask) {  // wave-uniform
+                const int lane = tid & 63;
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                unsigned base = 0;
+                if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(id_count + q0 + t, (unsigned)__popcll(mask));
+                base = __shfl(base, (int)__builtin_ctzll(mask));
+                const unsigned slot = base + rank;
+                if (pass && slot < ADC_ID_CAP) ids[(size_t)(q0 + t) * ADC_ID_CAP + slot] = (unsigned)n;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < M / 4; ++j) w[j] = wn[j];
+    }
+}
+
+// One block per query: exact fp32 score (m ascending, from 0) of every screened row; rows with score >= tau go
+// to the key list exactly as adc_scan_kernel<FILTER> would have put them.
+template <int M>
+__global__ __launch_bounds__(256) void adc_rescore_kernel(const uint8_t* __restrict__ codes,
+                                                          const float* __restrict__ lut,
+                                                          const float* __restrict__ thr,
+                                                          const unsigned* __restrict__ id_count,
+                                                          const unsigned* __restrict__ ids,
+                                                          unsigned* __restrict__ cand_count,
+                                                          unsigned long long* __restrict__ cand,
+                                                          int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tab = reinterpret_cast<float*>(smem);  // [M][256]
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < M * RC_K; i += 256) tab[i] = lut[(size_t)qi * M * RC_K + i];
+    const unsigned raw = id_count[qi];
+    const unsigned cnt = raw > ADC_ID_CAP ? ADC_ID_CAP : raw;
+    if (tid == 0 && raw > ADC_ID_CAP) atomicOr(status, 2);
+    const float tau = thr[qi];
+    __syncthreads();
+    for (unsigned i0 = 0; i0 < cnt; i0 += 256) {
+        const unsigned i = i0 + tid;
+        const bool live = i < cnt;
+        const unsigned n = ids[(size_t)qi * ADC_ID_CAP + (live ? i : 0)];
+        const unsigned* cp = reinterpret_cast<const unsigned*>(codes + (size_t)n * M);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < M / 4; ++j) {
+            const unsigned w = cp[j];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s = s + tab[(4 * j + b) * RC_K + ((w >> (8 * b)) & 0xFFu)];
+        }
+        const bool pass = live && (s >= tau);
+        const unsigned long long mask = __ballot(pass);
+        if (mask) {
+            const int lane = tid & 63;
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            unsigned base = 0;
+            if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(cand_count + qi, (unsigned)__popcll(mask));
+            base = __shfl(base, (int)__builtin_ctzll(mask));
+            const unsigned slot = base + rank;
+            if (pass && slot < ADC_CAND_CAP)
+                cand[(size_t)qi * ADC_CAND_CAP + slot] =
+                    ((unsigned long long)adc_order_key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - n);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 struct adc_ws_layout {
-    size_t lut, sample, thr, cnt, cand, total;
+    size_t lut, sample, thr, cnt, cand, qlut, tint, idcnt, ids, total;
     int64_t S;
 };
+static int adc_qs_for(int M) { return M <= 64 ? 8 : 4; }   // queries per byte gather (LDS: M*256*QS bytes)
 static adc_ws_layout adc_layout(int64_t N, int M, int nq) {
     adc_ws_layout L;
     L.S = N < ADC_SAMPLE_MAX ? N : ADC_SAMPLE_MAX;
@@ -261,6 +478,14 @@ static adc_ws_layout adc_layout(int64_t N, int M, int nq) {
     L.thr = o;    o += rc_align_up((size_t)nq * sizeof(float), 256);
     L.cnt = o;    o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
     L.cand = o;   o += rc_align_up((size_t)nq * ADC_CAND_CAP * sizeof(unsigned long long), 256);
+    L.qlut = L.tint = L.idcnt = L.ids = o;
+    if (N >= ADC_SCREEN_MIN_N) {
+        const int QS = adc_qs_for(M);
+        L.qlut = o;  o += rc_align_up((size_t)((nq + QS - 1) / QS) * M * RC_K * QS, 256);
+        L.tint = o;  o += rc_align_up((size_t)nq * sizeof(int), 256);
+        L.idcnt = o; o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
+        L.ids = o;   o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
+    }
     L.total = o;
     return L;
 }
@@ -276,34 +501,60 @@ static int adc_qt_for(int M) {
     return 1;                // M=96: 96 KiB
 }
 
+struct adc_bufs {
+    float* lut; float* sample; float* thr; unsigned* cnt; unsigned long long* cand;
+    uint8_t* qlut; int* tint; unsigned* idcnt; unsigned* ids;
+};
+
 template <int M, int QT>
-static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, const float* lut, int nq, int64_t S,
-                            float* sample, float* thr, unsigned* cnt, unsigned long long* cand, int r,
-                            hipStream_t s) {
+static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int nq, int64_t S, const adc_bufs& b, int r,
+                            int* status, hipStream_t s) {
     const size_t lds = (size_t)M * RC_K * QT * sizeof(float);
     const unsigned qg = (unsigned)((nq + QT - 1) / QT);
     auto ksample = adc_scan_kernel<M, QT, ADC_SAMPLE>;
     auto kfilter = adc_scan_kernel<M, QT, ADC_FILTER>;
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)ksample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kfilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ksample, dim3(qg, (unsigned)((S + ADC_TILE_DOCS - 1) / ADC_TILE_DOCS)), dim3(ADC_THREADS), lds, s,
-                       codes, N, lut, nq, S, sample, thr, cnt, cand);
+                       codes, N, b.lut, nq, S, b.sample, b.thr, b.cnt, b.cand);
     RC_LAUNCH_CHECK(h);
     const size_t tl = (size_t)S * sizeof(unsigned);
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)adc_threshold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tl));
-    hipLaunchKernelGGL(adc_threshold_kernel, dim3((unsigned)nq), dim3(1024), tl, s, sample, S, r, thr);
+    hipLaunchKernelGGL(adc_threshold_kernel, dim3((unsigned)nq), dim3(1024), tl, s, b.sample, S, r, b.thr);
     RC_LAUNCH_CHECK(h);
+    const unsigned tiles = (unsigned)((N + ADC_TILE_DOCS - 1) / ADC_TILE_DOCS);
+    if (N < ADC_SCREEN_MIN_N) {
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kfilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+        hipLaunchKernelGGL(kfilter, dim3(qg, tiles), dim3(ADC_THREADS), lds, s, codes, N, b.lut, nq, S, b.sample, b.thr,
+                           b.cnt, b.cand);
+        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+        RC_LAUNCH_CHECK(h);
+        return RC_OK;
+    }
+    constexpr int QS = (M <= 64) ? 8 : 4;
+    RC_HIP_CHECK(h, hipMemsetAsync(b.idcnt, 0, (size_t)nq * sizeof(unsigned), s));
+    hipLaunchKernelGGL(adc_qlut_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, QS, b.qlut, b.tint);
+    RC_LAUNCH_CHECK(h);
+    auto kscreen = adc_screen_kernel<M, QS>;
+    const size_t sl = (size_t)M * RC_K * QS;
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kscreen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
     rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-    hipLaunchKernelGGL(kfilter, dim3(qg, (unsigned)((N + ADC_TILE_DOCS - 1) / ADC_TILE_DOCS)), dim3(ADC_THREADS), lds, s,
-                       codes, N, lut, nq, S, sample, thr, cnt, cand);
+    hipLaunchKernelGGL(kscreen, dim3((unsigned)((nq + QS - 1) / QS), tiles), dim3(ADC_THREADS), sl, s, codes, N, b.qlut,
+                       b.tint, nq, b.idcnt, b.ids);
     rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+    RC_LAUNCH_CHECK(h);
+    auto krescore = adc_rescore_kernel<M>;
+    const size_t rl = (size_t)M * RC_K * sizeof(float);
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+    hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(256), rl, s, codes, b.lut, b.thr, b.idcnt, b.ids, b.cnt, b.cand,
+                       status);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
 
 #define ADC_CASE(MM, QQ) \
-    case MM: rc = adc_launch_scans<MM, QQ>(h, codes, N, lut, nq, L.S, sample, thr, cnt, cand, r, s); break;
+    case MM: rc = adc_launch_scans<MM, QQ>(h, codes, N, nq, L.S, bufs, r, status, s); break;
 
 extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K, float* lut,
                           rc_stream_t stream) {
@@ -327,10 +578,10 @@ extern "C" int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int
     if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
     char* w = (char*)ws;
     float* lut = (float*)(w + L.lut);
-    float* sample = (float*)(w + L.sample);
-    float* thr = (float*)(w + L.thr);
     unsigned* cnt = (unsigned*)(w + L.cnt);
     unsigned long long* cand = (unsigned long long*)(w + L.cand);
+    const adc_bufs bufs = {lut, (float*)(w + L.sample), (float*)(w + L.thr), cnt, cand, (uint8_t*)(w + L.qlut),
+                           (int*)(w + L.tint), (unsigned*)(w + L.idcnt), (unsigned*)(w + L.ids)};
     hipStream_t s = (hipStream_t)stream;
     int rc = rc_adc_lut(h, C, q, nq, D, M, K, lut, stream);
     if (rc != RC_OK) return rc;

@@ -531,3 +531,32 @@ def test_faiss_indexpq_file_round_trip(tmp_path):
     s1, i1 = idx.search(q, 20)
     s2, i2 = back.search(q, 20)
     assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
+
+
+@pytest.mark.parametrize("M,N,nq,k", [(48, 300000, 6, 1000), (96, 270000, 3, 10), (8, 400000, 9, 100),
+                                      (64, 262144, 4, 50), (24, 500000, 11, 200), (12, 262145, 2, 1)])
+def test_adc_integer_screening_path_is_exact(M, N, nq, k):
+    """N >= 2^18 takes the 8-bit screening + exact rescoring path; ids and score bits must still equal the
+    brute-force oracle (the integer threshold is a rigorous bound)."""
+    from repconc_amd import ops
+    C, codes, q = _adc_case(M, N, nq, seed=M * 7 + N)
+    codes[N // 2: N // 2 + 300] = codes[:300]          # duplicated rows: ties across the candidate boundary
+    scores, ids = ops.adc_search(_t(codes), _t(C), _t(q), k)
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    assert np.array_equal(ids.cpu().numpy(), wi)
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+def test_adc_screening_with_skewed_tables():
+    """Queries with one dominant sub-space and a constant (zero-range) sub-space: the common quantisation step is
+    set by the widest table, narrow tables collapse to a few levels, the bound must still hold."""
+    from repconc_amd import ops
+    M, N, nq, k = 48, 280000, 5, 100
+    C, codes, q = _adc_case(M, N, nq, seed=99)
+    q = q.copy()
+    q[:, :16] *= 40.0            # sub-space 0 dominates the score range
+    q[:, 16:32] = 0.0            # sub-space 1 contributes a constant 0
+    scores, ids = ops.adc_search(_t(codes), _t(C), _t(q), k)
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    assert np.array_equal(ids.cpu().numpy(), wi)
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), ws.view(np.uint32))
