@@ -234,168 +234,6 @@ __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
     }
 }
 
-// ---- LDS-DMA variant of sweep t >= 1 --------------------------------------------------------------------
-// Same arithmetic and the same reduction orders as sk_sweep_kernel<false> (bit-identical output); only the way
-// d reaches the lanes differs.  Each wave owns a ring of S stages of 4 KiB in LDS and keeps S-1 stages (its next
-// S-1 groups of 4 columns) in flight with global_load_lds_dwordx4 (no VGPR round trip, no registers tied up by
-// the prefetch), waits with a COUNTED vmcnt for the oldest stage only, and reads it back with four
-// conflict-free ds_read_b128.  A wave only ever reads what it loaded itself, so no barrier is involved.
-// Nothing else in the loop touches VMEM (column sums are parked in LDS and flushed after the loop), which keeps
-// the vmcnt arithmetic exact: 4 DMA instructions per stage, S-1 stages in flight.
-// One 16-byte-per-lane global -> LDS copy (1 KiB per wave instruction): lane L's bytes land at lds_dst + 16*L.
-// Written as asm so that hipcc does not count it: with the builtin the compiler drains vmcnt(0) in front of every
-// ds_read of the ring, which serialises the pipeline (guide 5.7: M0 is set and restored in the same statement).
-__device__ __forceinline__ void sk_glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
-template <int S>
-__global__ __launch_bounds__(SK_THREADS) void sk_sweep_dma_kernel(
-    const float* __restrict__ d, const double* __restrict__ rows_prev, int G, const double* __restrict__ f_in,
-    double* __restrict__ f_out, double* __restrict__ g, double* __restrict__ colsum, double* __restrict__ part,
-    unsigned* __restrict__ counters, double* __restrict__ rows_out, int64_t B, int cols_per_block,
-    double nscale_eps, double scale, const double* __restrict__ exp2_tab, int t, int* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) double sk_smem[];
-    double* tab = sk_smem;                              // [N]
-    double* fk_lds = tab + SK_N;                        // [256]
-    double* cs_lds = fk_lds + RC_K;                     // [SK_MAX_CPB] column sums of this block
-    int* gq_lds = reinterpret_cast<int*>(cs_lds + SK_MAX_CPB);   // [SK_MAX_CPB]
-    int* last_flag = gq_lds + SK_MAX_CPB;               // [4]
-    float* ring = reinterpret_cast<float*>(last_flag + 4);       // [4 waves][S][1024 floats]
-    double(*red)[RC_K] = reinterpret_cast<double(*)[RC_K]>(ring);  // aliases the ring after the loop
-
-    const int m = blockIdx.y, M = gridDim.y;
-    const int tid = threadIdx.x;
-    const int lane = tid & (SK_GROUP - 1);
-    const int grp = tid / SK_GROUP;
-    const int wv = tid >> 6, l64 = tid & 63;
-    const int64_t c0 = (int64_t)blockIdx.x * cols_per_block;
-    const int64_t c1 = (c0 + cols_per_block < B) ? c0 + cols_per_block : B;
-    const int ncols = (int)(c1 - c0);
-
-    for (int i = tid; i < SK_N; i += SK_THREADS) tab[i] = exp2_tab[i];
-    {
-        bool bad = false;
-        const double fn = sk_row_potential(rows_prev, G, M, m, tid, f_in, t, bad);
-        if (blockIdx.x == 0) f_out[(size_t)m * RC_K + tid] = fn;
-        fk_lds[tid] = fn * scale;
-        double* gm = g + (size_t)m * B + c0;
-        const double* cm = colsum + (size_t)m * B + c0;
-        for (int j = tid; j < ncols; j += SK_THREADS) {
-            double gn = 0.0;
-            if (t > 1) {
-                const double go = gm[j], c = cm[j];
-                const double gs = go * scale;
-                const double rg = gs - __builtin_rint(gs);
-                gn = go - (log(c) + rg / scale);
-                bad |= !(c > 0.0) || !(c < INFINITY);
-            }
-            gm[j] = gn;
-            gq_lds[j] = (int)__builtin_rint(gn * scale);
-        }
-        if (__any(bad) && (tid & 63) == 0) atomicOr(flags, RC_FLAG_NONFINITE);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA counting below starts from an empty queue
-    __syncthreads();
-
-    double fk[SK_EPL], R[SK_EPL];
-#pragma unroll
-    for (int i = 0; i < SK_EPL; ++i) {
-        fk[i] = fk_lds[sk_kidx(lane, i)];
-        R[i] = 0.0;
-    }
-    const float* dm = d + (size_t)m * B * RC_K + lane * 4;
-    float* ringw = ring + (size_t)wv * S * 1024;
-    // LDS byte address of this wave's ring (wave-uniform, made provably so for the "s" operand)
-    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(__attribute__((address_space(3))) float*)ringw);
-    const int nsteps = (ncols + SK_NG - 1) / SK_NG;
-
-    // stage `st` <- the 4 columns of step s of this wave (columns past the end re-read the last valid one)
-    auto issue = [&](int s) {
-        int64_t col = c0 + (int64_t)s * SK_NG + grp;
-        if (col >= c1) col = c1 - 1;
-        const float* src = dm + col * RC_K;
-        const unsigned dst = ring_lds + (unsigned)((s % S) * 4096);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sk_glds16(src + 64 * j, dst + 1024u * j);
-    };
-#pragma unroll
-    for (int s = 0; s < S - 1; ++s)
-        if (s < nsteps) issue(s);
-    for (int s = 0; s < nsteps; ++s) {
-        if (s + S - 1 < nsteps) {
-            issue(s + S - 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * (S - 1)) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        float x[SK_EPL];
-        const float4* sp = reinterpret_cast<const float4*>(ringw + (s % S) * 1024) + l64;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 a = sp[64 * j];
-            x[4 * j] = a.x; x[4 * j + 1] = a.y; x[4 * j + 2] = a.z; x[4 * j + 3] = a.w;
-        }
-        const int cj = s * SK_NG + grp;
-        const bool valid = cj < ncols;
-        double c;
-        double w[SK_EPL];
-        {
-            const int gq = gq_lds[valid ? cj : 0];
-            c = 0.0;
-#pragma unroll
-            for (int i = 0; i < SK_EPL; ++i) {
-                w[i] = sk_exp2n(__builtin_fma((double)x[i], nscale_eps, fk[i]), gq, tab);
-                c += w[i];
-            }
-            c = rc_row16_allreduce_sum(c);
-            const double rc = valid ? 1.0 / c : 0.0;
-#pragma unroll
-            for (int i = 0; i < SK_EPL; ++i) R[i] = __builtin_fma(w[i], rc, R[i]);
-            if (valid && lane == 0) cs_lds[cj] = c;
-        }
-    }
-    __syncthreads();   // every wave is done with its ring: the space becomes the reduction buffer
-    for (int j = tid; j < ncols; j += SK_THREADS) colsum[(size_t)m * B + c0 + j] = cs_lds[j];
-#pragma unroll
-    for (int i = 0; i < SK_EPL; ++i) red[grp][sk_kidx(lane, i)] = R[i];
-    __syncthreads();
-    double sres = red[0][tid];
-#pragma unroll
-    for (int q = 1; q < SK_NG; ++q) sres += red[q][tid];
-
-    const unsigned nblk = gridDim.x;
-    double* pm = part + (size_t)m * nblk * RC_K;
-    __hip_atomic_store(pm + (size_t)blockIdx.x * RC_K + tid, sres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(counters + m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *last_flag = ((old + 1u) % nblk == 0u);
-    }
-    __syncthreads();
-    if (*last_flag) {
-        double acc = 0.0;
-        unsigned i = 0;
-        for (; i + 8 <= nblk; i += 8) {
-            double v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v[j] = __hip_atomic_load(pm + (size_t)(i + j) * RC_K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc += v[j];
-        }
-        for (; i < nblk; ++i)
-            acc += __hip_atomic_load(pm + (size_t)i * RC_K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rows_out[(size_t)m * RC_K + tid] = acc;
-    }
-}
-
 // code[b][m] = argmax_k (L_kb + f_k), first maximum, with f brought up to date from the last sweep's row
 // sums in the prologue.  Same column ownership as the sweeps; the (value, index) pair is reduced across
 // the 16 lanes with rotations; ties keep the lower k.
@@ -509,25 +347,9 @@ extern "C" int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_pre
     } else {
         const double* f_in = f2 + (size_t)((t - 1) & 1) * M * RC_K;
         double* f_out = f2 + (size_t)(t & 1) * M * RC_K;
-        static int dma = -1;   // RC_SK_DMA=<stages> selects the LDS-DMA variant (A/B measurements)
-        if (dma < 0) { const char* e = getenv("RC_SK_DMA"); dma = e ? atoi(e) : 0; }
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
-        if (dma == 3 || dma == 4 || dma == 2) {
-            const size_t ldsd = ((size_t)SK_N + RC_K + SK_MAX_CPB) * sizeof(double) + (SK_MAX_CPB + 4) * sizeof(int) +
-                                (size_t)4 * dma * 4096;
-            if (dma == 2)
-                hipLaunchKernelGGL(sk_sweep_dma_kernel<2>, grid, dim3(SK_THREADS), ldsd, s, d, rows_prev, G, f_in, f_out, g,
-                                   colsum, part, counters, rows_out, B, cpb, nse, scale, tab, t, flags);
-            else if (dma == 3)
-                hipLaunchKernelGGL(sk_sweep_dma_kernel<3>, grid, dim3(SK_THREADS), ldsd, s, d, rows_prev, G, f_in, f_out, g,
-                                   colsum, part, counters, rows_out, B, cpb, nse, scale, tab, t, flags);
-            else
-                hipLaunchKernelGGL(sk_sweep_dma_kernel<4>, grid, dim3(SK_THREADS), ldsd, s, d, rows_prev, G, f_in, f_out, g,
-                                   colsum, part, counters, rows_out, B, cpb, nse, scale, tab, t, flags);
-        } else {
-            hipLaunchKernelGGL(sk_sweep_kernel<false>, grid, dim3(SK_THREADS), lds, s, d, rows_prev, G, f_in, f_out, g,
-                               colsum, part, counters, rows_out, B, cpb, nse, scale, tab, t, flags);
-        }
+        hipLaunchKernelGGL(sk_sweep_kernel<false>, grid, dim3(SK_THREADS), lds, s, d, rows_prev, G, f_in, f_out, g,
+                           colsum, part, counters, rows_out, B, cpb, nse, scale, tab, t, flags);
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
     }
     RC_LAUNCH_CHECK(h);
