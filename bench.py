@@ -129,7 +129,8 @@ def main():
         x = pool[i % n_pool]
         if not use_dist:
             return ops.assign_sinkhorn(x, C, EPS, ITERS, torch.uint8)
-        return assign_sinkhorn_sharded(x, C, EPS, ITERS, comm, dtype=torch.uint8)
+        return assign_sinkhorn_sharded(x, C, EPS, ITERS, comm, dtype=torch.uint8,
+                                       split=True if args.force_dist else None)
 
     for i in range(args.warmup):
         codes, flags = step(i)
@@ -170,7 +171,9 @@ def main():
         "config": {"workload": "SURVEY 8d-B / BASELINE configs[1] shape: constrained PQ assignment of "
                                "49152x768 batches (180 = 8.84M corpus), M=48 K=256 eps=0.003 T=100",
                    "global_batch": B, "rows_per_gpu": bl, "D": D, "M": M, "K": K, "sk_iters": ITERS,
-                   "parallelism": f"batch-sharded x{world}, all-gather of [M,K] f64 row sums per iteration"},
+                   "parallelism": f"batch-sharded x{world}, all-gather of [M,K] f64 row sums per iteration"
+                                  + (", two M-halves pipelined so the all-gather overlaps the other half's sweep"
+                                     if use_dist else "")},
         "sub_assignments_per_sec": round(value * M, 1),
         "max_code_imbalance": round(imb, 4),
         "roofline": roofline,

@@ -37,6 +37,7 @@ extern "C" {
 #define RC_ESHAPE (-2)     /* unsupported K / dsub / M                                 */
 #define RC_EHIP (-3)       /* a HIP runtime call failed (see rc_last_hip_error)        */
 #define RC_EWORKSPACE (-4) /* workspace smaller than the matching *_ws_bytes()         */
+#define RC_ECOMM (-5)      /* RCCL unavailable or a collective call failed             */
 
 #define RC_CODE_U8 0
 #define RC_CODE_I64 1
@@ -129,6 +130,26 @@ int rc_pq_assign_sinkhorn(rc_handle_t h, const float* x, int64_t ldx, const floa
                           int D, int M, int K, double eps, int iters, uint8_t* codes_u8,
                           int64_t* codes_i64, int* flags, void* ws, size_t ws_bytes,
                           rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-1 … a-4, one call, N ranks
+ * RepCONC.quantize with use_constraint=True in the dist.is_initialized() branch (modeling_repconc.py:47-67 with
+ * :78-80 and :149-157): every rank passes its equal row block of the batch and receives the codes of its rows; the
+ * uniform-assignment constraint is over the global batch.  Collectives run on RCCL inside the call (all-reduce
+ * MAX/MIN of the distance range, one all-gather of the [M,256] fp64 row sums per iteration), the sub-quantisers
+ * are solved as two independent chains on two streams so the all-gathers overlap sweeps (comm.hip).
+ *
+ * rc_comm_unique_ids: fill ids_host[2*128] on ONE rank (ncclGetUniqueId x2); the caller broadcasts the 256 bytes.
+ * rc_comm_init: every rank, same ids; creates two communicators on the handle's device.  RC_ECOMM if RCCL
+ * (librccl.so.1, resolved with dlopen at run time) is missing.
+ * ws: rc_pq_assign_sinkhorn_dist_ws_bytes(B_local, M, K, world) bytes. */
+int rc_comm_unique_ids(void* ids_host);
+int rc_comm_init(rc_handle_t h, const void* ids_host, int rank, int world);
+int rc_comm_destroy(rc_handle_t h);
+int rc_comm_world(rc_handle_t h);
+size_t rc_pq_assign_sinkhorn_dist_ws_bytes(int64_t B_local, int M, int K, int world);
+int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B_local,
+                               int D, int M, int K, double eps, int iters, uint8_t* codes_u8,
+                               int64_t* codes_i64, int* flags, void* ws, size_t ws_bytes, rc_stream_t stream);
 
 /* ------------------------------------------------------------------ a-6
  * decode (modeling_repconc.py:168-175): out[n, m*dsub:(m+1)*dsub] = C[m, codes[n,m], :], and

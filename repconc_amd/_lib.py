@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librepconc_hip.so")
 
-RC_OK, RC_EINVAL, RC_ESHAPE, RC_EHIP, RC_EWORKSPACE = 0, -1, -2, -3, -4
+RC_OK, RC_EINVAL, RC_ESHAPE, RC_EHIP, RC_EWORKSPACE, RC_ECOMM = 0, -1, -2, -3, -4, -5
 RC_CODE_U8, RC_CODE_I64 = 0, 1
 RC_FLAG_NONFINITE = 1
 PROF_SK_PASS, PROF_ADC_SCAN, PROF_ASSIGN_NEAREST, PROF_DIST_TABLE = 0, 1, 2, 3
@@ -38,6 +38,12 @@ PROTOTYPES = {
     "rc_sk_argmax": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "rc_pq_assign_sinkhorn_ws_bytes": (_sz, [_i64, _i, _i]),
     "rc_pq_assign_sinkhorn": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rc_comm_unique_ids": (_i, [_vp]),
+    "rc_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "rc_comm_destroy": (_i, [_vp]),
+    "rc_comm_world": (_i, [_vp]),
+    "rc_pq_assign_sinkhorn_dist_ws_bytes": (_sz, [_i64, _i, _i, _i]),
+    "rc_pq_assign_sinkhorn_dist": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_pq_decode": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "rc_pq_decode_bwd": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "rc_normalize_centroids": (_i, [_vp, _vp, _i, _i, _i, _vp]),

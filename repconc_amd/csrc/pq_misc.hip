@@ -16,6 +16,7 @@ extern "C" const char* rc_error_string(int code) {
         case RC_ESHAPE: return "unsupported shape (K must be 256, D/M one of 8,12,16,24,32,48,64,96)";
         case RC_EHIP: return "HIP runtime error";
         case RC_EWORKSPACE: return "workspace too small";
+        case RC_ECOMM: return "RCCL unavailable or collective failed";
         default: return "unknown error";
     }
 }
@@ -33,12 +34,20 @@ extern "C" int rc_create(rc_handle_t* out, int device) {
     h->last_hip_error = 0;
     h->profile_on = 0;
     h->exp2_tab[0] = h->exp2_tab[1] = nullptr;
+    h->comm[0] = h->comm[1] = nullptr;
+    h->comm_rank = 0;
+    h->comm_world = 0;
+    h->side_stream = nullptr;
+    h->ev_fork = h->ev_join = nullptr;
     *out = h;
     return RC_OK;
 }
 
+extern "C" int rc_comm_destroy(rc_handle_t h);
+
 extern "C" int rc_destroy(rc_handle_t h) {
     if (h) {
+        (void)rc_comm_destroy(h);
         for (auto& v : h->prof_ev)
             for (hipEvent_t e : v) (void)hipEventDestroy(e);
         for (double* t : h->exp2_tab)

@@ -18,7 +18,17 @@ struct rc_handle_s {
     int profile_on;
     std::vector<hipEvent_t> prof_ev[RC_PROF_NSLOT];  // start, stop, start, stop, ...
     double* exp2_tab[2];                             // device tables 2^(j/N): [0] N=256, [1] N=2048
+    // RCCL state of rc_comm_init (comm.hip): two communicators so two independent chains of collectives can be
+    // in flight on two streams
+    void* comm[2];
+    int comm_rank, comm_world;
+    hipStream_t side_stream;
+    hipEvent_t ev_fork, ev_join;
 };
+
+int rc_sk_argmax_strided(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2, int64_t B,
+                         int M, double eps, int t, int code_stride, int m_offset, uint8_t* codes_u8,
+                         int64_t* codes_i64, int* flags, hipStream_t s);
 
 // device pointer to the table 2^(j/2^tb), j < 2^tb (tb = 8 or 11), created on first use
 const double* rc_exp2_table(rc_handle_t h, int tb);

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_argmax_kernel(const float* __re
                                                                const double* __restrict__ rows_prev, int G,
                                                                const double* __restrict__ f_in, int t, int64_t B,
                                                                int cols_per_block, double ninv_eps,
+                                                               int code_stride, int m_offset,
                                                                uint8_t* __restrict__ codes_u8,
                                                                int64_t* __restrict__ codes_i64,
                                                                int* __restrict__ flags) {
@@ -280,8 +281,9 @@ __global__ __launch_bounds__(SK_THREADS) void sk_argmax_kernel(const float* __re
         SK_ARGMAX_STEP(8) SK_ARGMAX_STEP(4) SK_ARGMAX_STEP(2) SK_ARGMAX_STEP(1)
 #undef SK_ARGMAX_STEP
         if (lane == 0) {
-            if (codes_u8) codes_u8[col * M + m] = (uint8_t)bi;
-            if (codes_i64) codes_i64[col * M + m] = (int64_t)bi;
+            // codes [B, code_stride]; this launch owns the sub-quantisers m_offset .. m_offset + M - 1
+            if (codes_u8) codes_u8[col * code_stride + m_offset + m] = (uint8_t)bi;
+            if (codes_i64) codes_i64[col * code_stride + m_offset + m] = (int64_t)bi;
         }
     }
 }
@@ -356,6 +358,19 @@ extern "C" int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_pre
     return RC_OK;
 }
 
+// argmax over the sub-quantisers of `d` (M of them), written into codes [B, code_stride] at column m_offset
+int rc_sk_argmax_strided(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2, int64_t B,
+                         int M, double eps, int t, int code_stride, int m_offset, uint8_t* codes_u8,
+                         int64_t* codes_i64, int* flags, hipStream_t s) {
+    const int cpb = sk_cols_per_block(B, M);
+    const int64_t nblk = (B + cpb - 1) / cpb;
+    const double* f_in = f2 + (size_t)((t - 1) & 1) * M * RC_K;
+    hipLaunchKernelGGL(sk_argmax_kernel, dim3((unsigned)nblk, (unsigned)M), dim3(SK_THREADS), 0, s, d, rows_prev, G,
+                       f_in, t, B, cpb, -1.0 / eps, code_stride, m_offset, codes_u8, codes_i64, flags);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
 extern "C" int rc_sk_argmax(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2,
                             int64_t B, int M, int K, double eps, int t, uint8_t* codes_u8, int64_t* codes_i64,
                             int* flags, rc_stream_t stream) {
@@ -363,13 +378,8 @@ extern "C" int rc_sk_argmax(rc_handle_t h, const float* d, const double* rows_pr
         (!codes_u8 && !codes_i64))
         return RC_EINVAL;
     if (K != RC_K) return RC_ESHAPE;
-    const int cpb = sk_cols_per_block(B, M);
-    const int64_t nblk = (B + cpb - 1) / cpb;
-    const double* f_in = f2 + (size_t)((t - 1) & 1) * M * RC_K;
-    hipLaunchKernelGGL(sk_argmax_kernel, dim3((unsigned)nblk, (unsigned)M), dim3(SK_THREADS), 0, (hipStream_t)stream,
-                       d, rows_prev, G, f_in, t, B, cpb, -1.0 / eps, codes_u8, codes_i64, flags);
-    RC_LAUNCH_CHECK(h);
-    return RC_OK;
+    return rc_sk_argmax_strided(h, d, rows_prev, G, f2, B, M, eps, t, M, 0, codes_u8, codes_i64, flags,
+                                (hipStream_t)stream);
 }
 
 // ---- one-call single-rank constrained assignment -----------------------------------------

@@ -202,6 +202,57 @@ def assign_sinkhorn(x: torch.Tensor, centroids: torch.Tensor, eps: float, iters:
     return codes, flags
 
 
+# --------------------------------------------------------------------------- N ranks, native loop
+_comm_ready = {}
+
+
+def comm_init(group=None):
+    """Create the RCCL communicators of this process's handle (once).  The 256-byte unique ids are produced on rank 0
+    and broadcast through torch.distributed (any backend); everything after that is RCCL called from C."""
+    import torch.distributed as dist
+    dev = torch.cuda.current_device()
+    if _comm_ready.get(dev):
+        return
+    lib, h = _lib.load(), _lib.handle(dev)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ids = torch.zeros(256, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_char * 256)()
+        _lib.check(lib.rc_comm_unique_ids(C.cast(buf, C.c_void_p)), "rc_comm_unique_ids")
+        ids = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    if world > 1:
+        backend = dist.get_backend(group)
+        t = ids.to(torch.device("cuda", dev)) if backend == "nccl" else ids
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ids = t.cpu()
+    raw = (C.c_char * 256).from_buffer_copy(bytes(ids.numpy().tobytes()))
+    _lib.check(lib.rc_comm_init(h, C.cast(raw, C.c_void_p), rank, world), "rc_comm_init", h)
+    _comm_ready[dev] = True
+
+
+def assign_sinkhorn_dist(x: torch.Tensor, centroids: torch.Tensor, eps: float, iters: int, dtype=torch.int64):
+    """This rank's codes of the batch-sharded constrained assignment, the whole solve in one C call
+    (rc_pq_assign_sinkhorn_dist; comm_init() first).  modeling_repconc.py:47-67 with dist.is_initialized()."""
+    _need_cuda(x, centroids)
+    x, c = _rows_f32(x), _centroids(centroids)
+    B, D, M, _ = _shape(x, c)
+    lib, h, s, _ = _ctx(x)
+    world = lib.rc_comm_world(h)
+    if world < 1:
+        raise _lib.RepconcHipError("assign_sinkhorn_dist: call ops.comm_init() first")
+    codes = torch.empty((B, M), dtype=dtype, device=x.device)
+    flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
+    if B == 0:
+        return codes, flags
+    wsb = lib.rc_pq_assign_sinkhorn_dist_ws_bytes(B, M, K, world)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    u8 = codes if dtype == torch.uint8 else None
+    i64 = codes if dtype == torch.int64 else None
+    _lib.check(lib.rc_pq_assign_sinkhorn_dist(h, _p(x), x.stride(0), _p(c), B, D, M, K, float(eps), int(iters),
+                                              _p(u8), _p(i64), _p(flags), _p(ws), wsb, s), "rc_pq_assign_sinkhorn_dist", h)
+    return codes, flags
+
+
 # --------------------------------------------------------------------------- decode
 def decode_raw(codes: torch.Tensor, centroids: torch.Tensor) -> torch.Tensor:
     _need_cuda(codes, centroids)

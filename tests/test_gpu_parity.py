@@ -69,10 +69,11 @@ def test_virtual_shards_equal_unsharded(name, shards):
     B = x.shape[0]
     bl = B // shards
     xs = [_t(x[r * bl:(r + 1) * bl]) for r in range(shards)]
-    codes, flags = assign_sinkhorn_virtual(xs, _t(C), EPS, ITERS)
-    got = torch.cat(codes, 0).cpu().numpy().astype(np.uint8)
-    assert all(int(f.item()) == 0 for f in flags)
-    assert np.array_equal(got, g["codes_constrained"])
+    for split in (False, True):      # split: the two halves of M solved separately, as the multi-rank driver does
+        codes, flags = assign_sinkhorn_virtual(xs, _t(C), EPS, ITERS, split=split)
+        got = torch.cat(codes, 0).cpu().numpy().astype(np.uint8)
+        assert all(int(f.item()) == 0 for f in flags)
+        assert np.array_equal(got, g["codes_constrained"])
 
 
 def test_strided_and_half_inputs():
@@ -560,3 +561,34 @@ def test_adc_screening_with_skewed_tables():
     ws, wi = c_oracle.adc_search(codes, C, q, k)
     assert np.array_equal(ids.cpu().numpy(), wi)
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+def test_native_rccl_solve_single_rank(monkeypatch):
+    """csrc/comm.hip: the distributed solve driven from C over RCCL, on a one-rank communicator (all this box can
+    host): one chain and the two-chain/two-stream split must both reproduce the reference codes."""
+    import socket
+    import torch.distributed as dist
+    from repconc_amd import ops
+    from repconc_amd.sharded import TorchDistComm, assign_sinkhorn_sharded
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device(DEV))
+        created = True
+    try:
+        for name in ("m48_b1024_sample", "m8_b2048_sample", "m48_b1000_ragged"):
+            g, x, C = load_case(name)
+            for split in ("0", "1"):
+                monkeypatch.setenv("RC_DIST_SPLIT", split)
+                codes, flags = assign_sinkhorn_sharded(_t(x), _t(C), EPS, ITERS, TorchDistComm(), dtype=torch.uint8)
+                torch.cuda.synchronize()
+                assert int(flags.item()) == 0
+                assert np.array_equal(codes.cpu().numpy(), g["codes_constrained"]), (name, split)
+            c64, _ = ops.assign_sinkhorn_dist(_t(x), _t(C), EPS, ITERS, torch.int64)
+            assert np.array_equal(c64.cpu().numpy().astype(np.uint8), g["codes_constrained"])
+    finally:
+        if created:
+            dist.destroy_process_group()

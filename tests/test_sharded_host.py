@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, split):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,17 +34,18 @@ def _worker(rank, world, port, ret):
     _, x, C = load_case(CASE)
     bl = x.shape[0] // world
     codes, flags = assign_sinkhorn_sharded(torch.from_numpy(x[rank * bl:(rank + 1) * bl]), torch.from_numpy(C),
-                                           EPS, ITERS, TorchDistComm(), stages=NumpyStages())
+                                           EPS, ITERS, TorchDistComm(), stages=NumpyStages(), split=split)
     ret[rank] = codes.numpy().astype(np.uint8)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_gloo_sharded_equals_reference_codes(world):
+@pytest.mark.parametrize("world,split", [(2, False), (2, True)])
+def test_gloo_sharded_equals_reference_codes(world, split):
+    """split=True is the multi-GPU default: two halves of M in lock-step with ASYNC all-gathers (gloo here)."""
     g, x, C = load_case(CASE)
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), ret, split), nprocs=world, join=True)
         got = np.concatenate([ret[r] for r in range(world)], 0)
     assert np.array_equal(got, g["codes_constrained"][: got.shape[0]] if got.shape[0] != x.shape[0]
                           else g["codes_constrained"])
@@ -57,9 +58,10 @@ def test_virtual_shards_equal_reference_codes(shards):
     g, x, C = load_case(CASE)
     bl = x.shape[0] // shards
     xs = [torch.from_numpy(x[r * bl:(r + 1) * bl]) for r in range(shards)]
-    codes, flags = assign_sinkhorn_virtual(xs, torch.from_numpy(C), EPS, ITERS, stages=NumpyStages())
-    got = torch.cat(codes, 0).numpy().astype(np.uint8)
-    assert np.array_equal(got, g["codes_constrained"])
+    for split in (False, True):
+        codes, flags = assign_sinkhorn_virtual(xs, torch.from_numpy(C), EPS, ITERS, stages=NumpyStages(), split=split)
+        got = torch.cat(codes, 0).numpy().astype(np.uint8)
+        assert np.array_equal(got, g["codes_constrained"])
 
 
 def test_single_row_global_batch_is_all_zero_codes():
