@@ -129,8 +129,7 @@ def main():
         x = pool[i % n_pool]
         if not use_dist:
             return ops.assign_sinkhorn(x, C, EPS, ITERS, torch.uint8)
-        return assign_sinkhorn_sharded(x, C, EPS, ITERS, comm, dtype=torch.uint8,
-                                       split=True if args.force_dist else None)
+        return assign_sinkhorn_sharded(x, C, EPS, ITERS, comm, dtype=torch.uint8)
 
     for i in range(args.warmup):
         codes, flags = step(i)
@@ -149,12 +148,15 @@ def main():
     assert int(flags.item()) == 0, "Sinkhorn produced non-finite sums"
     value = args.steps * B / dt
     sweep_ms = ms_l.value / max(n_l.value, 1)
-    alg_bytes = bl * M * K * 4
+    # with N > 1 ranks the sub-quantisers run as two chains: one launch covers M/2 of them
+    n_chains = lib.rc_solve_num_chains(world, M) if os.environ.get("RC_DIST_NATIVE", "1") != "0" or not use_dist else 1
+    alg_bytes = bl * (M // n_chains) * K * 4
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if n_l.value else 0.0
     roofline = {"kernel": "sk_pass_kernel<false> (Sinkhorn sweep)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic("sk_sweep_kernel"), "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_ms": round(sweep_ms, 4), "launches_timed": n_l.value}
+                "avg_launch_ms": round(sweep_ms, 4), "launches_timed": n_l.value,
+                "sub_quantisers_per_launch": M // n_chains}
 
     # balance sanity of the last batch (every centroid gets ~B/K of the global batch)
     hist = ops.code_hist(codes)
@@ -172,8 +174,8 @@ def main():
                                "49152x768 batches (180 = 8.84M corpus), M=48 K=256 eps=0.003 T=100",
                    "global_batch": B, "rows_per_gpu": bl, "D": D, "M": M, "K": K, "sk_iters": ITERS,
                    "parallelism": f"batch-sharded x{world}, all-gather of [M,K] f64 row sums per iteration"
-                                  + (", two M-halves pipelined so the all-gather overlaps the other half's sweep"
-                                     if use_dist else "")},
+                                  + (", RCCL driven from C, two chains of M/2 sub-quantisers on two streams "
+                                     "(all-gathers overlap sweeps)" if use_dist else "")},
         "sub_assignments_per_sec": round(value * M, 1),
         "max_code_imbalance": round(imb, 4),
         "roofline": roofline,

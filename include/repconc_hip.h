@@ -146,6 +146,7 @@ int rc_comm_unique_ids(void* ids_host);
 int rc_comm_init(rc_handle_t h, const void* ids_host, int rank, int world);
 int rc_comm_destroy(rc_handle_t h);
 int rc_comm_world(rc_handle_t h);
+int rc_solve_num_chains(int world, int M); /* 1 or 2: launches per sweep (measurement bookkeeping) */
 size_t rc_pq_assign_sinkhorn_dist_ws_bytes(int64_t B_local, int M, int K, int world);
 int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B_local,
                                int D, int M, int K, double eps, int iters, uint8_t* codes_u8,

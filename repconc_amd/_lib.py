@@ -42,6 +42,7 @@ PROTOTYPES = {
     "rc_comm_init": (_i, [_vp, _vp, _i, _i]),
     "rc_comm_destroy": (_i, [_vp]),
     "rc_comm_world": (_i, [_vp]),
+    "rc_solve_num_chains": (_i, [_i, _i]),
     "rc_pq_assign_sinkhorn_dist_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rc_pq_assign_sinkhorn_dist": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_pq_decode": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),

@@ -88,9 +88,6 @@ extern "C" int rc_comm_init(rc_handle_t h, const void* ids_host, int rank, int w
         RC_NCCL_CHECK(h, n->CommInitRank(&c, world, id, rank));
         h->comm[i] = (void*)c;
     }
-    RC_HIP_CHECK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-    RC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    RC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     h->comm_rank = rank;
     h->comm_world = world;
     return RC_OK;
@@ -109,6 +106,14 @@ extern "C" int rc_comm_destroy(rc_handle_t h) {
 }
 
 extern "C" int rc_comm_world(rc_handle_t h) { return h ? h->comm_world : 0; }
+
+static int ensure_side_stream(rc_handle_t h) {
+    if (h->side_stream) return RC_OK;
+    RC_HIP_CHECK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    RC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    RC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    return RC_OK;
+}
 
 // ---- workspace of the distributed solve -------------------------------------------------------------------------
 namespace {
@@ -147,28 +152,24 @@ dist_ws dist_layout(int64_t B, int M, int world, bool split) {
     return L;
 }
 bool want_split(int world) {
+    // Default: two chains as soon as there is a collective to hide.  On one GPU the split only buys ~3 % (the tail
+    // of one sweep overlaps the head of the other: 53.1 -> 51.6 ms per 49152-row step) and makes per-launch timings
+    // overlap, so it stays off unless RC_DIST_SPLIT=1.
     const char* e = getenv("RC_DIST_SPLIT");
     if (e) return atoi(e) != 0;
     return world > 1;
 }
 }  // namespace
 
-extern "C" size_t rc_pq_assign_sinkhorn_dist_ws_bytes(int64_t B_local, int M, int K, int world) {
-    if (B_local <= 0 || M <= 0 || K != RC_K || world < 1) return 0;
-    return dist_layout(B_local, M, world, true).total;   // the split layout is the larger one
-}
+size_t rc_solve_ws_bytes(int64_t B, int M, int world) { return dist_layout(B, M, world, true).total; }
 
-extern "C" int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
-                                          int M, int K, double eps, int iters, uint8_t* codes_u8, int64_t* codes_i64,
-                                          int* flags, void* ws, size_t ws_bytes, rc_stream_t stream) {
-    nccl_api* n = nccl();
-    if (!n) return RC_ECOMM;
-    if (!h || !h->comm[0] || !x || !C || !flags || B <= 0 || M <= 0 || iters < 1 || !(eps > 0.0) ||
-        (!codes_u8 && !codes_i64))
-        return RC_EINVAL;
-    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
-    const int G = h->comm_world;
-    hipStream_t s0 = (hipStream_t)stream;
+// The whole constrained assignment of this rank's rows on `world` ranks (world == 1: no RCCL involved).
+int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D, int M, double eps,
+                    int iters, int world, uint8_t* codes_u8, int64_t* codes_i64, int* flags, void* ws, size_t ws_bytes,
+                    hipStream_t s0) {
+    const int G = world;
+    nccl_api* n = (G > 1) ? nccl() : nullptr;
+    if (G > 1 && (!n || !h->comm[0])) return RC_ECOMM;
     if ((int64_t)G * B == 1) {   // a global batch of one row: exact K-way tie, the reference returns code 0
         if (codes_u8) RC_HIP_CHECK(h, hipMemsetAsync(codes_u8, 0, (size_t)M, s0));
         if (codes_i64) RC_HIP_CHECK(h, hipMemsetAsync(codes_i64, 0, (size_t)M * sizeof(int64_t), s0));
@@ -180,16 +181,17 @@ extern "C" int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t
     float* d = (float*)(w + L.d);
     float* minmax = (float*)(w + L.minmax);
     int rc;
-    if ((rc = rc_pq_dist_table(h, x, ldx, C, B, D, M, K, d, minmax, w + L.dist_ws, rc_pq_dist_table_ws_bytes(B, M),
-                               stream)) != RC_OK) return rc;
+    if ((rc = rc_pq_dist_table(h, x, ldx, C, B, D, M, RC_K, d, minmax, w + L.dist_ws, rc_pq_dist_table_ws_bytes(B, M),
+                               (rc_stream_t)s0)) != RC_OK) return rc;
     if (G > 1) {   // modeling_repconc.py:79-80
         RC_NCCL_CHECK(h, n->AllReduce(minmax, minmax, (size_t)M, ncclFloat, ncclMax, (ncclComm_t)h->comm[0], s0));
         RC_NCCL_CHECK(h, n->AllReduce(minmax + M, minmax + M, (size_t)M, ncclFloat, ncclMin, (ncclComm_t)h->comm[0], s0));
     }
-    if ((rc = rc_pq_centre(h, d, minmax, B, M, K, stream)) != RC_OK) return rc;
+    if ((rc = rc_pq_centre(h, d, minmax, B, M, RC_K, (rc_stream_t)s0)) != RC_OK) return rc;
 
     hipStream_t st[2] = {s0, s0};
     if (L.nch == 2) {
+        if ((rc = ensure_side_stream(h)) != RC_OK) return rc;
         st[1] = h->side_stream;
         RC_HIP_CHECK(h, hipEventRecord(h->ev_fork, s0));
         RC_HIP_CHECK(h, hipStreamWaitEvent(st[1], h->ev_fork, 0));
@@ -200,15 +202,17 @@ extern "C" int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t
             const chain_ws& cw = L.ch[c];
             const int mc = L.mc[c];
             const float* dc = d + (size_t)L.m0[c] * B * RC_K;
-            double* rows = (double*)(w + cw.rows);
             double* gath = (double*)(w + cw.gathered);
             const size_t gsz = (size_t)G * mc * RC_K;
             const double* prev = gath + (size_t)((t + 1) & 1) * gsz;   // gathered row sums of sweep t-1
-            if ((rc = rc_sk_sweep(h, dc, prev, G, (double*)(w + cw.f2), (double*)(w + cw.g), (double*)(w + cw.colsum),
-                                  rows, B, mc, K, eps, t, flags, w + cw.sweep, rc_sk_ws_bytes(B, mc, K),
-                                  (rc_stream_t)st[c])) != RC_OK) return rc;
             double* out = gath + (size_t)(t & 1) * gsz;
-            RC_NCCL_CHECK(h, n->AllGather(rows, out, (size_t)mc * RC_K, ncclDouble, (ncclComm_t)h->comm[c], st[c]));
+            // one rank: the sweep writes its row sums straight into the "gathered" slot
+            double* rows = (G > 1) ? (double*)(w + cw.rows) : out;
+            if ((rc = rc_sk_sweep(h, dc, prev, G, (double*)(w + cw.f2), (double*)(w + cw.g), (double*)(w + cw.colsum),
+                                  rows, B, mc, RC_K, eps, t, flags, w + cw.sweep, rc_sk_ws_bytes(B, mc, RC_K),
+                                  (rc_stream_t)st[c])) != RC_OK) return rc;
+            if (G > 1)
+                RC_NCCL_CHECK(h, n->AllGather(rows, out, (size_t)mc * RC_K, ncclDouble, (ncclComm_t)h->comm[c], st[c]));
         }
     }
     for (int c = 0; c < L.nch; ++c) {
@@ -223,4 +227,23 @@ extern "C" int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t
         RC_HIP_CHECK(h, hipStreamWaitEvent(s0, h->ev_join, 0));
     }
     return RC_OK;
+}
+
+// number of independent chains (launches per sweep) the solve uses for `world` ranks and M sub-quantisers
+extern "C" int rc_solve_num_chains(int world, int M) { return (want_split(world) && M >= 2) ? 2 : 1; }
+
+extern "C" size_t rc_pq_assign_sinkhorn_dist_ws_bytes(int64_t B_local, int M, int K, int world) {
+    if (B_local <= 0 || M <= 0 || K != RC_K || world < 1) return 0;
+    return rc_solve_ws_bytes(B_local, M, world);
+}
+
+extern "C" int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
+                                          int M, int K, double eps, int iters, uint8_t* codes_u8, int64_t* codes_i64,
+                                          int* flags, void* ws, size_t ws_bytes, rc_stream_t stream) {
+    if (!h || !h->comm[0] || !x || !C || !flags || B <= 0 || M <= 0 || iters < 1 || !(eps > 0.0) ||
+        (!codes_u8 && !codes_i64))
+        return RC_EINVAL;
+    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
+    return rc_solve_chains(h, x, ldx, C, B, D, M, eps, iters, h->comm_world, codes_u8, codes_i64, flags, ws, ws_bytes,
+                           (hipStream_t)stream);
 }

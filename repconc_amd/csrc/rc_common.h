@@ -26,6 +26,11 @@ struct rc_handle_s {
     hipEvent_t ev_fork, ev_join;
 };
 
+// comm.hip: the full constrained assignment as one or two chains of sub-quantisers (world == 1: no RCCL)
+size_t rc_solve_ws_bytes(int64_t B, int M, int world);
+int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D, int M, double eps,
+                    int iters, int world, uint8_t* codes_u8, int64_t* codes_i64, int* flags, void* ws, size_t ws_bytes,
+                    hipStream_t s0);
 int rc_sk_argmax_strided(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2, int64_t B,
                          int M, double eps, int t, int code_stride, int m_offset, uint8_t* codes_u8,
                          int64_t* codes_i64, int* flags, hipStream_t s);

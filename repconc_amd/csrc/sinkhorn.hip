@@ -383,27 +383,9 @@ extern "C" int rc_sk_argmax(rc_handle_t h, const float* d, const double* rows_pr
 }
 
 // ---- one-call single-rank constrained assignment -----------------------------------------
-struct sk_ws_layout {
-    size_t d, minmax, f2, g, colsum, rows2, sweep_ws, dist_ws, total;
-};
-static sk_ws_layout sk_layout(int64_t B, int M) {
-    sk_ws_layout L;
-    size_t o = 0;
-    L.d = o;        o += rc_align_up((size_t)M * B * RC_K * sizeof(float), 256);
-    L.minmax = o;   o += rc_align_up((size_t)2 * M * sizeof(float), 256);
-    L.f2 = o;       o += rc_align_up((size_t)2 * M * RC_K * sizeof(double), 256);
-    L.g = o;        o += rc_align_up((size_t)M * B * sizeof(double), 256);
-    L.colsum = o;   o += rc_align_up((size_t)M * B * sizeof(double), 256);
-    L.rows2 = o;    o += rc_align_up((size_t)2 * M * RC_K * sizeof(double), 256);
-    L.sweep_ws = o; o += rc_sk_ws_bytes(B, M, RC_K);
-    L.dist_ws = o;  o += rc_pq_dist_table_ws_bytes(B, M);
-    L.total = o;
-    return L;
-}
-
 extern "C" size_t rc_pq_assign_sinkhorn_ws_bytes(int64_t B, int M, int K) {
     if (B <= 0 || M <= 0 || K != RC_K) return 0;
-    return sk_layout(B, M).total;
+    return rc_solve_ws_bytes(B, M, 1);
 }
 
 extern "C" int rc_pq_assign_sinkhorn(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
@@ -413,34 +395,6 @@ extern "C" int rc_pq_assign_sinkhorn(rc_handle_t h, const float* x, int64_t ldx,
         return RC_EINVAL;
     if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
     if (B == 0) return RC_OK;
-    if (B == 1) {
-        // One column: the first row normalisation (:158) makes every entry Q_k/Q_k = 1 exactly, so the
-        // reference's argmax is a K-way exact tie and returns index 0 for every sub-quantiser.
-        hipStream_t s1 = (hipStream_t)stream;
-        if (codes_u8) RC_HIP_CHECK(h, hipMemsetAsync(codes_u8, 0, (size_t)M, s1));
-        if (codes_i64) RC_HIP_CHECK(h, hipMemsetAsync(codes_i64, 0, (size_t)M * sizeof(int64_t), s1));
-        return RC_OK;
-    }
-    const sk_ws_layout L = sk_layout(B, M);
-    if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
-    char* w = (char*)ws;
-    float* d = (float*)(w + L.d);
-    float* minmax = (float*)(w + L.minmax);
-    double* f2 = (double*)(w + L.f2);
-    double* g = (double*)(w + L.g);
-    double* colsum = (double*)(w + L.colsum);
-    double* rows2 = (double*)(w + L.rows2);
-    void* sws = w + L.sweep_ws;
-    const size_t sws_bytes = rc_sk_ws_bytes(B, M, K);
-    int rc;
-    if ((rc = rc_pq_dist_table(h, x, ldx, C, B, D, M, K, d, minmax, w + L.dist_ws,
-                               rc_pq_dist_table_ws_bytes(B, M), stream)) != RC_OK) return rc;
-    if ((rc = rc_pq_centre(h, d, minmax, B, M, K, stream)) != RC_OK) return rc;
-    const size_t mk = (size_t)M * RC_K;
-    for (int t = 0; t < iters; ++t) {   // rows ping-pong: sweep t reads rows[(t-1)&1], writes rows[t&1]
-        if ((rc = rc_sk_sweep(h, d, rows2 + (size_t)((t + 1) & 1) * mk, 1, f2, g, colsum, rows2 + (size_t)(t & 1) * mk,
-                              B, M, K, eps, t, flags, sws, sws_bytes, stream)) != RC_OK) return rc;
-    }
-    return rc_sk_argmax(h, d, rows2 + (size_t)((iters - 1) & 1) * mk, 1, f2, B, M, K, eps, iters, codes_u8, codes_i64,
-                        flags, stream);
+    return rc_solve_chains(h, x, ldx, C, B, D, M, eps, iters, 1, codes_u8, codes_i64, flags, ws, ws_bytes,
+                           (hipStream_t)stream);
 }
