@@ -204,6 +204,21 @@ int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, 
 int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K,
                float* lut, rc_stream_t stream);
 
+/* ------------------------------------------------------------------ IVF extension (SURVEY §8d input D)
+ * The reference only ever builds a 1-list IVFPQ (evaluate_repconc.py:101-118); BASELINE.json's nlist=5000 config is a
+ * build-side extension.  Code rows are stored list-major (`codes` [N,M] sorted by coarse cell, `list_off` [nlist+1]
+ * row offsets, `ids` [N] corpus position of every row), NOT residual-encoded.  For query qi the rows of lists
+ * probes[qi, 0..nprobe) are scored exactly (same fp32 m-ascending sum as rc_adc_search) and the top-k returned with
+ * the same order (score desc, id asc); probing every list gives exactly the flat result.
+ * lut: [nq,M,256] from rc_adc_lut; base[qi,p] = rows scanned before probe p; count[qi] = rows scanned in total;
+ * stride >= max count.  ids -1 / score -inf pad queries whose probed lists hold fewer than k rows.
+ * ws: rc_ivf_search_ws_bytes(nq, stride).  status bit1: more than 16384 rows tie at the k-th score. */
+size_t rc_ivf_search_ws_bytes(int nq, int64_t stride);
+int rc_ivf_search(rc_handle_t h, const uint8_t* codes, const int64_t* list_off, const int64_t* ids, int64_t N,
+                  int M, int K, const float* lut, const int* probes, const int* base, const int* count, int nq,
+                  int nprobe, int64_t stride, int k, float* scores, int64_t* out_ids, int* status, void* ws,
+                  size_t ws_bytes, rc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

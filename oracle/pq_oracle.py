@@ -320,3 +320,25 @@ def mrr_at_k(ranked_ids: np.ndarray, positives, k: int = 10) -> float:
                 break
         rr.append(r)
     return round(float(np.mean(rr)), 5)
+
+
+# --------------------------------------------------------------------------- IVF extension
+def ivf_search(q, centroids, codes, list_ids, coarse, k, nprobe):
+    """Brute-force restatement of repconc_amd.ivf.IVFPQIndex.search (a build-side extension with no reference
+    counterpart): probe the nprobe cells with the largest <q, coarse centroid> (ties: lower cell),
+    score the rows of those cells with the flat ADC arithmetic, top-k by (score desc, id asc); -1 / -inf padding."""
+    nq = q.shape[0]
+    cs = q.astype(F32) @ coarse.astype(F32).T
+    order = np.lexsort((np.broadcast_to(np.arange(cs.shape[1]), cs.shape), -cs.astype(F64)), axis=1)[:, :nprobe]
+    lut = adc_lut(q, centroids)
+    out_s = np.full((nq, k), -np.inf, F32)
+    out_i = np.full((nq, k), -1, np.int64)
+    for qi in range(nq):
+        rows = np.nonzero(np.isin(list_ids, order[qi]))[0]
+        if len(rows) == 0:
+            continue
+        s = adc_scores(lut[qi:qi + 1], codes[rows])[0]
+        o = np.lexsort((rows, -s.astype(F64)))[:k]
+        out_s[qi, :len(o)] = s[o]
+        out_i[qi, :len(o)] = rows[o]
+    return out_s, out_i

@@ -567,6 +567,18 @@ extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq,
     return RC_OK;
 }
 
+// sort + emit stage, shared with the IVF path (ivf_search.hip)
+int rc_adc_launch_select(rc_handle_t h, const unsigned long long* cand, const unsigned* cnt, int nq, int64_t N, int k,
+                         int64_t id_offset, float* scores, int64_t* ids, int* status, hipStream_t s) {
+    const size_t sl = (size_t)ADC_CAND_CAP * sizeof(unsigned long long);
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)adc_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)sl));
+    hipLaunchKernelGGL(adc_select_kernel, dim3((unsigned)nq), dim3(1024), sl, s, cand, cnt, N, k, id_offset, scores, ids,
+                       status);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
 extern "C" int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, const float* C, int D,
                              const float* q, int nq, int k, int64_t id_offset, double sel_slack, float* scores,
                              int64_t* ids, int* status, void* ws, size_t ws_bytes, rc_stream_t stream) {
@@ -604,12 +616,5 @@ extern "C" int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int
     }
     if (rc != RC_OK) return rc;
     (void)adc_qt_for;
-    const int P = ADC_CAND_CAP;
-    const size_t sl = (size_t)P * sizeof(unsigned long long);
-    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)adc_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)sl));
-    hipLaunchKernelGGL(adc_select_kernel, dim3((unsigned)nq), dim3(1024), sl, s, cand, cnt, N, k, id_offset, scores, ids,
-                       status);
-    RC_LAUNCH_CHECK(h);
-    return RC_OK;
+    return rc_adc_launch_select(h, cand, cnt, nq, N, k, id_offset, scores, ids, status, s);
 }

@@ -592,3 +592,69 @@ def test_native_rccl_solve_single_rank(monkeypatch):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_ivf_extension_exact_and_equals_flat_when_all_lists_probed():
+    """repconc_amd.ivf (nlist > 1: a build-side extension, the reference only has nlist = 1): (a) probing every cell
+    == the flat search, bit for bit; (b) any nprobe == the brute-force oracle on the same cells; (c) recall grows
+    with nprobe."""
+    from repconc_amd import ops
+    from repconc_amd.index import PQIndex
+    from repconc_amd.ivf import IVFPQIndex
+    N, M, nlist, nq = 120000, 48, 64, 9
+    x = synth.clustered_embeddings(41, N)
+    C = synth.sample_centroids(42, x[:8192], M)
+    q = x[np.random.default_rng(43).integers(0, N, nq)] + 0.2 * synth.gaussian(44, (nq, 768))
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(C)
+    ivf.train(x[:30000], iters=6)
+    ivf.add(x)
+    assert ivf.ntotal == N and int(ivf.list_off[-1]) == N
+    codes = ops.assign_nearest(_t(x), _t(C), torch.uint8)
+    list_ids = torch.empty(N, dtype=torch.int64, device=DEV)
+    lens = (ivf.list_off[1:] - ivf.list_off[:-1])
+    list_ids[ivf.ids] = torch.repeat_interleave(torch.arange(nlist, device=DEV), lens)
+    assert torch.equal(ivf.codes, codes[ivf.ids])
+    flat = PQIndex(768, M, device=DEV)
+    flat.set_centroids(C)
+    flat.add_codes(codes)
+    for k in (10, 200):
+        fs, fi = flat.search(_t(q), k)
+        s, i = ivf.search(_t(q), k, nprobe=nlist)
+        assert torch.equal(i, fi) and torch.equal(s, fs)                         # (a)
+    recalls = []
+    for nprobe in (1, 4, 16):
+        s, i = ivf.search(q, 10, nprobe)
+        ws, wi = pq_oracle.ivf_search(q, C, codes.cpu().numpy(), list_ids.cpu().numpy(), ivf.coarse.cpu().numpy(), 10, nprobe)
+        assert np.array_equal(i, wi)                                             # (b)
+        assert np.array_equal(s.view(np.uint32), ws.view(np.uint32))
+        fi10 = flat.search(q, 10)[1]
+        recalls.append(np.mean([len(set(i[r]) & set(fi10[r])) / 10 for r in range(nq)]))
+    assert recalls[0] <= recalls[1] <= recalls[2] and recalls[2] > 0.8          # (c)
+    # a flat index re-organised without embeddings (cells from the reconstructions)
+    ivf2 = IVFPQIndex.from_flat(flat, 32, iters=4)
+    s2, i2 = ivf2.search(_t(q), 10, nprobe=32)
+    assert torch.equal(i2, flat.search(_t(q), 10)[1])
+    # tiny cells: fewer than k rows probed -> padded with -1 / -inf
+    s3, i3 = ivf.search(q[:2], 5000, nprobe=1)
+    n_rows = int((i3[0] >= 0).sum())
+    assert n_rows < 5000 and np.all(i3[0][n_rows:] == -1) and np.all(np.isinf(s3[0][n_rows:]))
+
+
+def test_encode_corpus_to_index_matches_forward_codes():
+    from types import SimpleNamespace
+    from repconc_amd.encode import encode_corpus_to_index
+    from repconc_amd.models.repconc import RepCONC
+    table = torch.from_numpy(synth.clustered_embeddings(4242, 1000))
+    C = synth.sample_centroids(4243, table.numpy(), 48)
+    cfg = SimpleNamespace(MCQ_M=48, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_IP")
+    model = RepCONC(cfg, _TableEncoder(table), False, None, None).to(DEV)
+    with torch.no_grad():
+        model.centroids.copy_(_t(C))
+    ids = torch.arange(1000, device=DEV)[:, None].repeat(1, 3)
+    batches = [(ids[i:i + 128], torch.ones_like(ids[i:i + 128])) for i in range(0, 1000, 128)]
+    index = encode_corpus_to_index(model, batches, id_offset=5000)
+    want = model(ids, torch.ones_like(ids), return_code=True).discrete_codes.to(torch.uint8)
+    assert index.ntotal == 1000 and torch.equal(index.codes, want) and index.id_offset == 5000
+    s, i = index.search(table[:4].numpy(), 3)
+    assert (i >= 5000).all()
