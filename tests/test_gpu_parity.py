@@ -658,3 +658,60 @@ def test_encode_corpus_to_index_matches_forward_codes():
     assert index.ntotal == 1000 and torch.equal(index.codes, want) and index.id_offset == 5000
     s, i = index.search(table[:4].numpy(), 3)
     assert (i >= 5000).all()
+
+
+def test_stage1_training_step_gradients_match_direct_autograd():
+    """The two-pass cached-gradient step (finetune_repconc.py:245-396 restated in repconc_amd/train/stage1.py) gives
+    the gradients of the one-pass objective  L(q, sg(decode)+ste) + w*mse ; the constrained quantiser and the decode
+    backward kernel sit inside the step."""
+    from transformers import BertConfig
+    from repconc_amd.models.dense import BertDense
+    from repconc_amd.models.repconc import RepCONC
+    from repconc_amd.train.stage1 import Stage1Config, contrastive_loss, make_optimizer, stage1_training_step
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=128, vocab_size=500,
+                     max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg.MCQ_M, cfg.MCQ_K, cfg.similarity_metric, cfg.pooling = 48, 256, "METRIC_IP", "mean"
+    enc = BertDense(cfg)
+    model = RepCONC(cfg, enc, True, 0.003, 20).to(DEV)
+    with torch.no_grad():
+        model.centroids.mul_(0.05)
+    nq, nneg, L = 24, 72, 12
+    mk = lambda n: {"input_ids": torch.randint(1, 500, (n, L), device=DEV), "attention_mask": torch.ones((n, L), dtype=torch.long, device=DEV)}
+    qin, pin, nin = mk(nq), mk(nq), mk(nneg)
+    qids = torch.arange(nq, device=DEV)
+    pos_ids = torch.arange(1000, 1000 + nq, device=DEV)
+    neg_ids = torch.arange(2000, 2000 + nneg, device=DEV)
+    neg_ids[5] = pos_ids[3]                                         # a duplicate and a false negative
+    qrels = {i: {1000 + i} for i in range(nq)}
+    qrels[2].add(int(neg_ids[7]))
+    scfg = Stage1Config(cache_chunk_size=10, mse_loss_weight=1e-2, dynamic_topk_hard_negative=11)
+    model.zero_grad()
+    loss = stage1_training_step(model, qin, pin, qids, pos_ids, qrels, scfg, nin, neg_ids)
+    got = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert np.isfinite(loss) and "centroids" in got and float(got["centroids"].abs().sum()) > 0
+    # one-pass reference objective with the same codes
+    model.zero_grad()
+    q = model(**qin).continuous_embeds
+    p = model(**pin).continuous_embeds
+    n = model(**nin).continuous_embeds
+    docs = torch.cat([p, n], 0)
+    with torch.no_grad():
+        codes = model.quantize(docs)
+    quant = model.decode(codes)
+    ste = quant.detach() + (docs - docs.detach()) + (quant - quant.detach())     # value = quant, grads to both
+    direct = contrastive_loss(q, ste, qids, torch.cat([pos_ids, neg_ids]), qrels, scfg, "METRIC_IP", 48)
+    mse = (((quant[:nq] - p) ** 2).sum(-1).mean() + ((quant[nq:] - n) ** 2).sum(-1).mean()) * scfg.mse_loss_weight
+    # chunk means: the step averages the MSE per chunk of 10, the reference does too (:374) — mirror it
+    mse = 0
+    for rep, qt in ((p, quant[:nq]), (n, quant[nq:])):
+        for a in range(0, rep.shape[0], 10):
+            mse = mse + ((qt[a:a + 10] - rep[a:a + 10]) ** 2).sum(-1).mean() * scfg.mse_loss_weight
+    (direct + mse).backward()
+    assert abs(float(direct.detach()) - loss) < 1e-4
+    for name, grad in got.items():
+        ref = dict(model.named_parameters())[name].grad
+        assert torch.allclose(grad, ref, rtol=2e-3, atol=2e-5), name
+    opt = make_optimizer(model)
+    opt.step()
+    assert len(opt.param_groups) == 3 and opt.param_groups[2]["lr"] == 5e-4
