@@ -507,7 +507,7 @@ struct adc_bufs {
 };
 
 template <int M, int QT>
-static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int nq, int64_t S, const adc_bufs& b, int r,
+static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int nq, int64_t S, const adc_bufs& b, int r, int k,
                             int* status, hipStream_t s) {
     const size_t lds = (size_t)M * RC_K * QT * sizeof(float);
     const unsigned qg = (unsigned)((nq + QT - 1) / QT);
@@ -523,7 +523,9 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
     hipLaunchKernelGGL(adc_threshold_kernel, dim3((unsigned)nq), dim3(1024), tl, s, b.sample, S, r, b.thr);
     RC_LAUNCH_CHECK(h);
     const unsigned tiles = (unsigned)((N + ADC_TILE_DOCS - 1) / ADC_TILE_DOCS);
-    if (N < ADC_SCREEN_MIN_N) {
+    // screening inflates the candidate list ~1.7x: beyond k = 2048 (Faiss-GPU's own limit) the id buffer could
+    // overflow, so large k keeps the exact scan
+    if (N < ADC_SCREEN_MIN_N || k > 2048) {
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kfilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         hipLaunchKernelGGL(kfilter, dim3(qg, tiles), dim3(ADC_THREADS), lds, s, codes, N, b.lut, nq, S, b.sample, b.thr,
@@ -554,7 +556,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
 }
 
 #define ADC_CASE(MM, QQ) \
-    case MM: rc = adc_launch_scans<MM, QQ>(h, codes, N, nq, L.S, bufs, r, status, s); break;
+    case MM: rc = adc_launch_scans<MM, QQ>(h, codes, N, nq, L.S, bufs, r, k, status, s); break;
 
 extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K, float* lut,
                           rc_stream_t stream) {
