@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librepconc_hip.so")
+LIB_PATH = os.environ.get("REPCONC_HIP_LIB") or os.path.join(_HERE, "lib", "librepconc_hip.so")   # env: A/B builds
 
 RC_OK, RC_EINVAL, RC_ESHAPE, RC_EHIP, RC_EWORKSPACE, RC_ECOMM = 0, -1, -2, -3, -4, -5
 RC_CODE_U8, RC_CODE_I64 = 0, 1
@@ -30,6 +30,9 @@ PROTOTYPES = {
     "rc_profile_enable": (_i, [_vp, _i]),
     "rc_profile_collect": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_d)]),
     "rc_pq_assign_nearest": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "rc_pq_assign_nearest_fast_ws_bytes": (_sz, [_i64, _i]),
+    "rc_pq_assign_nearest_fast": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "rc_pq_assign_nearest_fast_overflow": (_i, [_vp, _vp, _i64, _i, C.POINTER(_i)]),
     "rc_pq_dist_table_ws_bytes": (_sz, [_i64, _i]),
     "rc_pq_dist_table": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rc_pq_centre": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),

@@ -1,0 +1,436 @@
+// Nearest-code assignment with the matrix cores as a SCREEN and the exact-order arithmetic as the JUDGE.
+//
+// Reference: RepCONC.quantize with use_constraint=False, models/repconc/modeling_repconc.py:49-52,66 — the index-build
+// path for all 8.84 M passages.  Bit-exact codes need the reference's own fp32 rounding (sub, square, torch-CPU sum
+// order; pq_distance.hip), which a GEMM cannot reproduce.  But the GEMM form
+//     S[k,b] = ||c_k||^2 - 2 <c_k, x_b>            ( = d[k,b] - ||x_b||^2 up to rounding )
+// is within a provable distance E of the reference's d (both measured from the real-number distance), so the
+// reference's argmin is among the centroids with S <= S_min + 2E.  The MFMA pass keeps, per (row, sub-quantiser), the
+// best and second-best S: when the gap exceeds the margin the best IS the reference's code; otherwise (~2e-3 of the
+// pairs, and every exact tie) the pair is appended to a list and assign_redo_kernel recomputes it with the exact
+// arithmetic and the first-minimum rule.  Output = reference codes, bit for bit (tests compare with the exact kernel
+// and the oracle).
+//
+// Which MFMA.  v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 cycles / instruction, sharing the pipe with the
+// VALU epilogue: measured 19 ms per 4 M rows, 2.4x the exact kernel).  The bf16 XDL pipe is 16x faster and co-issues
+// with the VALU, so the screen splits every fp32 operand in two bf16 pieces, v = vh + vl + (|rest| <= 2^-18 |v|), and
+// takes three products  wh.xh + wh.xl + wl.xh  (w = -2c) accumulated in fp32:
+//     dropped terms  <= 3.1 * 2^-18 * sum|w_j x_j|  <= 1.2e-5 (||x||^2 + ||c||^2)
+//     fp32 accumulation of 3*KP+1 terms, each <= 1 ulp of a partial sum <= 2 (||x||^2+||c||^2):  (3 KP + 1) 2.4e-7
+//     ||c||^2 and the reference's own d: (dsub+2) 1.2e-7 each; the 4 tag bits (below): 3.8e-6
+// => E = [1.6e-5 + (3 KP + 2 dsub + 5) 2.4e-7] (||x||^2 + max_k ||c_k||^2),  margin = 2 E.
+//
+// Mapping (v_mfma_f32_32x32x16_bf16, 32 cycles): D = A*B + C with A[i][kk] = piece of -2 c_{32 kt + i}[kk] (LDS, 16 B
+// per lane), B[kk][j] = piece of x_{b0 + j}[kk] (registers), C = ||c||^2; rows of D = centroids, columns = documents,
+// so a lane holds 16 centroids of ONE document per tile and the running (min, second min) needs no cross-lane traffic
+// until the two half-waves merge once per sub-quantiser.  A wave owns 64 documents (two column sets): the A fragments
+// and ||c||^2 of a centroid tile are read once for both, and the two accumulator tiles ping-pong so that the VALU
+// epilogue of one overlaps the MFMAs of the next.  The kernel is then bound by that epilogue: 3 VALU ops per
+// (document, centroid) pair — v_and_or (tag), v_med3 (second min), v_med3 (min).
+#include "rc_common.h"
+
+typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
+typedef float mf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mf_bf16x8 __attribute__((ext_vector_type(8)));
+
+#define MF_COLS 32                 // documents per MFMA tile
+#define MF_SETS 2                  // tiles (column sets) per wave
+#define MF_WAVES 4
+#define MF_ROWS_PER_BLOCK (MF_COLS * MF_SETS * MF_WAVES)
+
+// exact reference distance (identical code to sqdist_exact in pq_distance.hip; duplicated because device functions
+// do not link across translation units without -fgpu-rdc)
+template <int DSUB>
+__device__ __forceinline__ float mf_exact(const float* __restrict__ x, const float* __restrict__ c) {
+    constexpr int NV = DSUB / 8, TAIL = DSUB % 8, FULL = NV / 4;
+    float sq[DSUB];
+#pragma unroll
+    for (int j = 0; j < DSUB; ++j) {
+        const float t = x[j] - c[j];
+        sq[j] = t * t;
+    }
+    float a[8];
+    if constexpr (FULL == 0) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float s = sq[l];
+#pragma unroll
+            for (int v = 1; v < NV; ++v) s = s + sq[8 * v + l];
+            a[l] = s;
+        }
+    } else {
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                float s = sq[8 * q + l];
+#pragma unroll
+                for (int i = 1; i < FULL; ++i) s = s + sq[8 * (4 * i + q) + l];
+                acc[q][l] = s;
+            }
+#pragma unroll
+        for (int v = 4 * FULL; v < NV; ++v)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[0][l] = acc[0][l] + sq[8 * v + l];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) a[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+    }
+    float r;
+    if constexpr (TAIL == 0) {
+        r = a[0];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) r = r + a[l];
+    } else {
+        r = sq[NV * 8];
+#pragma unroll
+        for (int j = 1; j < TAIL; ++j) r = r + sq[NV * 8 + j];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) r = r + a[l];
+    }
+    return r;
+}
+
+// min / second-min updates as two v_med3_f32 (target intrinsic: no canonicalisation ops around the bit-tagged values,
+// and visible to the instruction scheduler, unlike inline asm)
+__device__ __forceinline__ float mf_min(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
+__device__ __forceinline__ float mf_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// (v0, v1) -> packed bf16 pair of the leading pieces and of the remainders (v_cvt_pk_bf16_f32, round to nearest even)
+__device__ __forceinline__ void mf_split2(float v0, float v1, unsigned& hi, unsigned& lo) {
+    const mf_f32x2 v = {v0, v1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, mf_bf16x2));
+    const mf_f32x2 r = {v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xFFFF0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, mf_bf16x2));
+}
+
+template <int DSUB>
+struct mf_geom {
+    static constexpr int KP = (DSUB + 15) / 16 * 16;     // reduction length padded to the MFMA's 16
+    static constexpr int KS = KP / 16;                   // MFMA k-steps
+    static constexpr int NBUF = (DSUB <= 32) ? 2 : 1;    // LDS centroid buffers
+    static constexpr int BUF_BYTES = RC_K * KP * 2 * 2 + RC_K * 4 + 32;   // hi | lo | cn | wave maxima
+};
+
+// LDS per block: NBUF x { whi[256][KP] bf16 | wlo[256][KP] bf16 | cn[256] f32 | wave maxima[8] } | code tile [256][M].
+// NBUF = 2: sub-quantiser m+1's centroids are fetched into registers before the tile loop of m and written to the other
+// buffer after it, so one barrier per m and no exposed L2 latency.
+template <int DSUB>
+__global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ C, int64_t B, int M,
+                                                          uint8_t* __restrict__ codes_u8, int64_t* __restrict__ codes_i64,
+                                                          unsigned* __restrict__ redo_count, unsigned* __restrict__ redo,
+                                                          unsigned redo_cap) {
+    using G = mf_geom<DSUB>;
+    constexpr int KP = G::KP, KS = G::KS, NBUF = G::NBUF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
+    unsigned char* tile = mf_smem + NBUF * G::BUF_BYTES;           // [256][M]
+
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63;
+    const int col = l & 31, half = l >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * MF_ROWS_PER_BLOCK;
+    int64_t brow[MF_SETS];
+    const float* xrow[MF_SETS];
+#pragma unroll
+    for (int s = 0; s < MF_SETS; ++s) {
+        brow[s] = row0 + (wv * MF_SETS + s) * MF_COLS + col;       // shared by lanes l and l^32
+        xrow[s] = x + (brow[s] < B ? brow[s] : (B - 1)) * ldx;
+    }
+
+    float4 cst[DSUB / 4];                                           // centroid `tid` of the sub-quantiser being staged
+    auto fetch_c = [&](int m) {
+        const float4* cp = reinterpret_cast<const float4*>(C + ((size_t)m * RC_K + tid) * DSUB);
+#pragma unroll
+        for (int j4 = 0; j4 < DSUB / 4; ++j4) cst[j4] = cp[j4];
+    };
+    auto store_c = [&](unsigned char* buf) {                        // pieces of -2 c_k, cn[k] = sum_j c_kj^2
+        uint4* whi = reinterpret_cast<uint4*>(buf) + (size_t)tid * (KP / 8);
+        uint4* wlo = reinterpret_cast<uint4*>(buf + RC_K * KP * 2) + (size_t)tid * (KP / 8);
+        float* cn = reinterpret_cast<float*>(buf + RC_K * KP * 4);
+        float nrm = 0.f;
+#pragma unroll
+        for (int g = 0; g < KP / 8; ++g) {                          // 8 elements -> one 16-byte chunk of each piece
+            unsigned h[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (8 * g + 4 * q < DSUB) {
+                    const float4 v = cst[2 * g + q];
+                    mf_split2(-2.0f * v.x, -2.0f * v.y, h[2 * q], lo[2 * q]);
+                    mf_split2(-2.0f * v.z, -2.0f * v.w, h[2 * q + 1], lo[2 * q + 1]);
+                    nrm = __builtin_fmaf(v.x, v.x, nrm);
+                    nrm = __builtin_fmaf(v.y, v.y, nrm);
+                    nrm = __builtin_fmaf(v.z, v.z, nrm);
+                    nrm = __builtin_fmaf(v.w, v.w, nrm);
+                }
+            }
+            whi[g] = make_uint4(h[0], h[1], h[2], h[3]);
+            wlo[g] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+        cn[tid] = nrm;
+        float mx = nrm;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (l == 0) cn[RC_K + wv] = mx;
+    };
+    // this lane's 8 elements of k-step ks: [16 ks + 8 half, +8); zero beyond DSUB
+    float4 xq[MF_SETS][KS][2];
+    auto fetch_x = [&](int m) {
+#pragma unroll
+        for (int s = 0; s < MF_SETS; ++s)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = 16 * ks + 8 * half + 4 * q;
+                    xq[s][ks][q] = (e < DSUB) ? *reinterpret_cast<const float4*>(xrow[s] + m * DSUB + e)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+    };
+
+    fetch_c(0);
+    fetch_x(0);
+    store_c(mf_smem);
+    __syncthreads();
+
+    for (int m = 0; m < M; ++m) {
+        const unsigned char* buf = mf_smem + (NBUF == 2 ? (m & 1) : 0) * G::BUF_BYTES;
+        const uint4* whi = reinterpret_cast<const uint4*>(buf);
+        const uint4* wlo = reinterpret_cast<const uint4*>(buf + RC_K * KP * 2);
+        const float* cn = reinterpret_cast<const float*>(buf + RC_K * KP * 4);
+        const float cnmax = fmaxf(fmaxf(cn[RC_K], cn[RC_K + 1]), fmaxf(cn[RC_K + 2], cn[RC_K + 3]));
+
+        // B operands: bf16 pieces of this lane's elements; squared norm of the whole slice
+        mf_bf16x8 bh[MF_SETS][KS], bl[MF_SETS][KS];
+        float xn[MF_SETS];
+#pragma unroll
+        for (int s = 0; s < MF_SETS; ++s) {
+            float nrm = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                unsigned h[4], lo[4];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 v = xq[s][ks][q];
+                    mf_split2(v.x, v.y, h[2 * q], lo[2 * q]);
+                    mf_split2(v.z, v.w, h[2 * q + 1], lo[2 * q + 1]);
+                    nrm = __builtin_fmaf(v.x, v.x, nrm);
+                    nrm = __builtin_fmaf(v.y, v.y, nrm);
+                    nrm = __builtin_fmaf(v.z, v.z, nrm);
+                    nrm = __builtin_fmaf(v.w, v.w, nrm);
+                }
+                bh[s][ks] = __builtin_bit_cast(mf_bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+                bl[s][ks] = __builtin_bit_cast(mf_bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+            }
+            xn[s] = nrm + __shfl_xor(nrm, 32);
+        }
+        const int mn = (m + 1 < M) ? m + 1 : m;
+        fetch_x(mn);                                                // in flight during the tile loop
+        if (NBUF == 2) fetch_c(mn);
+
+        // Tiles T_i = (kt = i / 2, set = i % 2), accumulators ping-pong: MFMAs of T_i  ||  epilogue of T_{i-1}.
+        // Epilogue: running best / second best over this lane's 16 centroids of the tile; the register index r rides
+        // in the 4 low mantissa bits, the tile index of the best is tracked once per tile.
+        float m1[MF_SETS], m2[MF_SETS];
+        int ktb[MF_SETS];
+#pragma unroll
+        for (int s = 0; s < MF_SETS; ++s) { m1[s] = INFINITY; m2[s] = INFINITY; ktb[s] = 0; }
+        constexpr int NT = (RC_K / 32) * MF_SETS;
+        constexpr int NMF = 3 * KS;                                 // MFMAs per tile
+        constexpr int PER = (16 + NMF - 1) / NMF;                   // epilogue elements per MFMA slot
+        mf_f32x16 acc[2];
+        mf_bf16x8 ah[KS], al[KS];
+        mf_f32x16 cnv;
+        auto load_a = [&](int kt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int idx = (kt * 32 + col) * (KP / 8) + 2 * ks + half;
+                ah[ks] = __builtin_bit_cast(mf_bf16x8, whi[idx]);
+                al[ks] = __builtin_bit_cast(mf_bf16x8, wlo[idx]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnv[r] = cn[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+        };
+        auto scan = [&](const mf_f32x16& a, int s, int r0, int cnt) {
+#pragma unroll
+            for (int r = r0; r < r0 + cnt && r < 16; ++r) {
+                const float u = __uint_as_float((__float_as_uint(a[r]) & 0xFFFFFFF0u) | (unsigned)r);
+                m2[s] = mf_med3(m1[s], m2[s], u);
+                m1[s] = mf_min(m1[s], u);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i <= NT; ++i) {
+            const int kt = i / MF_SETS, s = i % MF_SETS;
+            const int pkt = (i - 1) / MF_SETS, ps = (i - 1) % MF_SETS;
+            if (i < NT && s == 0) load_a(kt);
+            float before = 0.f;
+            if (i > 0) before = m1[ps];
+            if (i < NT) acc[i & 1] = cnv;
+#pragma unroll
+            for (int j = 0; j < NMF; ++j) {
+                if (i < NT) {
+                    const int ks = j / 3, t = j % 3;
+                    acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 2 ? al[ks] : ah[ks],
+                                                                         t == 1 ? bl[s][ks] : bh[s][ks], acc[i & 1], 0, 0, 0);
+                }
+                if (i > 0) scan(acc[(i - 1) & 1], ps, j * PER, PER);
+            }
+            if (i > 0) ktb[ps] = (__float_as_uint(m1[ps]) != __float_as_uint(before)) ? pkt : ktb[ps];
+            if (i > 0 && i < NT) {
+#pragma unroll
+                for (int j = 0; j < NMF; ++j) {                     // issue order: 1 MFMA, then its share of the epilogue
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3 * PER, 0);
+                }
+            }
+        }
+        // rounding bound of the screen (file header): margin = 2 E
+        constexpr float MARGIN = 2.0f * (1.6e-5f + (float)(3 * KP + 2 * DSUB + 5) * 2.4e-7f);
+#pragma unroll
+        for (int s = 0; s < MF_SETS; ++s) {
+            const int r = (int)(__float_as_uint(m1[s]) & 15u);
+            int k1 = ktb[s] * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float a1 = m1[s], a2 = m2[s];
+            {   // merge the two half-waves that share a document
+                const float o1 = __shfl_xor(a1, 32), o2 = __shfl_xor(a2, 32);
+                const int ok = __shfl_xor(k1, 32);
+                const float lo = fminf(a1, o1);
+                const float second = fminf(fmaxf(a1, o1), fminf(a2, o2));
+                if (o1 < a1 || (o1 == a1 && ok < k1)) k1 = ok;
+                a1 = lo;
+                a2 = second;
+            }
+            const float margin = MARGIN * (xn[s] + cnmax);
+            const bool doubt = !((a2 - a1) > margin);               // also true for NaN / inf inputs
+            if (half == 0) {
+                tile[((wv * MF_SETS + s) * MF_COLS + col) * M + m] = (unsigned char)k1;
+                if (brow[s] < B && doubt) {
+                    const unsigned slot = atomicAdd(redo_count, 1u);
+                    if (slot < redo_cap) redo[slot] = (unsigned)(brow[s] * (int64_t)M + m);   // B*M < 2^32 (host)
+                }
+            }
+        }
+        if (m + 1 < M) {
+            if (NBUF == 2) {
+                store_c(mf_smem + ((m + 1) & 1) * G::BUF_BYTES);    // the other buffer: last read before the previous barrier
+                __syncthreads();
+            } else {
+                __syncthreads();                                    // every wave is done with this buffer
+                fetch_c(m + 1);
+                store_c(mf_smem);
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t rows = (B - row0 < MF_ROWS_PER_BLOCK) ? (B - row0) : MF_ROWS_PER_BLOCK;
+    const int64_t nbytes = rows * M;
+    if (codes_u8) {
+        unsigned char* dst = codes_u8 + row0 * M;   // row0*M is a multiple of 16 (256*M)
+        const int64_t n16 = nbytes / 16;
+        for (int64_t i = tid; i < n16; i += 256)
+            reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(tile)[i];
+        for (int64_t i = n16 * 16 + tid; i < nbytes; i += 256) dst[i] = tile[i];
+    }
+    if (codes_i64) {
+        int64_t* dst = codes_i64 + row0 * M;
+        for (int64_t i = tid; i < nbytes; i += 256) dst[i] = (int64_t)tile[i];
+    }
+}
+
+// exact recomputation of the doubtful (row, sub-quantiser) pairs: reference arithmetic, first minimum
+template <int DSUB>
+__global__ __launch_bounds__(256) void assign_redo_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ C, int M,
+                                                          const unsigned* __restrict__ redo_count,
+                                                          const unsigned* __restrict__ redo, unsigned redo_cap,
+                                                          uint8_t* __restrict__ codes_u8, int64_t* __restrict__ codes_i64) {
+    unsigned n = *redo_count;
+    if (n > redo_cap) n = redo_cap;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned e = redo[i];
+        const int64_t b = e / (unsigned)M;
+        const int m = (int)(e % (unsigned)M);
+        float xs[DSUB];
+        const float4* xp = reinterpret_cast<const float4*>(x + b * ldx + m * DSUB);
+#pragma unroll
+        for (int j = 0; j < DSUB / 4; ++j) {
+            const float4 v = xp[j];
+            xs[4 * j] = v.x; xs[4 * j + 1] = v.y; xs[4 * j + 2] = v.z; xs[4 * j + 3] = v.w;
+        }
+        const float* cm = C + (size_t)m * RC_K * DSUB;
+        float best = INFINITY;
+        int bi = 0;
+        for (int k = 0; k < RC_K; ++k) {
+            float cs[DSUB];
+            const float4* cp = reinterpret_cast<const float4*>(cm + k * DSUB);
+#pragma unroll
+            for (int j = 0; j < DSUB / 4; ++j) {
+                const float4 v = cp[j];
+                cs[4 * j] = v.x; cs[4 * j + 1] = v.y; cs[4 * j + 2] = v.z; cs[4 * j + 3] = v.w;
+            }
+            const float s = mf_exact<DSUB>(xs, cs);
+            if (s < best) { best = s; bi = k; }
+        }
+        if (codes_u8) codes_u8[b * M + m] = (uint8_t)bi;
+        if (codes_i64) codes_i64[b * M + m] = (int64_t)bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static unsigned mf_redo_cap(int64_t B, int M) { return (unsigned)(B * M / 32 + 65536); }
+
+extern "C" size_t rc_pq_assign_nearest_fast_ws_bytes(int64_t B, int M) {
+    if (B <= 0 || M <= 0) return 0;
+    return rc_align_up(256 + (size_t)mf_redo_cap(B, M) * sizeof(unsigned), 256);
+}
+
+// Asynchronous.  If more than B*M/32 + 65536 pairs are doubtful (degenerate codebooks: duplicated centroids) the list
+// overflows and the codes of the dropped pairs are provisional: query rc_pq_assign_nearest_fast_overflow afterwards.
+extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
+                                         int M, int K, uint8_t* codes_u8, int64_t* codes_i64, void* ws, size_t ws_bytes,
+                                         rc_stream_t stream) {
+    if (!h || !x || !C || B < 0 || M <= 0 || D <= 0 || ldx < D || (!codes_u8 && !codes_i64)) return RC_EINVAL;
+    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M) || B * (int64_t)M > 0xFFFFFFFFll) return RC_ESHAPE;
+    if (((uintptr_t)x & 15) || (ldx % 4) != 0) return RC_EINVAL;
+    if (B == 0) return RC_OK;
+    if (!ws || ws_bytes < rc_pq_assign_nearest_fast_ws_bytes(B, M)) return RC_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* redo_count = (unsigned*)ws;
+    unsigned* redo = (unsigned*)((char*)ws + 256);
+    const unsigned cap = mf_redo_cap(B, M);
+    RC_HIP_CHECK(h, hipMemsetAsync(redo_count, 0, 256, s));
+    const int dsub = D / M;
+    const int64_t nblk = (B + MF_ROWS_PER_BLOCK - 1) / MF_ROWS_PER_BLOCK;
+    const int kp = (dsub + 15) / 16 * 16;
+    const size_t lds = (size_t)(dsub <= 32 ? 2 : 1) * ((size_t)RC_K * kp * 4 + RC_K * 4 + 32) + (size_t)MF_ROWS_PER_BLOCK * M;
+    rc_prof_mark(h, RC_PROF_ASSIGN_NEAREST, s);
+    switch (dsub) {
+#define MF_CASE(DS)                                                                                                      \
+        case DS: {                                                                                                       \
+            auto kern = assign_mfma_kernel<DS>;                                                                          \
+            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, x, ldx, C, B, M, codes_u8, codes_i64,     \
+                               redo_count, redo, cap);                                                                   \
+            hipLaunchKernelGGL(assign_redo_kernel<DS>, dim3((unsigned)(h->num_cus * 4)), dim3(256), 0, s, x, ldx, C, M,  \
+                               redo_count, redo, cap, codes_u8, codes_i64);                                              \
+        } break;
+        MF_CASE(8) MF_CASE(12) MF_CASE(16) MF_CASE(24) MF_CASE(32) MF_CASE(48) MF_CASE(64) MF_CASE(96)
+#undef MF_CASE
+        default: return RC_ESHAPE;
+    }
+    rc_prof_mark(h, RC_PROF_ASSIGN_NEAREST, s);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+// After the stream has drained: did the doubt list overflow?  (1 = yes: rerun with rc_pq_assign_nearest.)
+extern "C" int rc_pq_assign_nearest_fast_overflow(rc_handle_t h, const void* ws, int64_t B, int M, int* doubtful_host) {
+    if (!h || !ws) return RC_EINVAL;
+    unsigned n = 0;
+    RC_HIP_CHECK(h, hipMemcpy(&n, ws, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (doubtful_host) *doubtful_host = (int)n;
+    return n > mf_redo_cap(B, M) ? 1 : 0;
+}

@@ -75,21 +75,49 @@ def _code_dtype(codes: torch.Tensor) -> int:
 
 
 # --------------------------------------------------------------------------- nearest codes
-def assign_nearest(x: torch.Tensor, centroids: torch.Tensor, dtype=torch.int64) -> torch.Tensor:
-    """argmin_k ||x_m - C[m,k]||^2 -> codes [B, M].  modeling_repconc.py:49-52,66."""
+def assign_nearest(x: torch.Tensor, centroids: torch.Tensor, dtype=torch.int64, method: str = "auto",
+                   stats: dict | None = None) -> torch.Tensor:
+    """argmin_k ||x_m - C[m,k]||^2 -> codes [B, M].  modeling_repconc.py:49-52,66.
+
+    method: "exact" = every distance in the reference's fp32 order (rc_pq_assign_nearest); "mfma" = matrix-core screen
+    + exact recomputation of the doubtful pairs (rc_pq_assign_nearest_fast) — the same codes, bit for bit; "auto" =
+    mfma when its alignment preconditions hold.  stats (optional dict) receives {"method", "doubtful"}.
+    """
     _need_cuda(x, centroids)
     x, c = _rows_f32(x), _centroids(centroids)
     B, D, M, _ = _shape(x, c)
     lib, h, s, _ = _ctx(x)
     codes = torch.empty((B, M), dtype=dtype, device=x.device)
-    if B == 0:
-        return codes
     u8 = codes if dtype == torch.uint8 else None
     i64 = codes if dtype == torch.int64 else None
     if u8 is None and i64 is None:
         raise ValueError("dtype must be torch.uint8 or torch.int64")
+    if method not in ("auto", "exact", "mfma"):
+        raise ValueError("method must be auto|exact|mfma")
+    if B == 0:
+        return codes
+    fast_ok = x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and B * M < 2 ** 32
+    if method == "mfma" and not fast_ok:
+        raise _lib.RepconcHipError("mfma assignment needs 16-byte aligned rows, ldx % 4 == 0 and B*M < 2^32")
+    if method != "exact" and fast_ok:
+        n = lib.rc_pq_assign_nearest_fast_ws_bytes(B, M)
+        ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.rc_pq_assign_nearest_fast(h, _p(x), x.stride(0), _p(c), B, D, M, K, _p(u8), _p(i64), _p(ws), n, s),
+                   "rc_pq_assign_nearest_fast", h)
+        torch.cuda.current_stream(x.device).synchronize()
+        doubtful = C.c_int(0)
+        over = lib.rc_pq_assign_nearest_fast_overflow(h, _p(ws), B, M, C.byref(doubtful))
+        if over < 0:
+            _lib.check(over, "rc_pq_assign_nearest_fast_overflow", h)
+        if stats is not None:
+            stats.update(method="mfma", doubtful=int(doubtful.value), overflow=bool(over))
+        if not over:
+            return codes
     _lib.check(lib.rc_pq_assign_nearest(h, _p(x), x.stride(0), _p(c), B, D, M, K, _p(u8), _p(i64), s),
                "rc_pq_assign_nearest", h)
+    if stats is not None:
+        stats.setdefault("doubtful", 0)
+        stats["method"] = "exact"
     return codes
 
 

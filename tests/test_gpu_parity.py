@@ -24,9 +24,10 @@ def test_nearest_codes_bit_exact(name):
     from repconc_amd import ops
     g, x, C = load_case(name)
     for dt in (torch.uint8, torch.int64):
-        codes = ops.assign_nearest(_t(x), _t(C), dt)
-        assert codes.dtype == dt
-        assert np.array_equal(codes.cpu().numpy().astype(np.uint8), g["codes_nearest"])
+        for method in ("exact", "mfma"):
+            codes = ops.assign_nearest(_t(x), _t(C), dt, method=method)
+            assert codes.dtype == dt
+            assert np.array_equal(codes.cpu().numpy().astype(np.uint8), g["codes_nearest"]), method
 
 
 @pytest.mark.parametrize("name", golden_cases())
@@ -715,3 +716,87 @@ def test_stage1_training_step_gradients_match_direct_autograd():
     opt = make_optimizer(model)
     opt.step()
     assert len(opt.param_groups) == 3 and opt.param_groups[2]["lr"] == 5e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# matrix-core screen + exact rescoring (csrc/pq_assign_mfma.hip): the same codes as the exact-order kernel
+@pytest.mark.parametrize("M", [96, 64, 48, 32, 24, 16, 12, 8])
+def test_mfma_screened_assignment_equals_exact(M):
+    from repconc_amd import ops
+    rng = np.random.default_rng(1000 + M)
+    B = 1000 + 7 * M                                   # not a multiple of the 128-row block
+    x = rng.standard_normal((B, 768)).astype(np.float32)
+    C = rng.standard_normal((M, 256, 768 // M)).astype(np.float32)
+    st = {}
+    fast = ops.assign_nearest(_t(x), _t(C), torch.uint8, method="mfma", stats=st)
+    exact = ops.assign_nearest(_t(x), _t(C), torch.uint8, method="exact")
+    assert st["method"] == "mfma" and not st["overflow"]
+    assert torch.equal(fast, exact)
+    assert np.array_equal(fast.cpu().numpy(), c_oracle.quantize(x, C, False)[0])
+    assert st["doubtful"] < B * M // 20               # the screen decides almost everything
+
+
+def test_mfma_screened_assignment_ties_and_near_ties():
+    """Duplicated centroids (exact ties -> the FIRST index must win), centroids differing in the last bit, rows that
+    sit exactly between two centroids, and wildly scaled rows: everything doubtful must reach the exact judge."""
+    from repconc_amd import ops
+    rng = np.random.default_rng(77)
+    M, dsub, B = 48, 16, 2048
+    C = rng.standard_normal((M, 256, dsub)).astype(np.float32)
+    C[:, 200] = C[:, 3]                                # exact duplicates
+    C[:, 201] = np.nextafter(C[:, 5], np.float32(np.inf))   # one ulp away
+    x = rng.standard_normal((B, 768)).astype(np.float32)
+    xs = x.reshape(B, M, dsub)
+    xs[:256, :] = C[:, 3][None]                        # on a duplicated centroid
+    xs[256:512, :] = C[:, 5][None] + 1e-7
+    xs[512:768, :] = 0.5 * (C[:, 7] + C[:, 9])[None]   # equidistant in exact arithmetic
+    xs[768:900] *= 1e4
+    xs[900:1024] *= 1e-4
+    x = xs.reshape(B, 768)
+    st = {}
+    fast = ops.assign_nearest(_t(x), _t(C), torch.int64, method="mfma", stats=st)
+    exact = ops.assign_nearest(_t(x), _t(C), torch.int64, method="exact")
+    assert torch.equal(fast, exact)
+    assert np.array_equal(fast.cpu().numpy(), c_oracle.quantize(x, C, False)[0])
+    assert st["doubtful"] >= 512 * M            # the duplicate and one-ulp rows for certain
+
+
+def test_mfma_assignment_overflow_falls_back_and_unaligned_rows():
+    """All centroids identical: every pair is doubtful, the list overflows and assign_nearest("auto") must fall back
+    to the exact kernel (codes all 0).  Unaligned rows: ops realigns, the raw C call refuses."""
+    from repconc_amd import ops, _lib
+    rng = np.random.default_rng(5)
+    M, B = 48, 8192
+    C = np.repeat(rng.standard_normal((M, 1, 16)).astype(np.float32), 256, axis=1)
+    x = rng.standard_normal((B, 768)).astype(np.float32)
+    st = {}
+    codes = ops.assign_nearest(_t(x), _t(C), torch.uint8, stats=st)
+    assert st["method"] == "exact" and st["overflow"]
+    assert int(codes.max()) == 0
+    wide = torch.zeros((64, 771), device=DEV)
+    wide[:, 1:769] = _t(x[:64])
+    st = {}
+    C2 = rng.standard_normal((M, 256, 16)).astype(np.float32)
+    got = ops.assign_nearest(wide[:, 1:769], _t(C2), torch.uint8, stats=st)   # ops realigns the rows (one copy)
+    assert st["method"] == "mfma"
+    assert np.array_equal(got.cpu().numpy(), c_oracle.quantize(x[:64], C2, False)[0])
+    # the C entry point itself rejects what it cannot load as float4
+    lib, h = _lib.load(), _lib.handle(0)
+    v = wide[:, 1:769]
+    out = torch.empty((64, M), dtype=torch.uint8, device=DEV)
+    n = lib.rc_pq_assign_nearest_fast_ws_bytes(64, M)
+    ws = torch.empty(n, dtype=torch.uint8, device=DEV)
+    rc = lib.rc_pq_assign_nearest_fast(h, v.data_ptr(), v.stride(0), _t(C2).data_ptr(), 64, 768, M, 256,
+                                       out.data_ptr(), None, ws.data_ptr(), n, None)
+    assert rc == _lib.RC_EINVAL
+
+
+def test_adc_large_k_uses_exact_scan():
+    """k > 2048 on a large index must bypass the integer screen (candidate-buffer bound) and still be exact."""
+    from repconc_amd import ops
+    M, N, nq, k = 48, 300000, 3, 3000
+    C, codes, q = _adc_case(M, N, nq, seed=4242)
+    scores, ids = ops.adc_search(_t(codes), _t(C), _t(q), k)
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    assert np.array_equal(ids.cpu().numpy(), wi)
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), ws.view(np.uint32))
