@@ -225,6 +225,42 @@ def main():
                                  "gather rate and the VALU byte accumulation (DESIGN.md §4)"},
         }
 
+    # ------------------------------------------------------------------ index-build leg (nearest codes, a-1/a-5)
+    if not args.no_adc:
+        nb = 1 << 20                                           # rows per rank per pass (a 1 M-passage encode chunk)
+        xb = torch.randn((nb, D), device=dev, generator=torch.Generator(device=dev).manual_seed(20225 + rank))
+        ib = {}
+        for method in ("exact", "mfma"):
+            ops.assign_nearest(xb[:8192], C, torch.uint8, method=method)
+            barrier()
+            lib.rc_profile_enable(h, 1)
+            t0 = time.perf_counter()
+            st = {}
+            for _ in range(3):
+                nc = ops.assign_nearest(xb, C, torch.uint8, method=method, stats=st)
+            barrier()
+            bdt = max_over_ranks(time.perf_counter() - t0)
+            lib.rc_profile_enable(h, 0)
+            lib.rc_profile_collect(h, _lib.PROF_ASSIGN_NEAREST, ctypes.byref(n_l), ctypes.byref(ms_l))
+            ib[method] = (3 * nb * world / bdt, ms_l.value / max(n_l.value, 1), st.get("doubtful", 0), nc)
+        same = bool(torch.equal(ib["exact"][3], ib["mfma"][3]))
+        bytes_per_vec = D * 4 + M
+        out["index_build"] = {
+            "metric": "nearest_code_assignments_per_sec", "value": round(ib["mfma"][0], 1), "unit": "vectors/s",
+            "rows_per_pass_per_gpu": nb, "kernel_ms_per_pass": round(ib["mfma"][1], 3),
+            "method": "split-bf16 MFMA screen + exact fp32 rescoring of the doubtful pairs (csrc/pq_assign_mfma.hip)",
+            "doubtful_pairs_per_pass": ib["mfma"][2], "codes_identical_to_exact_kernel": same,
+            "exact_kernel": {"value": round(ib["exact"][0], 1), "kernel_ms_per_pass": round(ib["exact"][1], 3)},
+            "roofline": {"kernel": "assign_mfma_kernel<16> + assign_redo_kernel<16>", "bound": "hbm",
+                         "achieved": round(nb * bytes_per_vec / (ib["mfma"][1] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(nb * bytes_per_vec / (ib["mfma"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("assign_mfma_kernel"), "algorithmic_bytes_per_launch": nb * bytes_per_vec,
+                         "note": "far from the HBM roof by construction: 256 candidate distances per (row, sub-quantiser) "
+                                 "cost 3 VALU ops each in the min/second-min epilogue (VALU ~80 % busy, PMC), the bf16 "
+                                 "MFMAs run underneath (DESIGN.md §3.5)"},
+        }
+        del xb
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     if world == 1 and not args.no_cpu:
         from oracle import c_oracle

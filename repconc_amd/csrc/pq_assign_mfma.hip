@@ -16,7 +16,7 @@
 // with the VALU, so the screen splits every fp32 operand in two bf16 pieces, v = vh + vl + (|rest| <= 2^-18 |v|), and
 // takes three products  wh.xh + wh.xl + wl.xh  (w = -2c) accumulated in fp32:
 //     dropped terms  <= 3.1 * 2^-18 * sum|w_j x_j|  <= 1.2e-5 (||x||^2 + ||c||^2)
-//     fp32 accumulation of 3*KP+1 terms, each <= 1 ulp of a partial sum <= 2 (||x||^2+||c||^2):  (3 KP + 1) 2.4e-7
+//     fp32 accumulation of 3*KP+3 terms (||c||^2 enters as 3 exact bf16 pieces times 1.0), each <= 1 ulp of a partial sum <= 2 (||x||^2+||c||^2):  (3 KP + 1) 2.4e-7
 //     ||c||^2 and the reference's own d: (dsub+2) 1.2e-7 each; the 4 tag bits (below): 3.8e-6
 // => E = [1.6e-5 + (3 KP + 2 dsub + 5) 2.4e-7] (||x||^2 + max_k ||c_k||^2),  margin = 2 E.
 //
@@ -28,6 +28,8 @@
 // epilogue of one overlaps the MFMAs of the next.  The kernel is then bound by that epilogue: 3 VALU ops per
 // (document, centroid) pair — v_and_or (tag), v_med3 (second min), v_med3 (min).
 #include "rc_common.h"
+
+#include <type_traits>
 
 typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
 typedef float mf_f32x2 __attribute__((ext_vector_type(2)));
@@ -92,9 +94,14 @@ __device__ __forceinline__ float mf_exact(const float* __restrict__ x, const flo
     return r;
 }
 
-// min / second-min updates as two v_med3_f32 (target intrinsic: no canonicalisation ops around the bit-tagged values,
-// and visible to the instruction scheduler, unlike inline asm)
-__device__ __forceinline__ float mf_min(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
+// min / second-min updates as two v_med3_f32: m2' = med3(m1, m2, u), m1' = med3(m1, u, -inf).  The target intrinsic
+// needs no canonicalisation of the bit-tagged values and stays visible to the instruction scheduler (inline asm does
+// not); -inf comes through an opaque SGPR, otherwise the compiler folds the second one into v_max + v_min (2 ops).
+__device__ __forceinline__ float mf_opaque_neg_inf() {
+    float v;
+    asm volatile("s_mov_b32 %0, 0xff800000" : "=s"(v));
+    return v;
+}
 __device__ __forceinline__ float mf_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
 // (v0, v1) -> packed bf16 pair of the leading pieces and of the remainders (v_cvt_pk_bf16_f32, round to nearest even)
@@ -110,14 +117,15 @@ struct mf_geom {
     static constexpr int KP = (DSUB + 15) / 16 * 16;     // reduction length padded to the MFMA's 16
     static constexpr int KS = KP / 16;                   // MFMA k-steps
     static constexpr int NBUF = (DSUB <= 32) ? 2 : 1;    // LDS centroid buffers
-    static constexpr int BUF_BYTES = RC_K * KP * 2 * 2 + RC_K * 4 + 32;   // hi | lo | cn | wave maxima
+    static constexpr int BUF_BYTES = RC_K * KP * 2 * 2 + RC_K * 16 + 32;  // hi | lo | cn pieces | wave maxima
 };
 
-// LDS per block: NBUF x { whi[256][KP] bf16 | wlo[256][KP] bf16 | cn[256] f32 | wave maxima[8] } | code tile [256][M].
+// LDS per block: NBUF x { whi[256][KP] bf16 | wlo[256][KP] bf16 | cn3[256] (3 bf16 pieces of ||c||^2, 16 B) | wave
+// maxima[8] } | code tile [256][M].
 // NBUF = 2: sub-quantiser m+1's centroids are fetched into registers before the tile loop of m and written to the other
 // buffer after it, so one barrier per m and no exposed L2 latency.
 template <int DSUB>
-__global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void assign_mfma_kernel(const float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ C, int64_t B, int M,
                                                           uint8_t* __restrict__ codes_u8, int64_t* __restrict__ codes_i64,
                                                           unsigned* __restrict__ redo_count, unsigned* __restrict__ redo,
@@ -148,7 +156,8 @@ __global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restric
     auto store_c = [&](unsigned char* buf) {                        // pieces of -2 c_k, cn[k] = sum_j c_kj^2
         uint4* whi = reinterpret_cast<uint4*>(buf) + (size_t)tid * (KP / 8);
         uint4* wlo = reinterpret_cast<uint4*>(buf + RC_K * KP * 2) + (size_t)tid * (KP / 8);
-        float* cn = reinterpret_cast<float*>(buf + RC_K * KP * 4);
+        uint4* cn3 = reinterpret_cast<uint4*>(buf + RC_K * KP * 4);
+        float* wmax = reinterpret_cast<float*>(buf + RC_K * KP * 4 + RC_K * 16);
         float nrm = 0.f;
 #pragma unroll
         for (int g = 0; g < KP / 8; ++g) {                          // 8 elements -> one 16-byte chunk of each piece
@@ -168,11 +177,17 @@ __global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restric
             whi[g] = make_uint4(h[0], h[1], h[2], h[3]);
             wlo[g] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
-        cn[tid] = nrm;
+        {   // ||c||^2 = p0 + p1 + p2 exactly (3 x 8 significant bits); it enters the tile as one more MFMA against ones
+            unsigned p01, r01, p2, dummy;
+            mf_split2(nrm, 0.f, p01, r01);                           // p01.lo16 = p0, r01.lo16 = p1
+            const float rest = (nrm - __uint_as_float(p01 << 16)) - __uint_as_float(r01 << 16);
+            mf_split2(rest, 0.f, p2, dummy);
+            cn3[tid] = make_uint4((p01 & 0xFFFFu) | (r01 << 16), p2 & 0xFFFFu, 0u, 0u);
+        }
         float mx = nrm;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        if (l == 0) cn[RC_K + wv] = mx;
+        if (l == 0) wmax[wv] = mx;
     };
     // this lane's 8 elements of k-step ks: [16 ks + 8 half, +8); zero beyond DSUB
     float4 xq[MF_SETS][KS][2];
@@ -198,8 +213,9 @@ __global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restric
         const unsigned char* buf = mf_smem + (NBUF == 2 ? (m & 1) : 0) * G::BUF_BYTES;
         const uint4* whi = reinterpret_cast<const uint4*>(buf);
         const uint4* wlo = reinterpret_cast<const uint4*>(buf + RC_K * KP * 2);
-        const float* cn = reinterpret_cast<const float*>(buf + RC_K * KP * 4);
-        const float cnmax = fmaxf(fmaxf(cn[RC_K], cn[RC_K + 1]), fmaxf(cn[RC_K + 2], cn[RC_K + 3]));
+        const uint4* cn3 = reinterpret_cast<const uint4*>(buf + RC_K * KP * 4);
+        const float* wmax = reinterpret_cast<const float*>(buf + RC_K * KP * 4 + RC_K * 16);
+        const float cnmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 
         // B operands: bf16 pieces of this lane's elements; squared norm of the whole slice
         mf_bf16x8 bh[MF_SETS][KS], bl[MF_SETS][KS];
@@ -229,62 +245,88 @@ __global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restric
         fetch_x(mn);                                                // in flight during the tile loop
         if (NBUF == 2) fetch_c(mn);
 
-        // Tiles T_i = (kt = i / 2, set = i % 2), accumulators ping-pong: MFMAs of T_i  ||  epilogue of T_{i-1}.
+        // Tiles T(kt, set), accumulators ping-pong: MFMAs of one tile  ||  epilogue of the previous one.
         // Epilogue: running best / second best over this lane's 16 centroids of the tile; the register index r rides
         // in the 4 low mantissa bits, the tile index of the best is tracked once per tile.
         float m1[MF_SETS], m2[MF_SETS];
         int ktb[MF_SETS];
+        const float ninf = mf_opaque_neg_inf();
 #pragma unroll
         for (int s = 0; s < MF_SETS; ++s) { m1[s] = INFINITY; m2[s] = INFINITY; ktb[s] = 0; }
-        constexpr int NT = (RC_K / 32) * MF_SETS;
-        constexpr int NMF = 3 * KS;                                 // MFMAs per tile
+        constexpr int NMF = 3 * KS + 1;                             // MFMAs per tile
         constexpr int PER = (16 + NMF - 1) / NMF;                   // epilogue elements per MFMA slot
-        mf_f32x16 acc[2];
-        mf_bf16x8 ah[KS], al[KS];
-        mf_f32x16 cnv;
-        auto load_a = [&](int kt) {
+        struct afrag { mf_bf16x8 h[KS], l[KS], cn; };
+        const mf_bf16x8 ones = __builtin_bit_cast(mf_bf16x8, make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u));
+        auto load_a = [&](afrag& A, int kt) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int idx = (kt * 32 + col) * (KP / 8) + 2 * ks + half;
-                ah[ks] = __builtin_bit_cast(mf_bf16x8, whi[idx]);
-                al[ks] = __builtin_bit_cast(mf_bf16x8, wlo[idx]);
+                A.h[ks] = __builtin_bit_cast(mf_bf16x8, whi[idx]);
+                A.l[ks] = __builtin_bit_cast(mf_bf16x8, wlo[idx]);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cnv[r] = cn[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+            const uint4 c = cn3[kt * 32 + col];
+            A.cn = __builtin_bit_cast(mf_bf16x8, half ? make_uint4(0u, 0u, 0u, 0u) : c);
         };
         auto scan = [&](const mf_f32x16& a, int s, int r0, int cnt) {
 #pragma unroll
             for (int r = r0; r < r0 + cnt && r < 16; ++r) {
                 const float u = __uint_as_float((__float_as_uint(a[r]) & 0xFFFFFFF0u) | (unsigned)r);
                 m2[s] = mf_med3(m1[s], m2[s], u);
-                m1[s] = mf_min(m1[s], u);
+                m1[s] = mf_med3(m1[s], u, ninf);
             }
         };
-#pragma unroll
-        for (int i = 0; i <= NT; ++i) {
-            const int kt = i / MF_SETS, s = i % MF_SETS;
-            const int pkt = (i - 1) / MF_SETS, ps = (i - 1) % MF_SETS;
-            if (i < NT && s == 0) load_a(kt);
-            float before = 0.f;
-            if (i > 0) before = m1[ps];
-            if (i < NT) acc[i & 1] = cnv;
+        // W = true: issue the MFMAs of tile (A, set sw) into aw;  R = true: run the epilogue of tile (kr, set sr) from ar
+        auto step = [&](auto W, auto R, mf_f32x16& aw, const afrag& A, auto sw, const mf_f32x16& ar, auto sr, int kr) {
+            constexpr bool w = decltype(W)::value, rd = decltype(R)::value;
+            constexpr int SW = decltype(sw)::value, SR = decltype(sr)::value;
+            const float before = m1[SR];
 #pragma unroll
             for (int j = 0; j < NMF; ++j) {
-                if (i < NT) {
-                    const int ks = j / 3, t = j % 3;
-                    acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 2 ? al[ks] : ah[ks],
-                                                                         t == 1 ? bl[s][ks] : bh[s][ks], acc[i & 1], 0, 0, 0);
+                if constexpr (w) {
+                    if (j == 0) {
+                        const mf_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        aw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.cn, ones, zero, 0, 0, 0);
+                    } else {
+                        const int ks = (j - 1) / 3, t = (j - 1) % 3;
+                        aw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 2 ? A.l[ks] : A.h[ks],
+                                                                     t == 1 ? bl[SW][ks] : bh[SW][ks], aw, 0, 0, 0);
+                    }
                 }
-                if (i > 0) scan(acc[(i - 1) & 1], ps, j * PER, PER);
+                if constexpr (rd) scan(ar, SR, j * PER, PER);
             }
-            if (i > 0) ktb[ps] = (__float_as_uint(m1[ps]) != __float_as_uint(before)) ? pkt : ktb[ps];
-            if (i > 0 && i < NT) {
+            if constexpr (rd) ktb[SR] = (__float_as_uint(m1[SR]) != __float_as_uint(before)) ? kr : ktb[SR];
+            if constexpr (w && rd) {
 #pragma unroll
                 for (int j = 0; j < NMF; ++j) {                     // issue order: 1 MFMA, then its share of the epilogue
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 3 * PER, 0);
                 }
             }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        mf_f32x16 acc0, acc1 = {};
+        afrag A0, A1;
+        load_a(A0, 0);
+        step(T_{}, F_{}, acc0, A0, S0{}, acc1, S1{}, 0);            // T(0,0)
+#pragma unroll 1
+        for (int kt = 0; kt < RC_K / 32 - 2; kt += 2) {
+            load_a(A1, kt + 1);
+            step(T_{}, T_{}, acc1, A0, S1{}, acc0, S0{}, kt);       // T(kt,1)    || epilogue T(kt,0)
+            step(T_{}, T_{}, acc0, A1, S0{}, acc1, S1{}, kt);       // T(kt+1,0)  || epilogue T(kt,1)
+            load_a(A0, kt + 2);
+            step(T_{}, T_{}, acc1, A1, S1{}, acc0, S0{}, kt + 1);   // T(kt+1,1)  || epilogue T(kt+1,0)
+            step(T_{}, T_{}, acc0, A0, S0{}, acc1, S1{}, kt + 1);   // T(kt+2,0)  || epilogue T(kt+1,1)
+        }
+        {
+            constexpr int kt = RC_K / 32 - 2;
+            load_a(A1, kt + 1);
+            step(T_{}, T_{}, acc1, A0, S1{}, acc0, S0{}, kt);
+            step(T_{}, T_{}, acc0, A1, S0{}, acc1, S1{}, kt);
+            step(T_{}, T_{}, acc1, A1, S1{}, acc0, S0{}, kt + 1);
+            step(F_{}, T_{}, acc0, A1, S0{}, acc1, S1{}, kt + 1);
         }
         // rounding bound of the screen (file header): margin = 2 E
         constexpr float MARGIN = 2.0f * (1.6e-5f + (float)(3 * KP + 2 * DSUB + 5) * 2.4e-7f);
@@ -340,7 +382,9 @@ __global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restric
     }
 }
 
-// exact recomputation of the doubtful (row, sub-quantiser) pairs: reference arithmetic, first minimum
+// exact recomputation of the doubtful (row, sub-quantiser) pairs: reference arithmetic, first minimum.  One wave per
+// pair: lane l judges centroids l, l+64, l+128, l+192 (ascending, so the first minimum within the lane), then a
+// butterfly keeps the smaller distance and, on equal distances, the smaller index.
 template <int DSUB>
 __global__ __launch_bounds__(256) void assign_redo_kernel(const float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ C, int M,
@@ -349,7 +393,9 @@ __global__ __launch_bounds__(256) void assign_redo_kernel(const float* __restric
                                                           uint8_t* __restrict__ codes_u8, int64_t* __restrict__ codes_i64) {
     unsigned n = *redo_count;
     if (n > redo_cap) n = redo_cap;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned i = wave; i < n; i += nwaves) {
         const unsigned e = redo[i];
         const int64_t b = e / (unsigned)M;
         const int m = (int)(e % (unsigned)M);
@@ -363,7 +409,9 @@ __global__ __launch_bounds__(256) void assign_redo_kernel(const float* __restric
         const float* cm = C + (size_t)m * RC_K * DSUB;
         float best = INFINITY;
         int bi = 0;
-        for (int k = 0; k < RC_K; ++k) {
+#pragma unroll
+        for (int q = 0; q < RC_K / 64; ++q) {
+            const int k = q * 64 + lane;
             float cs[DSUB];
             const float4* cp = reinterpret_cast<const float4*>(cm + k * DSUB);
 #pragma unroll
@@ -374,8 +422,16 @@ __global__ __launch_bounds__(256) void assign_redo_kernel(const float* __restric
             const float s = mf_exact<DSUB>(xs, cs);
             if (s < best) { best = s; bi = k; }
         }
-        if (codes_u8) codes_u8[b * M + m] = (uint8_t)bi;
-        if (codes_i64) codes_i64[b * M + m] = (int64_t)bi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) {
+            if (codes_u8) codes_u8[b * M + m] = (uint8_t)bi;
+            if (codes_i64) codes_i64[b * M + m] = (int64_t)bi;
+        }
     }
 }
 
@@ -405,7 +461,7 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
     const int dsub = D / M;
     const int64_t nblk = (B + MF_ROWS_PER_BLOCK - 1) / MF_ROWS_PER_BLOCK;
     const int kp = (dsub + 15) / 16 * 16;
-    const size_t lds = (size_t)(dsub <= 32 ? 2 : 1) * ((size_t)RC_K * kp * 4 + RC_K * 4 + 32) + (size_t)MF_ROWS_PER_BLOCK * M;
+    const size_t lds = (size_t)(dsub <= 32 ? 2 : 1) * ((size_t)RC_K * kp * 4 + RC_K * 16 + 32) + (size_t)MF_ROWS_PER_BLOCK * M;
     rc_prof_mark(h, RC_PROF_ASSIGN_NEAREST, s);
     switch (dsub) {
 #define MF_CASE(DS)                                                                                                      \

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""profiles/pmc_summary.json from the raw per-kernel counter means (tools/pmc_parse.py output).
+    python tools/pmc_summary.py <raw.json> <out.json> [note]
+FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half the bytes of
+wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is used as reported."""
+import json
+import sys
+
+raw = json.load(open(sys.argv[1]))
+note = sys.argv[3] if len(sys.argv) > 3 else ""
+B, M, K, NC, NQ, NB = 49152, 48, 256, 8841823, 1200, 1 << 20
+ALG = {  # SURVEY 8(d) per-unit bytes x units per launch
+    "sk_sweep_kernel": ("sk_sweep_kernel<false>", B * M * K * 4),
+    "adc_screen_kernel": ("adc_screen_kernel<48, 8>", NQ * NC * M),
+    "assign_mfma_kernel": ("assign_mfma_kernel<16>", NB * (768 * 4 + M)),
+}
+out = {"_how": "tools/pmc_collect.sh: rocprofv3 --pmc <group> --kernel-trace, one pass per counter group, over "
+               "`python bench.py --steps 1 --warmup 1 --no-cpu --adc-batches 1`; means per launch. FETCH_SIZE/WRITE_SIZE are "
+               "KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md. " + note}
+for key, (kname, alg) in ALG.items():
+    c = raw.get(kname)
+    if not c:
+        continue
+    f, w = c.get("FETCH_SIZE", {}).get("mean"), c.get("WRITE_SIZE", {}).get("mean")
+    e = {"kernel": kname, "launches": c.get("FETCH_SIZE", {}).get("n"), "fetch_size_kib_mean": f, "write_size_kib_mean": w,
+         "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024) if f is not None and w is not None else None,
+         "algorithmic_bytes_per_launch": alg,
+         "sq": {k: v["mean"] for k, v in c.items() if k not in ("FETCH_SIZE", "WRITE_SIZE")}}
+    sq = e["sq"]
+    if "SQ_INSTS_VALU" in sq and "GRBM_GUI_ACTIVE" in sq:
+        # GRBM_GUI_ACTIVE sums the 8 XCDs; a wave64 VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs
+        e["valu_busy_frac"] = round(sq["SQ_INSTS_VALU"] * 4 / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
+    out[key] = e
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print({k: (v.get("hbm_bytes_per_launch"), v.get("valu_busy_frac")) for k, v in out.items() if k != "_how"})
