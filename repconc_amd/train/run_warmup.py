@@ -14,8 +14,8 @@ training loop below restates Faiss 1.7.x's published procedure (SURVEY.md Append
 
 Arithmetic: assignment (`rc_pq_assign_nearest`), sufficient statistics (`rc_kmeans_stats`) and centroid update
 (`rc_kmeans_update`) are the HIP kernels; the 768x768 rotation GEMM and SVD are library calls on PyTorch-ROCm
-(SURVEY.md §2.3 K8).  With several ranks each rank passes its corpus shard and the statistics are summed with one
-all-reduce per Lloyd iteration.
+(SURVEY.md §2.3 K8).  With several ranks each rank passes its corpus shard and the statistics are combined with one
+all-gather + rank-ordered sum per Lloyd iteration (`gather_stats_`).
 """
 from __future__ import annotations
 
@@ -52,10 +52,24 @@ class PreTransformIndex:
         return (scores.cpu().numpy(), ids.cpu().numpy()) if as_numpy else (scores, ids)
 
 
-def _allreduce_stats(sums, counts):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(sums)
-        dist.all_reduce(counts)
+def gather_stats_(sums: torch.Tensor, counts: torch.Tensor, group=None):
+    """Sum the per-shard Lloyd statistics over the ranks, in place (BASELINE north_star: "RCCL all-gather
+    over xGMI of per-shard centroid sufficient statistics").  ONE all-gather of the packed [M,K,dsub+1] fp64 block
+    (sums | counts; 1.7 MB per rank at M=48) followed by a rank-ordered sum: unlike an all-reduce, whose ring order is
+    not fixed, every rank then holds bit-identical statistics and therefore bit-identical centroids."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sums, counts
+    G = dist.get_world_size(group)
+    M, K, dsub = sums.shape
+    packed = torch.cat([sums, counts.to(sums.dtype).unsqueeze(-1)], dim=-1).contiguous()     # counts < 2^53: exact
+    gathered = torch.empty((G,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    total = gathered[0].clone()
+    for r in range(1, G):
+        total += gathered[r]
+    sums.copy_(total[..., :dsub])
+    counts.copy_(total[..., dsub].round().to(counts.dtype))
+    return sums, counts
 
 
 def _reseed_empty(C: torch.Tensor, counts: torch.Tensor):
@@ -89,7 +103,7 @@ def train_pq(x: torch.Tensor, M: int, n_iter: int, centroids: Optional[torch.Ten
     for it in range(n_iter):
         codes = ops.assign_nearest(x, C, torch.uint8)
         sums, counts = ops.kmeans_stats(x, codes)
-        _allreduce_stats(sums, counts)
+        gather_stats_(sums, counts)
         ops.kmeans_update_(sums, counts, C)
         _reseed_empty(C, counts)
     codes = ops.assign_nearest(x, C, torch.uint8)

@@ -75,3 +75,40 @@ def test_single_row_global_batch_is_all_zero_codes():
     codes, _ = assign_sinkhorn_sharded(torch.from_numpy(x[:1]), torch.from_numpy(C), EPS, ITERS, SingleComm(),
                                        stages=NumpyStages())
     assert np.array_equal(codes.numpy(), want)
+
+
+def _stats_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pq_oracle
+    from repconc_amd.train.run_warmup import gather_stats_
+    _, x, C = load_case(CASE)
+    n = x.shape[0] // world
+    xs = x[rank * n:(rank + 1) * n]
+    codes = pq_oracle.quantize(xs, C, False)
+    sums, counts = pq_oracle.kmeans_stats(xs, codes, C.shape[0])
+    s, c = torch.from_numpy(sums.astype(np.float64)), torch.from_numpy(counts.astype(np.int64))
+    gather_stats_(s, c)
+    ret[rank] = (s.numpy().copy(), c.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_gloo_kmeans_statistics_all_gather_is_rank_identical():
+    """Index-build sharding: per-shard Lloyd statistics -> one all-gather -> rank-ordered sum.  Both ranks
+    must hold bit-identical totals, equal to the unsharded statistics (counts exactly, sums to fp64 rounding)."""
+    from oracle import pq_oracle
+    _, x, C = load_case(CASE)
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_stats_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        (s0, c0), (s1, c1) = ret[0], ret[1]
+    assert np.array_equal(s0.view(np.uint64), s1.view(np.uint64)) and np.array_equal(c0, c1)
+    n = x.shape[0] // world * world
+    codes = pq_oracle.quantize(x[:n], C, False)
+    sums, counts = pq_oracle.kmeans_stats(x[:n], codes, C.shape[0])
+    assert np.array_equal(c0, counts)
+    np.testing.assert_allclose(s0, sums, rtol=1e-12, atol=1e-12)
