@@ -62,8 +62,9 @@ def gather_stats_(sums: torch.Tensor, counts: torch.Tensor, group=None):
     G = dist.get_world_size(group)
     M, K, dsub = sums.shape
     packed = torch.cat([sums, counts.to(sums.dtype).unsqueeze(-1)], dim=-1).contiguous()     # counts < 2^53: exact
-    gathered = torch.empty((G,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(gathered, packed, group=group)
+    flat = torch.empty((G * M, K, dsub + 1), dtype=packed.dtype, device=packed.device)    # concatenation form (gloo + nccl)
+    dist.all_gather_into_tensor(flat, packed, group=group)
+    gathered = flat.view(G, M, K, dsub + 1)
     total = gathered[0].clone()
     for r in range(1, G):
         total += gathered[r]
