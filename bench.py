@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=B_GLOBAL, help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="development: run the N>1 code path (RCCL collectives, staged sweeps) with one rank")
+    ap.add_argument("--dist-driver", choices=("auto", "staged"), default="auto",
+                    help="N>1: auto = native RCCL loop if it passes the self-check, staged = torch.distributed loop")
     return ap.parse_args()
 
 
@@ -131,6 +133,44 @@ def main():
             return ops.assign_sinkhorn(x, C, EPS, ITERS, torch.uint8)
         return assign_sinkhorn_sharded(x, C, EPS, ITERS, comm, dtype=torch.uint8)
 
+    # ------------------------------------------------------------------ multi-rank self-check (untimed)
+    # On a small global batch: (1) the native RCCL solve (csrc/comm.hip) against the Python-staged torch.distributed
+    # solve, (2) the gathered sharded codes against the unsharded single-GPU solve of the same batch on rank 0.  If the
+    # native driver errors or disagrees on any rank, every rank switches to the staged driver and the line says so.
+    dist_check = None
+    if use_dist:
+        gb = 1024 * world
+        xs_full = np.random.default_rng(20230).standard_normal((gb, D), dtype=np.float32)
+        xs_loc = torch.from_numpy(xs_full[rank * 1024:(rank + 1) * 1024]).to(dev)
+        os.environ["RC_DIST_NATIVE"] = "0"
+        c_staged, _ = assign_sinkhorn_sharded(xs_loc, C, EPS, ITERS, comm, dtype=torch.uint8)
+        native_ok, why = 1, ""
+        if args.dist_driver != "staged":
+            os.environ["RC_DIST_NATIVE"] = "1"
+            try:
+                c_native, _ = assign_sinkhorn_sharded(xs_loc, C, EPS, ITERS, comm, dtype=torch.uint8)
+                torch.cuda.synchronize()
+                if not torch.equal(c_native, c_staged):
+                    native_ok, why = 0, "codes differ from the staged driver"
+            except Exception as e:                           # rc_comm_init / RCCL failure: reported, not hidden
+                native_ok, why = 0, f"{type(e).__name__}: {e}"
+        else:
+            native_ok, why = 0, "--dist-driver staged"
+        t = torch.tensor([native_ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        native_all = bool(int(t.item()))
+        os.environ["RC_DIST_NATIVE"] = "1" if native_all else "0"
+        gathered = [torch.empty_like(c_staged) for _ in range(world)]
+        dist.all_gather(gathered, c_staged)
+        unsharded_equal = None
+        if rank == 0:
+            ref_codes, _ = ops.assign_sinkhorn(torch.from_numpy(xs_full).to(dev), C, EPS, ITERS, torch.uint8)
+            unsharded_equal = bool(torch.equal(torch.cat(gathered, 0), ref_codes))
+        dist_check = {"global_batch": gb, "driver": "native RCCL loop (csrc/comm.hip)" if native_all else
+                      "python-staged torch.distributed loop", "native_equals_staged": bool(native_ok) if args.dist_driver != "staged" else None,
+                      "native_note": why or None, "sharded_equals_unsharded": unsharded_equal}
+        del xs_loc, c_staged, gathered
+
     for i in range(args.warmup):
         codes, flags = step(i)
     barrier()
@@ -180,6 +220,8 @@ def main():
         "max_code_imbalance": round(imb, 4),
         "roofline": roofline,
     }
+    if dist_check is not None:
+        out["multi_gpu_check"] = dist_check
 
     # ------------------------------------------------------------------ ADC search leg
     if not args.no_adc:
