@@ -415,6 +415,124 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_kernel(const uint8_t* 
     }
 }
 
+// The same screen with the byte accumulation on the matrix cores (M % 8 == 0; 8 queries per group, 4 when M > 64).
+// PMC on adc_screen_kernel<48,8>: 9.3e9 VALU instructions per 1200-query launch = 95 % of the kernel's VALU cycles,
+// the LDS gathers active 12 of its 18 ms — the v_perm/v_add accumulation is the limiter.  Here a wave takes 32 rows;
+// lanes l and l+32 share row (l & 31) and gather the two halves of its M codes.  Two gathered 8-byte entries (two
+// sub-quantisers x 8 queries) ARE the 16-byte A operand of v_mfma_i32_32x32x32_i8 in lane-natural layout
+// (A[row][t], t = 8 g + query); B is the constant selection matrix B[t][j] = [t % 8 == j], so
+//     D[row][j] += sum_{g, half} entry_{g,half}[j]      — one MFMA folds 4 sub-quantisers of 32 rows x 8 queries
+// (QS = 4: four 4-byte entries per lane, 8 sub-quantisers x 4 queries).
+// The pairing of A and B bytes is by (half-wave, byte position), so it does not depend on how the hardware numbers k.
+// VALU per gather drops from ~10 instructions to the address computation; results arrive as D: lane j (< 8) of each
+// half-wave holds query j's sums for 16 rows (row = (r&3) + 8 (r>>2) + 4 (lane>>5)).  The MFMA is signed: bytes are
+// staged as l - 128 and the integer threshold is lowered by 128 M.
+typedef int adc_i32x4 __attribute__((ext_vector_type(4)));
+typedef int adc_i32x16 __attribute__((ext_vector_type(16)));
+
+template <int M, int QS>
+__global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma_kernel(const uint8_t* __restrict__ codes, int64_t N,
+                                                                      const uint8_t* __restrict__ qlut,
+                                                                      const int* __restrict__ tint, int nq,
+                                                                      unsigned* __restrict__ id_count,
+                                                                      unsigned* __restrict__ ids) {
+    constexpr int HM = M / 2, NW = HM / 4;                  // codes per half-wave, dwords of codes per lane
+    constexpr int G = 16 / QS;                              // gathered entries per A operand (QS bytes each)
+    static_assert((QS == 8 || QS == 4) && HM % G == 0 && HM % 4 == 0, "unsupported (M, QS)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * QS;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(qlut + (size_t)blockIdx.x * M * RC_K * QS);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < M * RC_K * QS / 16; i += ADC_THREADS) {
+            uint4 v = src[i];
+            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;   // l -> l - 128 (signed)
+            dst[i] = v;
+        }
+    }
+    const int l = tid & 63, wv = tid >> 6;
+    const int d = l & 31, hh = l >> 5;
+    int tq = INT_MAX;                                        // this lane's query (as the D column j = d)
+    if (d < QS && q0 + d < nq) {
+        const int t = tint[q0 + d];
+        tq = (t == INT_MIN) ? INT_MIN : t - 128 * M;
+    }
+    adc_i32x4 bsel = {0, 0, 0, 0};                           // B[t][j = d] = [t % QS == d]
+    if (d < QS) {
+        const int one = 1 << (8 * (d & 3));
+        if constexpr (QS == 8) {
+            bsel[d >> 2] = one;
+            bsel[2 + (d >> 2)] = one;
+        } else {
+            bsel[0] = bsel[1] = bsel[2] = bsel[3] = one;
+        }
+    }
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.y * ADC_TILE_DOCS;
+    const int64_t t1 = (t0 + ADC_TILE_DOCS < N) ? t0 + ADC_TILE_DOCS : N;
+    constexpr int NWAVES = ADC_THREADS / 64;
+    const unsigned char* tabh = smem + (size_t)hh * HM * RC_K * QS;      // this half-wave's sub-quantisers
+    auto load_row = [&](int64_t n, unsigned (&dst)[NW]) {
+        const uint8_t* cp = codes + (n < t1 ? n : (t1 - 1)) * M + hh * HM;
+        if constexpr (HM % 16 == 0) {
+#pragma unroll
+            for (int j = 0; j < HM / 16; ++j) {
+                const uint4 v = reinterpret_cast<const uint4*>(cp)[j];
+                dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w;
+            }
+        } else if constexpr (HM % 8 == 0) {
+#pragma unroll
+            for (int j = 0; j < HM / 8; ++j) {
+                const uint2 v = reinterpret_cast<const uint2*>(cp)[j];
+                dst[2 * j] = v.x; dst[2 * j + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) dst[j] = reinterpret_cast<const unsigned*>(cp)[j];
+        }
+    };
+    unsigned w[NW], wn[NW];
+    load_row(t0 + wv * 32 + d, w);
+    for (int64_t i0 = t0 + wv * 32; i0 < t1; i0 += NWAVES * 32) {   // wave-uniform
+        load_row(i0 + NWAVES * 32 + d, wn);
+        adc_i32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < HM / G; ++n) {
+            adc_i32x4 a;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int mm = G * n + g;
+                const unsigned c = (w[mm >> 2] >> (8 * (mm & 3))) & 0xFFu;
+                const unsigned char* e = tabh + ((size_t)mm * RC_K + c) * QS;
+                if constexpr (QS == 8) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(e);
+                    a[2 * g] = (int)v.x;
+                    a[2 * g + 1] = (int)v.y;
+                } else {
+                    a[g] = (int)*reinterpret_cast<const unsigned*>(e);
+                }
+            }
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bsel, acc, 0, 0, 0);
+        }
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) any |= (acc[r] >= tq);
+        if (__ballot(any)) {                                  // rare: ~2e-4 of the (row, query) pairs pass
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t n = i0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (acc[r] >= tq && n < t1) {
+                    const unsigned slot = atomicAdd(id_count + q0 + d, 1u);
+                    if (slot < ADC_ID_CAP) ids[(size_t)(q0 + d) * ADC_ID_CAP + slot] = (unsigned)n;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) w[j] = wn[j];
+    }
+}
+
 // One block per query: exact fp32 score (m ascending, from 0) of every screened row; rows with score >= tau go
 // to the key list exactly as adc_scan_kernel<FILTER> would have put them.
 template <int M>
@@ -538,14 +656,34 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
     RC_HIP_CHECK(h, hipMemsetAsync(b.idcnt, 0, (size_t)nq * sizeof(unsigned), s));
     hipLaunchKernelGGL(adc_qlut_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, QS, b.qlut, b.tint);
     RC_LAUNCH_CHECK(h);
-    auto kscreen = adc_screen_kernel<M, QS>;
     const size_t sl = (size_t)M * RC_K * QS;
-    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kscreen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
-    rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-    hipLaunchKernelGGL(kscreen, dim3((unsigned)((nq + QS - 1) / QS), tiles), dim3(ADC_THREADS), sl, s, codes, N, b.qlut,
-                       b.tint, nq, b.idcnt, b.ids);
-    rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-    RC_LAUNCH_CHECK(h);
+    const dim3 sgrid((unsigned)((nq + QS - 1) / QS), tiles);
+    if constexpr (M % 8 == 0) {
+        static const bool valu_screen = getenv("RC_ADC_VALU_SCREEN") != nullptr;     // A/B switch for measurements
+        if (!valu_screen) {
+            auto kmf = adc_screen_mfma_kernel<M, QS>;
+            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
+            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+            hipLaunchKernelGGL(kmf, sgrid, dim3(ADC_THREADS), sl, s, codes, N, b.qlut, b.tint, nq, b.idcnt, b.ids);
+            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+            RC_LAUNCH_CHECK(h);
+        }
+        if (valu_screen) {
+            auto kscreen = adc_screen_kernel<M, QS>;
+            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kscreen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
+            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+            hipLaunchKernelGGL(kscreen, sgrid, dim3(ADC_THREADS), sl, s, codes, N, b.qlut, b.tint, nq, b.idcnt, b.ids);
+            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+            RC_LAUNCH_CHECK(h);
+        }
+    } else {
+        auto kscreen = adc_screen_kernel<M, QS>;
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kscreen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
+        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+        hipLaunchKernelGGL(kscreen, sgrid, dim3(ADC_THREADS), sl, s, codes, N, b.qlut, b.tint, nq, b.idcnt, b.ids);
+        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+        RC_LAUNCH_CHECK(h);
+    }
     auto krescore = adc_rescore_kernel<M>;
     const size_t rl = (size_t)M * RC_K * sizeof(float);
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
