@@ -258,13 +258,13 @@ def main():
             "index": f"{N_CORPUS} x {M} B uint8 uniform codes, resident", "query_batch": nq_batch,
             "batches": args.adc_batches, "ms_per_batch": round(adt / args.adc_batches * 1e3, 2),
             "parallelism": f"index replicated, queries split x{world}",
-            "roofline": {"kernel": "adc_screen_kernel<48,8> (8-bit screening scan)", "bound": "hbm", "achieved": round(adc_ach, 1),
+            "roofline": {"kernel": "adc_screen_mfma_kernel<48,8> (8-bit screening scan, i8 MFMA accumulation)", "bound": "hbm", "achieved": round(adc_ach, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(adc_ach / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("adc_screen_kernel"), "algorithmic_bytes_per_launch": adc_alg,
+                         "traffic": pmc_traffic("adc_screen_mfma_kernel"), "algorithmic_bytes_per_launch": adc_alg,
                          "avg_launch_ms": round(scan_ms, 3), "launches_timed": n_l.value,
                          "note": "algorithmic bytes = N*M code bytes per query (SURVEY 8d); 8 queries share every code "
-                                 "read and tiles are re-read from L2, so frac > 1 — the physical limits are the LDS "
-                                 "gather rate and the VALU byte accumulation (DESIGN.md §4)"},
+                                 "read and tiles are re-read from L2, so frac > 1 — the physical limit is the LDS "
+                                 "gather rate (random 8-byte reads, 67 % bank-conflict cycles; DESIGN.md §4)"},
         }
 
     # ------------------------------------------------------------------ index-build leg (nearest codes, a-1/a-5)

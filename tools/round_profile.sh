@@ -4,7 +4,7 @@ TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 O=$ROOT/gpurun_out/$TAG; mkdir -p $O
 cd $ROOT
-python -m pytest tests -q -m gpu 2>&1 | tail -15 > $O/${TAG}_pytest_gpu.txt
+python -m pytest tests -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -15 > $O/${TAG}_pytest_gpu.txt
 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 export TMPDIR=/tmp
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- python $ROOT/bench.py --steps 3 --no-cpu > $O/bench_prof.out 2>&1)
