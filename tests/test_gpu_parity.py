@@ -761,6 +761,24 @@ def test_mfma_screened_assignment_ties_and_near_ties():
     assert st["doubtful"] >= 512 * M            # the duplicate and one-ulp rows for certain
 
 
+def test_mfma_screened_assignment_non_finite_rows():
+    """NaN / Inf / overflow-scale rows: the margin is non-finite, so the pair is doubtful and the exact judge decides
+    exactly like the exact kernel (code 0 when every distance is NaN or +inf)."""
+    from repconc_amd import ops
+    rng = np.random.default_rng(78)
+    M, B = 48, 512
+    C = rng.standard_normal((M, 256, 16)).astype(np.float32)
+    x = rng.standard_normal((B, 768)).astype(np.float32)
+    x[3, 100] = np.nan
+    x[7, :] = np.inf
+    x[11, 5] = -np.inf
+    x[13, :] = 1e30                      # squares overflow fp32
+    x[17, :] = 3e19                      # ||x||^2 overflows only in the sum
+    fast = ops.assign_nearest(_t(x), _t(C), torch.uint8, method="mfma")
+    exact = ops.assign_nearest(_t(x), _t(C), torch.uint8, method="exact")
+    assert torch.equal(fast, exact)
+
+
 def test_mfma_assignment_overflow_falls_back_and_unaligned_rows():
     """All centroids identical: every pair is doubtful, the list overflows and assign_nearest("auto") must fall back
     to the exact kernel (codes all 0).  Unaligned rows: ops realigns, the raw C call refuses."""
