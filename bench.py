@@ -146,6 +146,26 @@ def main():
         c_staged, _ = assign_sinkhorn_sharded(xs_loc, C, EPS, ITERS, comm, dtype=torch.uint8)
         native_ok, why = 1, ""
         if args.dist_driver != "staged":
+            # first in a child process with a timeout: a hang or crash in the RCCL communicator set-up stays there
+            import subprocess
+            env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 17))
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # the child makes its own TCP store on the new port
+            child = subprocess.Popen([sys.executable, "-m", "repconc_amd.dist_probe"], cwd=ROOT, env=env,
+                                     stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            try:
+                prc = child.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                child.kill()
+                child.wait()
+                prc = -9
+            if prc != 0:
+                native_ok, why = 0, f"out-of-process probe failed (exit {prc})"
+        if args.dist_driver != "staged":
+            t = torch.tensor([native_ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)          # every rank must have passed the probe
+            if native_ok and not int(t.item()):
+                native_ok, why = 0, "out-of-process probe failed on another rank"
+        if args.dist_driver != "staged" and native_ok:
             os.environ["RC_DIST_NATIVE"] = "1"
             try:
                 c_native, _ = assign_sinkhorn_sharded(xs_loc, C, EPS, ITERS, comm, dtype=torch.uint8)
@@ -154,7 +174,7 @@ def main():
                     native_ok, why = 0, "codes differ from the staged driver"
             except Exception as e:                           # rc_comm_init / RCCL failure: reported, not hidden
                 native_ok, why = 0, f"{type(e).__name__}: {e}"
-        else:
+        if args.dist_driver == "staged":
             native_ok, why = 0, "--dist-driver staged"
         t = torch.tensor([native_ok], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -189,7 +209,10 @@ def main():
     value = args.steps * B / dt
     sweep_ms = ms_l.value / max(n_l.value, 1)
     # with N > 1 ranks the sub-quantisers run as two chains: one launch covers M/2 of them
-    n_chains = lib.rc_solve_num_chains(world, M) if os.environ.get("RC_DIST_NATIVE", "1") != "0" or not use_dist else 1
+    if not use_dist or os.environ.get("RC_DIST_NATIVE", "1") != "0":
+        n_chains = lib.rc_solve_num_chains(world, M)
+    else:                                                   # staged driver: two halves when world > 1 (sharded.py)
+        n_chains = 2 if (world > 1 and M >= 2 and os.environ.get("RC_SHARD_SPLIT", "1") != "0") else 1
     alg_bytes = bl * (M // n_chains) * K * 4
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if n_l.value else 0.0
     roofline = {"kernel": "sk_sweep_kernel<false> (Sinkhorn sweep incl. fused row/column updates)", "bound": "hbm", "achieved": round(achieved, 1),

@@ -1,0 +1,47 @@
+"""Out-of-process probe of the native multi-rank solve (csrc/comm.hip over RCCL).
+
+`python -m repconc_amd.dist_probe` is started by every rank of a job (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
+MASTER_PORT from the environment, its own rendezvous port), runs the native constrained assignment and the
+torch.distributed-staged one on a small batch and exits 0 iff they agree.  A caller that cannot afford a hang in an
+untested communicator set-up (bench.py on a node it has never seen) runs it with a timeout and falls back to the
+staged driver when it fails — the failure stays inside the child process.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+
+def main() -> int:
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from .sharded import TorchDistComm, assign_sinkhorn_sharded
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29550")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    rng = np.random.default_rng(4242)
+    M, K, D, rows = 48, 256, 768, 512
+    x = rng.standard_normal((rows * world, D), dtype=np.float32)
+    C = torch.from_numpy(np.ascontiguousarray(x[:K].reshape(K, M, D // M).transpose(1, 0, 2))).to(dev)
+    xl = torch.from_numpy(x[rank * rows:(rank + 1) * rows]).to(dev)
+    comm = TorchDistComm()
+    os.environ["RC_DIST_NATIVE"] = "0"
+    staged, _ = assign_sinkhorn_sharded(xl, C, 0.003, 100, comm, dtype=torch.uint8)
+    os.environ["RC_DIST_NATIVE"] = "1"
+    native, _ = assign_sinkhorn_sharded(xl, C, 0.003, 100, comm, dtype=torch.uint8)
+    torch.cuda.synchronize()
+    ok = torch.tensor([int(torch.equal(staged, native))], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    dist.destroy_process_group()
+    return 0 if int(ok.item()) == 1 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -30,6 +30,9 @@ for key, (kname, alg) in ALG.items():
     if "SQ_INSTS_VALU" in sq and "GRBM_GUI_ACTIVE" in sq:
         # GRBM_GUI_ACTIVE sums the 8 XCDs; a wave64 VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs
         e["valu_busy_frac"] = round(sq["SQ_INSTS_VALU"] * 4 / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
+    if sq.get("SQ_VALU_MFMA_BUSY_CYCLES") and "GRBM_GUI_ACTIVE" in sq:
+        # SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe cycles summed over the SIMDs (32 per 32x32x16 bf16 / 32x32x32 i8 MFMA)
+        e["mfma_busy_frac"] = round(sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
     out[key] = e
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print({k: (v.get("hbm_bytes_per_launch"), v.get("valu_busy_frac")) for k, v in out.items() if k != "_how"})
