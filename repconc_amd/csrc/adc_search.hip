@@ -61,6 +61,32 @@ __global__ __launch_bounds__(RC_K) void adc_lut_kernel(const float* __restrict__
     lut[((size_t)qi * M + m) * RC_K + k] = s;
 }
 
+// Same arithmetic, supported dsub: thread k keeps its centroid row in registers and walks a chunk of queries (the
+// query slice is block-uniform -> scalar loads), so the 16 KiB centroid table is read once per 32 queries instead of
+// once per query (0.40 ms -> per 1200 queries at M = 48 for the kernel above).
+#define ADC_LUT_QCHUNK 32
+template <int DSUB>
+__global__ __launch_bounds__(RC_K) void adc_lut_rows_kernel(const float* __restrict__ C, const float* __restrict__ q,
+                                                            int nq, int D, int M, float* __restrict__ lut) {
+    const int m = blockIdx.y, k = threadIdx.x;
+    float c[DSUB];
+    const float4* cp = reinterpret_cast<const float4*>(C + ((size_t)m * RC_K + k) * DSUB);
+#pragma unroll
+    for (int j = 0; j < DSUB / 4; ++j) {
+        const float4 v = cp[j];
+        c[4 * j] = v.x; c[4 * j + 1] = v.y; c[4 * j + 2] = v.z; c[4 * j + 3] = v.w;
+    }
+    const int q0 = blockIdx.x * ADC_LUT_QCHUNK;
+    const int q1 = (q0 + ADC_LUT_QCHUNK < nq) ? q0 + ADC_LUT_QCHUNK : nq;
+    for (int qi = q0; qi < q1; ++qi) {
+        const float* qs = q + (size_t)qi * D + m * DSUB;   // block-uniform
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < DSUB; ++j) s = s + qs[j] * c[j];
+        lut[((size_t)qi * M + m) * RC_K + k] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ 2/4. scan
 template <int QT> struct adc_vec;
 template <> struct adc_vec<1> { using type = float; };
@@ -701,8 +727,19 @@ extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq,
     if (!h || !C || !q || !lut || nq < 0 || M <= 0 || D <= 0) return RC_EINVAL;
     if (K != RC_K || D % M != 0) return RC_ESHAPE;
     if (nq == 0) return RC_OK;
-    hipLaunchKernelGGL(adc_lut_kernel, dim3((unsigned)nq, (unsigned)M), dim3(RC_K), 0, (hipStream_t)stream, C, q, D, M,
-                       lut);
+    const dim3 cg((unsigned)((nq + ADC_LUT_QCHUNK - 1) / ADC_LUT_QCHUNK), (unsigned)M);
+    switch (D / M) {
+#define ADC_LUT_CASE(DS)                                                                                              \
+        case DS:                                                                                                      \
+            hipLaunchKernelGGL(adc_lut_rows_kernel<DS>, cg, dim3(RC_K), 0, (hipStream_t)stream, C, q, nq, D, M, lut); \
+            break;
+        ADC_LUT_CASE(8) ADC_LUT_CASE(12) ADC_LUT_CASE(16) ADC_LUT_CASE(24) ADC_LUT_CASE(32) ADC_LUT_CASE(48)
+        ADC_LUT_CASE(64) ADC_LUT_CASE(96)
+#undef ADC_LUT_CASE
+        default:
+            hipLaunchKernelGGL(adc_lut_kernel, dim3((unsigned)nq, (unsigned)M), dim3(RC_K), 0, (hipStream_t)stream, C, q, D,
+                               M, lut);
+    }
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
