@@ -38,6 +38,7 @@ extern "C" {
 #define RC_EHIP (-3)       /* a HIP runtime call failed (see rc_last_hip_error)        */
 #define RC_EWORKSPACE (-4) /* workspace smaller than the matching *_ws_bytes()         */
 #define RC_ECOMM (-5)      /* RCCL unavailable or a collective call failed             */
+#define RC_ESELECT (-6)    /* ADC candidate selection did not converge (thousands of identical codes) */
 
 #define RC_CODE_U8 0
 #define RC_CODE_I64 1
@@ -49,6 +50,7 @@ extern "C" {
 
 typedef struct rc_handle_s* rc_handle_t;
 typedef void* rc_stream_t;
+typedef struct rc_index_s* rc_index_t;   /* stateful PQ index, see rc_index_* below */
 
 int rc_version(void);
 const char* rc_error_string(int code);
@@ -215,6 +217,26 @@ int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, 
 /* the look-up tables alone (test hook): lut [nq,M,K] fp32 */
 int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K,
                float* lut, rc_stream_t stream);
+
+/* ------------------------------------------------------------------ a-9 … a-11, stateful form
+ * The index object the reference keeps inside Faiss (initialize_index / add_docs / index.search,
+ * models/repconc/evaluate_repconc.py:78-98,182; JPQ's per-step synchronize_model_index, models/jpq/finetune_jpq.py:209-214),
+ * with the device memory owned by the library: codes [ntotal, M] uint8 in one allocation whose capacity doubles,
+ * the centroid table [M,256,D/M] (set_centroids rewrites it in place: 786 KB per JPQ step instead of re-cloning the
+ * index), and the search workspace.  All pointers are device pointers.  rc_index_search is synchronous: it loops over
+ * rc_adc_search until the status word is clean (RC_ESELECT after 4 attempts).  Empty index: -inf scores, -1 ids.
+ * One index per handle/device; not thread-safe. */
+int rc_index_create(rc_handle_t h, int D, int M, int K, rc_index_t* out);
+int rc_index_destroy(rc_index_t idx);
+int rc_index_set_centroids(rc_index_t idx, const float* C, rc_stream_t stream);
+int rc_index_reserve(rc_index_t idx, int64_t rows, rc_stream_t stream);
+int rc_index_add_codes(rc_index_t idx, const uint8_t* codes, int64_t n, rc_stream_t stream);
+int rc_index_reset(rc_index_t idx);
+int64_t rc_index_ntotal(rc_index_t idx);
+const uint8_t* rc_index_codes(rc_index_t idx);
+const float* rc_index_centroids(rc_index_t idx);
+int rc_index_search(rc_index_t idx, const float* q, int nq, int k, float* scores, int64_t* ids,
+                    rc_stream_t stream);
 
 /* ------------------------------------------------------------------ IVF extension (SURVEY §8d input D)
  * The reference only ever builds a 1-list IVFPQ (evaluate_repconc.py:101-118); BASELINE.json's nlist=5000 config is a

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REPCONC_HIP_LIB") or os.path.join(_HERE, "lib", "librepconc_hip.so")   # env: A/B builds
 
-RC_OK, RC_EINVAL, RC_ESHAPE, RC_EHIP, RC_EWORKSPACE, RC_ECOMM = 0, -1, -2, -3, -4, -5
+RC_OK, RC_EINVAL, RC_ESHAPE, RC_EHIP, RC_EWORKSPACE, RC_ECOMM, RC_ESELECT = 0, -1, -2, -3, -4, -5, -6
 RC_CODE_U8, RC_CODE_I64 = 0, 1
 RC_FLAG_NONFINITE = 1
 PROF_SK_PASS, PROF_ADC_SCAN, PROF_ASSIGN_NEAREST, PROF_DIST_TABLE = 0, 1, 2, 3
@@ -59,6 +59,16 @@ PROTOTYPES = {
     "rc_ivf_search_ws_bytes": (_sz, [_i, _i64]),
     "rc_ivf_search": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_adc_lut": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rc_index_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
+    "rc_index_destroy": (_i, [_vp]),
+    "rc_index_set_centroids": (_i, [_vp, _vp, _vp]),
+    "rc_index_reserve": (_i, [_vp, _i64, _vp]),
+    "rc_index_add_codes": (_i, [_vp, _vp, _i64, _vp]),
+    "rc_index_reset": (_i, [_vp]),
+    "rc_index_ntotal": (_i64, [_vp]),
+    "rc_index_codes": (_vp, [_vp]),
+    "rc_index_centroids": (_vp, [_vp]),
+    "rc_index_search": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,156 @@
+// Stateful PQ index behind the C ABI (SURVEY.md §8b proposal: rc_index_create / set_centroids / add_codes / search).
+//
+// Replaces what the reference keeps inside Faiss objects: `initialize_index` + `add_docs`
+// (models/repconc/evaluate_repconc.py:78-98: IndexPQ(D, M, 8, IP), centroids <- C.ravel(), codes appended raw) and
+// `index.search` (:182, models/jpq/finetune_jpq.py:176).  The library owns the device memory: codes [ntotal, M] uint8
+// in one growing allocation (capacity doubles, so appending the corpus chunk by chunk is amortised O(N) — the reference's
+// add_docs round-trips the whole code vector through numpy on every call), the [M,256,dsub] centroid table (rewritten in
+// place by rc_index_set_centroids: the JPQ per-step `synchronize_model_index`, finetune_jpq.py:209-214, is a 786 KB
+// copy), and the search workspace.  rc_index_search is the host loop around rc_adc_search: it reads the status word
+// and retries with another selection slack exactly like repconc_amd.ops.adc_search.  Python uses torch-owned tensors
+// (repconc_amd/index.py) over the stateless entry points; this file is for hosts without torch.
+#include "rc_common.h"
+
+struct rc_index_s {
+    rc_handle_t h;
+    int D, M, K;
+    float* C;            // [M, K, D/M]
+    uint8_t* codes;      // [cap, M]
+    int64_t n, cap;
+    void* ws;
+    size_t ws_bytes;
+    int* status;         // device word
+    bool have_centroids;
+};
+
+#define RC_IDX_HIP(idx, call)                                                  \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) { (idx)->h->last_hip_error = (int)e_; return RC_EHIP; } \
+    } while (0)
+
+extern "C" int rc_index_create(rc_handle_t h, int D, int M, int K, rc_index_t* out) {
+    if (!h || !out || D <= 0 || M <= 0) return RC_EINVAL;
+    if (K != RC_K || D % M != 0) return RC_ESHAPE;
+    rc_index_s* idx = new (std::nothrow) rc_index_s();
+    if (!idx) return RC_EINVAL;
+    idx->h = h; idx->D = D; idx->M = M; idx->K = K;
+    idx->C = nullptr; idx->codes = nullptr; idx->n = 0; idx->cap = 0; idx->ws = nullptr; idx->ws_bytes = 0;
+    idx->status = nullptr; idx->have_centroids = false;
+    hipError_t e = hipMalloc((void**)&idx->C, (size_t)M * K * (D / M) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&idx->status, 256);
+    if (e != hipSuccess) {
+        h->last_hip_error = (int)e;
+        if (idx->C) (void)hipFree(idx->C);
+        delete idx;
+        return RC_EHIP;
+    }
+    *out = idx;
+    return RC_OK;
+}
+
+extern "C" int rc_index_destroy(rc_index_t idx) {
+    if (!idx) return RC_EINVAL;
+    if (idx->C) (void)hipFree(idx->C);
+    if (idx->codes) (void)hipFree(idx->codes);
+    if (idx->ws) (void)hipFree(idx->ws);
+    if (idx->status) (void)hipFree(idx->status);
+    delete idx;
+    return RC_OK;
+}
+
+extern "C" int64_t rc_index_ntotal(rc_index_t idx) { return idx ? idx->n : -1; }
+extern "C" const uint8_t* rc_index_codes(rc_index_t idx) { return idx ? idx->codes : nullptr; }
+extern "C" const float* rc_index_centroids(rc_index_t idx) { return (idx && idx->have_centroids) ? idx->C : nullptr; }
+
+extern "C" int rc_index_set_centroids(rc_index_t idx, const float* C, rc_stream_t stream) {
+    if (!idx || !C) return RC_EINVAL;
+    RC_IDX_HIP(idx, hipMemcpyAsync(idx->C, C, (size_t)idx->M * idx->K * (idx->D / idx->M) * sizeof(float),
+                                   hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    idx->have_centroids = true;
+    return RC_OK;
+}
+
+extern "C" int rc_index_reserve(rc_index_t idx, int64_t rows, rc_stream_t stream) {
+    if (!idx || rows < 0) return RC_EINVAL;
+    if (rows <= idx->cap) return RC_OK;
+    if (rows > 0xFFFFFFFFll) return RC_ESHAPE;
+    uint8_t* fresh = nullptr;
+    RC_IDX_HIP(idx, hipMalloc((void**)&fresh, (size_t)rows * idx->M));
+    hipStream_t s = (hipStream_t)stream;
+    if (idx->n > 0) {
+        hipError_t e = hipMemcpyAsync(fresh, idx->codes, (size_t)idx->n * idx->M, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);            // the old block is freed right below
+        if (e != hipSuccess) { (void)hipFree(fresh); idx->h->last_hip_error = (int)e; return RC_EHIP; }
+    }
+    if (idx->codes) (void)hipFree(idx->codes);
+    idx->codes = fresh;
+    idx->cap = rows;
+    return RC_OK;
+}
+
+extern "C" int rc_index_add_codes(rc_index_t idx, const uint8_t* codes, int64_t n, rc_stream_t stream) {
+    if (!idx || n < 0 || (n > 0 && !codes)) return RC_EINVAL;
+    if (n == 0) return RC_OK;
+    if (idx->n + n > idx->cap) {
+        int64_t want = idx->cap * 2;
+        if (want < idx->n + n) want = idx->n + n;
+        if (want > 0xFFFFFFFFll) want = 0xFFFFFFFFll;
+        if (want < idx->n + n) return RC_ESHAPE;
+        const int rc = rc_index_reserve(idx, want, stream);
+        if (rc != RC_OK) return rc;
+    }
+    RC_IDX_HIP(idx, hipMemcpyAsync(idx->codes + (size_t)idx->n * idx->M, codes, (size_t)n * idx->M,
+                                   hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    idx->n += n;
+    return RC_OK;
+}
+
+extern "C" int rc_index_reset(rc_index_t idx) {
+    if (!idx) return RC_EINVAL;
+    idx->n = 0;
+    return RC_OK;
+}
+
+// Synchronous (reads the status word between attempts).  scores [nq,k], ids [nq,k] on the device.
+extern "C" int rc_index_search(rc_index_t idx, const float* q, int nq, int k, float* scores, int64_t* ids,
+                               rc_stream_t stream) {
+    if (!idx || nq < 0 || k <= 0 || (nq > 0 && (!q || !scores || !ids))) return RC_EINVAL;
+    if (!idx->have_centroids) return RC_EINVAL;
+    if (nq == 0) return RC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (idx->n == 0) {                                   // Faiss semantics: -inf scores, -1 labels
+        const size_t cnt = (size_t)nq * k;
+        float* hs = (float*)malloc(cnt * sizeof(float));
+        int64_t* hi = (int64_t*)malloc(cnt * sizeof(int64_t));
+        if (!hs || !hi) { free(hs); free(hi); return RC_EINVAL; }
+        for (size_t i = 0; i < cnt; ++i) { hs[i] = -INFINITY; hi[i] = -1; }
+        hipError_t e = hipMemcpyAsync(scores, hs, cnt * sizeof(float), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(ids, hi, cnt * sizeof(int64_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        free(hs); free(hi);
+        if (e != hipSuccess) { idx->h->last_hip_error = (int)e; return RC_EHIP; }
+        return RC_OK;
+    }
+    const size_t need = rc_adc_search_ws_bytes(idx->n, idx->M, idx->K, nq, k);
+    if (need == 0) return RC_ESHAPE;
+    if (need > idx->ws_bytes) {
+        if (idx->ws) (void)hipFree(idx->ws);
+        idx->ws = nullptr; idx->ws_bytes = 0;
+        RC_IDX_HIP(idx, hipMalloc(&idx->ws, need));
+        idx->ws_bytes = need;
+    }
+    double slack = 6.0;
+    int st = 0;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        RC_IDX_HIP(idx, hipMemsetAsync(idx->status, 0, sizeof(int), s));
+        const int rc = rc_adc_search(idx->h, idx->codes, idx->n, idx->M, idx->K, idx->C, idx->D, q, nq, k, 0, slack, scores,
+                                     ids, idx->status, idx->ws, idx->ws_bytes, stream);
+        if (rc != RC_OK) return rc;
+        RC_IDX_HIP(idx, hipMemcpyAsync(&st, idx->status, sizeof(int), hipMemcpyDeviceToHost, s));
+        RC_IDX_HIP(idx, hipStreamSynchronize(s));
+        if (st == 0) return RC_OK;
+        slack = (st & 1) ? slack * 3.0 + 2.0 : (slack / 3.0);     // too few candidates -> widen; overflow -> tighten
+    }
+    return RC_ESELECT;
+}

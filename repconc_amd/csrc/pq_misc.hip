@@ -17,6 +17,7 @@ extern "C" const char* rc_error_string(int code) {
         case RC_EHIP: return "HIP runtime error";
         case RC_EWORKSPACE: return "workspace too small";
         case RC_ECOMM: return "RCCL unavailable or collective failed";
+        case RC_ESELECT: return "ADC candidate selection did not converge";
         default: return "unknown error";
     }
 }

@@ -818,3 +818,40 @@ def test_adc_large_k_uses_exact_scan():
     ws, wi = c_oracle.adc_search(codes, C, q, k)
     assert np.array_equal(ids.cpu().numpy(), wi)
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+def test_c_index_handle_api_matches_oracle():
+    """The stateful C index (csrc/index.hip: create / set_centroids / add_codes in chunks / search / reset) driven with
+    raw pointers, as a host without torch tensors would: results equal the brute-force oracle bit for bit; growth keeps
+    earlier rows; an empty index answers -inf / -1; set_centroids takes effect in place (JPQ step)."""
+    import ctypes
+    from repconc_amd import _lib
+    lib, h = _lib.load(), _lib.handle(0)
+    M, N, nq, k = 48, 70000, 5, 50
+    C, codes, q = _adc_case(M, N, nq, seed=31337)
+    idx = ctypes.c_void_p()
+    assert lib.rc_index_create(h, 768, M, 256, ctypes.byref(idx)) == 0
+    try:
+        dq, dC, dcodes = _t(q), _t(C), _t(codes)
+        sc = torch.empty((nq, k), dtype=torch.float32, device=DEV)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=DEV)
+        assert lib.rc_index_search(idx, dq.data_ptr(), nq, k, sc.data_ptr(), ids.data_ptr(), None) == _lib.RC_EINVAL  # no centroids
+        assert lib.rc_index_set_centroids(idx, dC.data_ptr(), None) == 0
+        assert lib.rc_index_search(idx, dq.data_ptr(), nq, k, sc.data_ptr(), ids.data_ptr(), None) == 0
+        assert bool((ids == -1).all()) and bool(torch.isinf(sc).all())
+        for a, b in ((0, 1000), (1000, 1001), (1001, 40000), (40000, N)):          # forces several reallocations
+            assert lib.rc_index_add_codes(idx, dcodes[a:b].data_ptr(), b - a, None) == 0
+        assert lib.rc_index_ntotal(idx) == N
+        torch.cuda.synchronize()
+        assert lib.rc_index_search(idx, dq.data_ptr(), nq, k, sc.data_ptr(), ids.data_ptr(), None) == 0
+        ws, wi = c_oracle.adc_search(codes, C, q, k)
+        assert np.array_equal(ids.cpu().numpy(), wi)
+        assert np.array_equal(sc.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+        C2 = (C * np.float32(0.5) + np.float32(0.25)).astype(np.float32)
+        assert lib.rc_index_set_centroids(idx, _t(C2).data_ptr(), None) == 0
+        assert lib.rc_index_search(idx, dq.data_ptr(), nq, k, sc.data_ptr(), ids.data_ptr(), None) == 0
+        ws, wi = c_oracle.adc_search(codes, C2, q, k)
+        assert np.array_equal(ids.cpu().numpy(), wi)
+        assert lib.rc_index_reset(idx) == 0 and lib.rc_index_ntotal(idx) == 0
+    finally:
+        assert lib.rc_index_destroy(idx) == 0
