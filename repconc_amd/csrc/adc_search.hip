@@ -559,6 +559,118 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma_kernel(const uint
     }
 }
 
+// M = 96: the 8-query byte tables are 196 KiB, more than a CU's LDS, and 4-query tables cost two LDS gathers per
+// 8 queries.  Two-phase variant: LDS holds the tables of HALF the sub-quantisers (96 KiB) at a time; a wave keeps the
+// partial sums of R = 4 chunks of 32 rows in registers (R x 16 accumulator VGPRs) across the swap, and consecutive
+// rounds visit the halves in alternating order (0,1 | 1,0 | 0,1 ...) so the table in LDS is replaced once per round of
+// 16 waves x R x 32 = 2048 rows.  Same arithmetic, threshold and candidate list as adc_screen_mfma_kernel.
+template <int M>
+__global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma2_kernel(const uint8_t* __restrict__ codes, int64_t N,
+                                                                       const uint8_t* __restrict__ qlut,
+                                                                       const int* __restrict__ tint, int nq,
+                                                                       unsigned* __restrict__ id_count,
+                                                                       unsigned* __restrict__ ids) {
+    constexpr int QS = 8, PM = M / 2, HM = PM / 2, NW = HM / 4, R = 4;   // per phase, per half-wave, dwords, chunks
+    static_assert(HM % 2 == 0 && HM % 4 == 0, "unsupported M");
+    constexpr int NWAVES = ADC_THREADS / 64;
+    constexpr int ROUND = NWAVES * R * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * QS;
+    const uint8_t* qsrc = qlut + (size_t)blockIdx.x * M * RC_K * QS;
+    auto fill = [&](int phase) {
+        const uint4* src = reinterpret_cast<const uint4*>(qsrc + (size_t)phase * PM * RC_K * QS);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < PM * RC_K * QS / 16; i += ADC_THREADS) {
+            uint4 v = src[i];
+            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;   // l -> l - 128 (signed)
+            dst[i] = v;
+        }
+    };
+    const int l = tid & 63, wv = tid >> 6;
+    const int d = l & 31, hh = l >> 5;
+    int tq = INT_MAX;
+    if (d < QS && q0 + d < nq) {
+        const int t = tint[q0 + d];
+        tq = (t == INT_MIN) ? INT_MIN : t - 128 * M;
+    }
+    adc_i32x4 bsel = {0, 0, 0, 0};
+    if (d < QS) {
+        const int one = 1 << (8 * (d & 3));
+        bsel[d >> 2] = one;
+        bsel[2 + (d >> 2)] = one;
+    }
+    const int64_t t0 = (int64_t)blockIdx.y * ADC_TILE_DOCS;
+    const int64_t t1 = (t0 + ADC_TILE_DOCS < N) ? t0 + ADC_TILE_DOCS : N;
+    const unsigned char* tabh = smem + (size_t)hh * HM * RC_K * QS;
+    int in_lds = -1;
+    int first = 0;                                           // phase visited first this round
+    for (int64_t r0 = t0; r0 < t1; r0 += ROUND) {            // block-uniform
+        adc_i32x16 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = adc_i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            const int phase = step == 0 ? first : 1 - first;
+            if (in_lds != phase) {
+                __syncthreads();                             // every wave is done gathering from the old half
+                fill(phase);
+                __syncthreads();
+                in_lds = phase;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t i0 = r0 + (int64_t)(wv * R + r) * 32;
+                if (i0 < t1) {                                // wave-uniform
+                    const int64_t n = i0 + d;
+                    const uint8_t* cp = codes + (n < t1 ? n : (t1 - 1)) * M + phase * PM + hh * HM;
+                    unsigned w[NW];
+                    if constexpr (HM % 8 == 0) {
+#pragma unroll
+                        for (int j = 0; j < HM / 8; ++j) {
+                            const uint2 v = reinterpret_cast<const uint2*>(cp)[j];
+                            w[2 * j] = v.x; w[2 * j + 1] = v.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NW; ++j) w[j] = reinterpret_cast<const unsigned*>(cp)[j];
+                    }
+#pragma unroll
+                    for (int g2 = 0; g2 < HM / 2; ++g2) {
+                        const int ma = 2 * g2, mb = 2 * g2 + 1;
+                        const unsigned ca = (w[ma >> 2] >> (8 * (ma & 3))) & 0xFFu;
+                        const unsigned cb = (w[mb >> 2] >> (8 * (mb & 3))) & 0xFFu;
+                        const uint2 ea = *reinterpret_cast<const uint2*>(tabh + ((size_t)ma * RC_K + ca) * QS);
+                        const uint2 eb = *reinterpret_cast<const uint2*>(tabh + ((size_t)mb * RC_K + cb) * QS);
+                        const adc_i32x4 a = {(int)ea.x, (int)ea.y, (int)eb.x, (int)eb.y};
+                        acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bsel, acc[r], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        first = 1 - first;                                    // the half now in LDS goes first next round
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i0 = r0 + (int64_t)(wv * R + r) * 32;
+            if (i0 < t1) {
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) any |= (acc[r][e] >= tq);
+                if (__ballot(any)) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t n = i0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (acc[r][e] >= tq && n < t1) {
+                            const unsigned slot = atomicAdd(id_count + q0 + d, 1u);
+                            if (slot < ADC_ID_CAP) ids[(size_t)(q0 + d) * ADC_ID_CAP + slot] = (unsigned)n;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One block per query: exact fp32 score (m ascending, from 0) of every screened row; rows with score >= tau go
 // to the key list exactly as adc_scan_kernel<FILTER> would have put them.
 template <int M>
@@ -612,7 +724,7 @@ struct adc_ws_layout {
     size_t lut, sample, thr, cnt, cand, qlut, tint, idcnt, ids, total;
     int64_t S;
 };
-static int adc_qs_for(int M) { return M <= 64 ? 8 : 4; }   // queries per byte gather (LDS: M*256*QS bytes)
+static int adc_qs_for(int M) { (void)M; return 8; }   // table groups are sized for 8 queries (covers the 4-query kernels)
 static adc_ws_layout adc_layout(int64_t N, int M, int nq) {
     adc_ws_layout L;
     L.S = N < ADC_SAMPLE_MAX ? N : ADC_SAMPLE_MAX;
@@ -678,38 +790,35 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
         RC_LAUNCH_CHECK(h);
         return RC_OK;
     }
-    constexpr int QS = (M <= 64) ? 8 : 4;
     RC_HIP_CHECK(h, hipMemsetAsync(b.idcnt, 0, (size_t)nq * sizeof(unsigned), s));
-    hipLaunchKernelGGL(adc_qlut_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, QS, b.qlut, b.tint);
-    RC_LAUNCH_CHECK(h);
-    const size_t sl = (size_t)M * RC_K * QS;
-    const dim3 sgrid((unsigned)((nq + QS - 1) / QS), tiles);
-    if constexpr (M % 8 == 0) {
-        static const bool valu_screen = getenv("RC_ADC_VALU_SCREEN") != nullptr;     // A/B switch for measurements
-        if (!valu_screen) {
-            auto kmf = adc_screen_mfma_kernel<M, QS>;
-            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
-            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-            hipLaunchKernelGGL(kmf, sgrid, dim3(ADC_THREADS), sl, s, codes, N, b.qlut, b.tint, nq, b.idcnt, b.ids);
-            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-            RC_LAUNCH_CHECK(h);
-        }
-        if (valu_screen) {
-            auto kscreen = adc_screen_kernel<M, QS>;
-            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kscreen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
-            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-            hipLaunchKernelGGL(kscreen, sgrid, dim3(ADC_THREADS), sl, s, codes, N, b.qlut, b.tint, nq, b.idcnt, b.ids);
-            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-            RC_LAUNCH_CHECK(h);
-        }
-    } else {
-        auto kscreen = adc_screen_kernel<M, QS>;
-        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kscreen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
+    // Screen variant: 8 queries per gather on the matrix cores (tables in LDS: one pass for M <= 64, two half-table
+    // phases above); M % 8 != 0 and the A/B switches RC_ADC_VALU_SCREEN / RC_ADC_ONE_PHASE use the older kernels.
+    static const bool valu_screen = getenv("RC_ADC_VALU_SCREEN") != nullptr;
+    static const bool one_phase = getenv("RC_ADC_ONE_PHASE") != nullptr;
+    auto screen = [&](auto kern, int QS, size_t sl) -> int {
+        hipLaunchKernelGGL(adc_qlut_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, QS, b.qlut, b.tint);
+        RC_LAUNCH_CHECK(h);
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-        hipLaunchKernelGGL(kscreen, sgrid, dim3(ADC_THREADS), sl, s, codes, N, b.qlut, b.tint, nq, b.idcnt, b.ids);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((nq + QS - 1) / QS), tiles), dim3(ADC_THREADS), sl, s, codes, N, b.qlut,
+                           b.tint, nq, b.idcnt, b.ids);
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         RC_LAUNCH_CHECK(h);
+        return RC_OK;
+    };
+    constexpr int QS1 = (M <= 64) ? 8 : 4;                  // one-pass kernels: M * 256 * QS bytes of LDS
+    int src = RC_OK;
+    if constexpr (M % 8 == 0 && M > 64) {
+        if (!valu_screen && !one_phase) src = screen(adc_screen_mfma2_kernel<M>, 8, (size_t)(M / 2) * RC_K * 8);
+        else if (!valu_screen) src = screen(adc_screen_mfma_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
+        else src = screen(adc_screen_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
+    } else if constexpr (M % 8 == 0) {
+        if (!valu_screen) src = screen(adc_screen_mfma_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
+        else src = screen(adc_screen_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
+    } else {
+        src = screen(adc_screen_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
     }
+    if (src != RC_OK) return src;
     auto krescore = adc_rescore_kernel<M>;
     const size_t rl = (size_t)M * RC_K * sizeof(float);
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
