@@ -559,19 +559,23 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma_kernel(const uint
     }
 }
 
-// M = 96: the 8-query byte tables are 196 KiB, more than a CU's LDS, and 4-query tables cost two LDS gathers per
-// 8 queries.  Two-phase variant: LDS holds the tables of HALF the sub-quantisers (96 KiB) at a time; a wave keeps the
-// partial sums of R = 4 chunks of 32 rows in registers (R x 16 accumulator VGPRs) across the swap, and consecutive
-// rounds visit the halves in alternating order (0,1 | 1,0 | 0,1 ...) so the table in LDS is replaced once per round of
-// 16 waves x R x 32 = 2048 rows.  Same arithmetic, threshold and candidate list as adc_screen_mfma_kernel.
-template <int M>
+// Phased variant: more queries per gather than the LDS can hold tables for.  LDS keeps the byte tables of M / NP
+// sub-quantisers at a time; a wave keeps the partial sums of R = 4 chunks of 32 rows in accumulator registers across the
+// table swaps, and consecutive rounds visit the phases in alternating direction (0..NP-1 | NP-1..0 | ...) so the table
+// already in LDS is reused: NP - 1 refills per round of 16 waves x R x 32 = 2048 rows.
+//   QS = 16 (one ds_read_b128 = 16 queries = the whole A operand; B[t][j] = [t == j]): M <= 64 with NP = 2 — half the LDS
+//            instructions per query of the one-pass 8-query kernel;
+//   QS = 8, NP = 2: M = 96 (its 8-query tables are 196 KiB; the one-pass kernel had to fall back to 4 queries per gather).
+// Same arithmetic, threshold and candidate list as adc_screen_mfma_kernel.
+template <int M, int QS, int NP>
 __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma2_kernel(const uint8_t* __restrict__ codes, int64_t N,
                                                                        const uint8_t* __restrict__ qlut,
                                                                        const int* __restrict__ tint, int nq,
                                                                        unsigned* __restrict__ id_count,
                                                                        unsigned* __restrict__ ids) {
-    constexpr int QS = 8, PM = M / 2, HM = PM / 2, NW = HM / 4, R = 4;   // per phase, per half-wave, dwords, chunks
-    static_assert(HM % 2 == 0 && HM % 4 == 0, "unsupported M");
+    constexpr int PM = M / NP, HM = PM / 2, R = 4;           // sub-quantisers per phase, per half-wave; chunks per wave
+    constexpr int G = 16 / QS;                               // gathers per A operand
+    static_assert((QS == 8 || QS == 16) && M % NP == 0 && PM % 2 == 0 && HM % G == 0 && HM % 4 == 0, "unsupported (M, QS, NP)");
     constexpr int NWAVES = ADC_THREADS / 64;
     constexpr int ROUND = NWAVES * R * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -594,26 +598,26 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma2_kernel(const uin
         const int t = tint[q0 + d];
         tq = (t == INT_MIN) ? INT_MIN : t - 128 * M;
     }
-    adc_i32x4 bsel = {0, 0, 0, 0};
+    adc_i32x4 bsel = {0, 0, 0, 0};                           // B[t][j = d] = [t % QS == d]
     if (d < QS) {
         const int one = 1 << (8 * (d & 3));
         bsel[d >> 2] = one;
-        bsel[2 + (d >> 2)] = one;
+        if constexpr (QS == 8) bsel[2 + (d >> 2)] = one;
     }
     const int64_t t0 = (int64_t)blockIdx.y * ADC_TILE_DOCS;
     const int64_t t1 = (t0 + ADC_TILE_DOCS < N) ? t0 + ADC_TILE_DOCS : N;
     const unsigned char* tabh = smem + (size_t)hh * HM * RC_K * QS;
     int in_lds = -1;
-    int first = 0;                                           // phase visited first this round
+    bool forward = true;
     for (int64_t r0 = t0; r0 < t1; r0 += ROUND) {            // block-uniform
         adc_i32x16 acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = adc_i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int step = 0; step < 2; ++step) {
-            const int phase = step == 0 ? first : 1 - first;
+        for (int step = 0; step < NP; ++step) {
+            const int phase = forward ? step : NP - 1 - step;
             if (in_lds != phase) {
-                __syncthreads();                             // every wave is done gathering from the old half
+                __syncthreads();                             // every wave is done gathering from the old tables
                 fill(phase);
                 __syncthreads();
                 in_lds = phase;
@@ -624,31 +628,40 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma2_kernel(const uin
                 if (i0 < t1) {                                // wave-uniform
                     const int64_t n = i0 + d;
                     const uint8_t* cp = codes + (n < t1 ? n : (t1 - 1)) * M + phase * PM + hh * HM;
-                    unsigned w[NW];
+                    unsigned char cb[HM];                     // this lane's codes of the phase (HM bytes, 4-byte aligned)
                     if constexpr (HM % 8 == 0) {
 #pragma unroll
                         for (int j = 0; j < HM / 8; ++j) {
                             const uint2 v = reinterpret_cast<const uint2*>(cp)[j];
-                            w[2 * j] = v.x; w[2 * j + 1] = v.y;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) { cb[8 * j + b] = (v.x >> (8 * b)) & 0xFFu; cb[8 * j + 4 + b] = (v.y >> (8 * b)) & 0xFFu; }
                         }
                     } else {
 #pragma unroll
-                        for (int j = 0; j < NW; ++j) w[j] = reinterpret_cast<const unsigned*>(cp)[j];
+                        for (int j = 0; j < HM / 4; ++j) {
+                            const unsigned v = reinterpret_cast<const unsigned*>(cp)[j];
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) cb[4 * j + b] = (v >> (8 * b)) & 0xFFu;
+                        }
                     }
 #pragma unroll
-                    for (int g2 = 0; g2 < HM / 2; ++g2) {
-                        const int ma = 2 * g2, mb = 2 * g2 + 1;
-                        const unsigned ca = (w[ma >> 2] >> (8 * (ma & 3))) & 0xFFu;
-                        const unsigned cb = (w[mb >> 2] >> (8 * (mb & 3))) & 0xFFu;
-                        const uint2 ea = *reinterpret_cast<const uint2*>(tabh + ((size_t)ma * RC_K + ca) * QS);
-                        const uint2 eb = *reinterpret_cast<const uint2*>(tabh + ((size_t)mb * RC_K + cb) * QS);
-                        const adc_i32x4 a = {(int)ea.x, (int)ea.y, (int)eb.x, (int)eb.y};
+                    for (int g2 = 0; g2 < HM / G; ++g2) {
+                        adc_i32x4 a;
+                        if constexpr (QS == 16) {
+                            const uint4 e = *reinterpret_cast<const uint4*>(tabh + ((size_t)g2 * RC_K + cb[g2]) * QS);
+                            a = adc_i32x4{(int)e.x, (int)e.y, (int)e.z, (int)e.w};
+                        } else {
+                            const int ma = 2 * g2, mb = 2 * g2 + 1;
+                            const uint2 ea = *reinterpret_cast<const uint2*>(tabh + ((size_t)ma * RC_K + cb[ma]) * QS);
+                            const uint2 eb = *reinterpret_cast<const uint2*>(tabh + ((size_t)mb * RC_K + cb[mb]) * QS);
+                            a = adc_i32x4{(int)ea.x, (int)ea.y, (int)eb.x, (int)eb.y};
+                        }
                         acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bsel, acc[r], 0, 0, 0);
                     }
                 }
             }
         }
-        first = 1 - first;                                    // the half now in LDS goes first next round
+        forward = !forward;                                   // the tables now in LDS go first next round
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t i0 = r0 + (int64_t)(wv * R + r) * 32;
@@ -724,7 +737,7 @@ struct adc_ws_layout {
     size_t lut, sample, thr, cnt, cand, qlut, tint, idcnt, ids, total;
     int64_t S;
 };
-static int adc_qs_for(int M) { (void)M; return 8; }   // table groups are sized for 8 queries (covers the 4-query kernels)
+static int adc_qs_for(int M) { (void)M; return 16; }   // table groups are sized for 16 queries (covers the 8- and 4-query kernels)
 static adc_ws_layout adc_layout(int64_t N, int M, int nq) {
     adc_ws_layout L;
     L.S = N < ADC_SAMPLE_MAX ? N : ADC_SAMPLE_MAX;
@@ -809,7 +822,15 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
     constexpr int QS1 = (M <= 64) ? 8 : 4;                  // one-pass kernels: M * 256 * QS bytes of LDS
     int src = RC_OK;
     if constexpr (M % 8 == 0 && M > 64) {
-        if (!valu_screen && !one_phase) src = screen(adc_screen_mfma2_kernel<M>, 8, (size_t)(M / 2) * RC_K * 8);
+        if (!valu_screen && !one_phase) src = screen(adc_screen_mfma2_kernel<M, 8, 2>, 8, (size_t)(M / 2) * RC_K * 8);
+        else if (!valu_screen) src = screen(adc_screen_mfma_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
+        else src = screen(adc_screen_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
+    } else if constexpr (M % 16 == 0) {
+        // 16 queries per ds_read_b128 in two phases: measured SLOWER than the one-pass 8-query kernel at M = 48
+        // (66-70 k vs 75-78 k queries/s: a b128 gather costs as many LDS cycles per query as a b64 one, and the
+        // table refills come on top); kept behind RC_ADC_Q16 for experiments.
+        static const bool q16 = getenv("RC_ADC_Q16") != nullptr;
+        if (!valu_screen && q16) src = screen(adc_screen_mfma2_kernel<M, 16, 2>, 16, (size_t)(M / 2) * RC_K * 16);
         else if (!valu_screen) src = screen(adc_screen_mfma_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
         else src = screen(adc_screen_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
     } else if constexpr (M % 8 == 0) {
