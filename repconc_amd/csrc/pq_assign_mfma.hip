@@ -344,8 +344,10 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
                 a1 = lo;
                 a2 = second;
             }
-            const float margin = MARGIN * (xn[s] + cnmax);
-            const bool doubt = !((a2 - a1) > margin);               // also true for NaN / inf inputs
+            // also doubtful: NaN / inf inputs (margin non-finite) and magnitudes so small that products of the bf16
+            // pieces may be flushed denormals (<= 1.2e-38 per term, far below margin once the scale exceeds 1e-30)
+            const float scale = xn[s] + cnmax;
+            const bool doubt = !((a2 - a1) > MARGIN * scale) || !(scale > 1e-30f);
             if (half == 0) {
                 tile[((wv * MF_SETS + s) * MF_COLS + col) * M + m] = (unsigned char)k1;
                 if (brow[s] < B && doubt) {

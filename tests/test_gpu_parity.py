@@ -774,9 +774,16 @@ def test_mfma_screened_assignment_non_finite_rows():
     x[11, 5] = -np.inf
     x[13, :] = 1e30                      # squares overflow fp32
     x[17, :] = 3e19                      # ||x||^2 overflows only in the sum
+    x[19:40] *= 1e-22                    # squares are denormal / underflow
     fast = ops.assign_nearest(_t(x), _t(C), torch.uint8, method="mfma")
     exact = ops.assign_nearest(_t(x), _t(C), torch.uint8, method="exact")
     assert torch.equal(fast, exact)
+    tiny = (rng.standard_normal((B, 768)) * 1e-20).astype(np.float32)      # everything below the 1e-30 scale floor
+    Ct = (C * np.float32(1e-20)).astype(np.float32)
+    st = {}
+    fast = ops.assign_nearest(_t(tiny), _t(Ct), torch.uint8, method="mfma", stats=st)
+    assert torch.equal(fast, ops.assign_nearest(_t(tiny), _t(Ct), torch.uint8, method="exact"))
+    assert st["doubtful"] == B * M or st["overflow"]
 
 
 def test_mfma_assignment_overflow_falls_back_and_unaligned_rows():
