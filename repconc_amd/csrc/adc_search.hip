@@ -38,6 +38,7 @@
 #define ADC_THREADS 1024
 #define ADC_SAMPLE_MAX 32768
 #define ADC_CAND_CAP 16384
+#define ADC_SELECT_SMALL 4096   // candidates the small-LDS launch of the select kernel sorts
 #define ADC_TILE_DOCS 32768
 
 __device__ __forceinline__ unsigned adc_order_key(float s) {
@@ -240,15 +241,20 @@ __global__ __launch_bounds__(1024) void adc_threshold_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------ 5. select
 // One block per query.  Sort the candidate keys descending (bitonic, LDS), emit the first k.
 // status |= 1 if fewer than min(k,N) candidates were collected, |= 2 if the list overflowed.
-__global__ __launch_bounds__(1024) void adc_select_kernel(const unsigned long long* __restrict__ cand,
+// Up to ADC_SELECT_SMALL candidates (the usual case: ~1.5 k for k = 1000) are sorted in 32 KiB of LDS, so several
+// blocks share a CU; longer lists (k > 2048, or a loose threshold) are sorted in place in the candidate buffer in global
+// memory — same network, same result, slower.
+__global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __restrict__ cand,
                                                           const unsigned* __restrict__ cand_count, int64_t N, int k,
                                                           int64_t id_offset, float* __restrict__ scores,
                                                           int64_t* __restrict__ ids, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     const int qi = blockIdx.x, tid = threadIdx.x;
     const unsigned raw = cand_count[qi];
     const int cnt = raw > ADC_CAND_CAP ? ADC_CAND_CAP : (int)raw;
+    const bool in_lds = cnt <= ADC_SELECT_SMALL;             // block-uniform
+    unsigned long long* gk = cand + (size_t)qi * ADC_CAND_CAP;
+    unsigned long long* keys = in_lds ? reinterpret_cast<unsigned long long*>(smem) : gk;
     const int64_t want = (k < N) ? k : N;
     if (tid == 0) {
         int st = 0;
@@ -258,7 +264,11 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(const unsigned long lo
     }
     int P = 1024;
     while (P < cnt) P <<= 1;
-    for (int i = tid; i < P; i += 1024) keys[i] = (i < cnt) ? cand[(size_t)qi * ADC_CAND_CAP + i] : 0ull;
+    if (in_lds) {
+        for (int i = tid; i < P; i += 1024) keys[i] = (i < cnt) ? gk[i] : 0ull;
+    } else {
+        for (int i = cnt + tid; i < P; i += 1024) gk[i] = 0ull;       // P <= ADC_CAND_CAP
+    }
     __syncthreads();
     for (int size = 2; size <= P; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -875,12 +885,10 @@ extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq,
 }
 
 // sort + emit stage, shared with the IVF path (ivf_search.hip)
-int rc_adc_launch_select(rc_handle_t h, const unsigned long long* cand, const unsigned* cnt, int nq, int64_t N, int k,
+int rc_adc_launch_select(rc_handle_t h, unsigned long long* cand, const unsigned* cnt, int nq, int64_t N, int k,
                          int64_t id_offset, float* scores, int64_t* ids, int* status, hipStream_t s) {
-    const size_t sl = (size_t)ADC_CAND_CAP * sizeof(unsigned long long);
-    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)adc_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)sl));
-    hipLaunchKernelGGL(adc_select_kernel, dim3((unsigned)nq), dim3(1024), sl, s, cand, cnt, N, k, id_offset, scores, ids,
+    const size_t ss = (size_t)ADC_SELECT_SMALL * sizeof(unsigned long long);
+    hipLaunchKernelGGL(adc_select_kernel, dim3((unsigned)nq), dim3(1024), ss, s, cand, cnt, N, k, id_offset, scores, ids,
                        status);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
