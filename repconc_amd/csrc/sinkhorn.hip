@@ -290,8 +290,11 @@ __global__ __launch_bounds__(SK_THREADS) void sk_argmax_kernel(const float* __re
 
 // ------------------------------------------------------------------------------------------ host
 // columns per block: every block pays a fixed prologue (16 KiB table, 256 potentials, its columns' g) and
-// the partial hand-off, so blocks should be as long as the grid allows while still giving every CU ~6 blocks
-// (3 are resident at a time).  Measured on MI355X at M = 48: B = 6144 -> 192 (79 us; 64 -> 102 us),
+// the partial hand-off, so blocks should be as long as the grid allows while still filling the chip once:
+// 3 blocks are resident per CU (VGPR-limited), 256 CUs -> the longest block length that still yields >= 768 blocks.
+// Measured on MI355X (us per sweep; blocks in brackets):  B = 6144, M = 48: 96 -> 93 [3072], 192 -> 80 [1536],
+// 384 -> 75 [768], 512 -> 87 [576];  B = 6144, M = 24 (one chain of the two-chain multi-rank solve): 96 -> 48 [1536],
+// 192 -> 39 [768], 256 -> 46 [576];  B = 12288, M = 48: 192 -> 163, 384 -> 155 [1536], 512 -> 158 [1152];
 // B >= 24576 -> 512.
 static int sk_cols_per_block(int64_t B, int M) {
     static int forced = -1;   // development override
@@ -299,7 +302,7 @@ static int sk_cols_per_block(int64_t B, int M) {
     if (forced >= 16 && forced <= SK_MAX_CPB) return forced;
     static const int cand[] = {512, 384, 256, 192, 128, 96, 64};
     for (int c : cand)
-        if (((B + c - 1) / c) * M >= 1536) return c;
+        if (((B + c - 1) / c) * M >= 768) return c;
     return 64;
 }
 static double sk_scale() { return (double)SK_N / SK_LN2; }
