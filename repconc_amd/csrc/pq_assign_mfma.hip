@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
                                                           const float* __restrict__ C, int64_t B, int M,
                                                           uint8_t* __restrict__ codes_u8, int64_t* __restrict__ codes_i64,
                                                           unsigned* __restrict__ redo_count, unsigned* __restrict__ redo,
-                                                          unsigned redo_cap) {
+                                                          unsigned redo_cap, int MC) {
+    // blockIdx.y selects a chunk of MC sub-quantisers (small batches: more blocks than B / 256 alone would give)
     using G = mf_geom<DSUB>;
     constexpr int KP = G::KP, KS = G::KS, NBUF = G::NBUF;
     extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
@@ -204,13 +205,16 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
                 }
     };
 
-    fetch_c(0);
-    fetch_x(0);
+    const int m0 = blockIdx.y * MC;
+    const int mc = (m0 + MC <= M) ? MC : (M - m0);
+    fetch_c(m0);
+    fetch_x(m0);
     store_c(mf_smem);
     __syncthreads();
 
-    for (int m = 0; m < M; ++m) {
-        const unsigned char* buf = mf_smem + (NBUF == 2 ? (m & 1) : 0) * G::BUF_BYTES;
+    for (int mi = 0; mi < mc; ++mi) {
+        const int m = m0 + mi;
+        const unsigned char* buf = mf_smem + (NBUF == 2 ? (mi & 1) : 0) * G::BUF_BYTES;
         const uint4* whi = reinterpret_cast<const uint4*>(buf);
         const uint4* wlo = reinterpret_cast<const uint4*>(buf + RC_K * KP * 2);
         const uint4* cn3 = reinterpret_cast<const uint4*>(buf + RC_K * KP * 4);
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
             }
             xn[s] = nrm + __shfl_xor(nrm, 32);
         }
-        const int mn = (m + 1 < M) ? m + 1 : m;
+        const int mn = (mi + 1 < mc) ? m + 1 : m;
         fetch_x(mn);                                                // in flight during the tile loop
         if (NBUF == 2) fetch_c(mn);
 
@@ -349,16 +353,16 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
             const float scale = xn[s] + cnmax;
             const bool doubt = !((a2 - a1) > MARGIN * scale) || !(scale > 1e-30f);
             if (half == 0) {
-                tile[((wv * MF_SETS + s) * MF_COLS + col) * M + m] = (unsigned char)k1;
+                tile[((wv * MF_SETS + s) * MF_COLS + col) * mc + mi] = (unsigned char)k1;
                 if (brow[s] < B && doubt) {
                     const unsigned slot = atomicAdd(redo_count, 1u);
                     if (slot < redo_cap) redo[slot] = (unsigned)(brow[s] * (int64_t)M + m);   // B*M < 2^32 (host)
                 }
             }
         }
-        if (m + 1 < M) {
+        if (mi + 1 < mc) {
             if (NBUF == 2) {
-                store_c(mf_smem + ((m + 1) & 1) * G::BUF_BYTES);    // the other buffer: last read before the previous barrier
+                store_c(mf_smem + ((mi + 1) & 1) * G::BUF_BYTES);    // the other buffer: last read before the previous barrier
                 __syncthreads();
             } else {
                 __syncthreads();                                    // every wave is done with this buffer
@@ -370,17 +374,25 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
     }
     __syncthreads();
     const int64_t rows = (B - row0 < MF_ROWS_PER_BLOCK) ? (B - row0) : MF_ROWS_PER_BLOCK;
-    const int64_t nbytes = rows * M;
-    if (codes_u8) {
-        unsigned char* dst = codes_u8 + row0 * M;   // row0*M is a multiple of 16 (256*M)
-        const int64_t n16 = nbytes / 16;
-        for (int64_t i = tid; i < n16; i += 256)
-            reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(tile)[i];
-        for (int64_t i = n16 * 16 + tid; i < nbytes; i += 256) dst[i] = tile[i];
-    }
-    if (codes_i64) {
-        int64_t* dst = codes_i64 + row0 * M;
-        for (int64_t i = tid; i < nbytes; i += 256) dst[i] = (int64_t)tile[i];
+    const int64_t nbytes = rows * mc;
+    if (mc == M) {                                  // whole rows: the tile is the output image
+        if (codes_u8) {
+            unsigned char* dst = codes_u8 + row0 * M;   // row0*M is a multiple of 16 (256*M)
+            const int64_t n16 = nbytes / 16;
+            for (int64_t i = tid; i < n16; i += 256)
+                reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(tile)[i];
+            for (int64_t i = n16 * 16 + tid; i < nbytes; i += 256) dst[i] = tile[i];
+        }
+        if (codes_i64) {
+            int64_t* dst = codes_i64 + row0 * M;
+            for (int64_t i = tid; i < nbytes; i += 256) dst[i] = (int64_t)tile[i];
+        }
+    } else {                                        // a column chunk of the rows
+        for (int64_t i = tid; i < nbytes; i += 256) {
+            const int64_t r = i / mc, j = i - r * mc;
+            if (codes_u8) codes_u8[(row0 + r) * M + m0 + j] = tile[i];
+            if (codes_i64) codes_i64[(row0 + r) * M + m0 + j] = (int64_t)tile[i];
+        }
     }
 }
 
@@ -462,6 +474,9 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
     RC_HIP_CHECK(h, hipMemsetAsync(redo_count, 0, 256, s));
     const int dsub = D / M;
     const int64_t nblk = (B + MF_ROWS_PER_BLOCK - 1) / MF_ROWS_PER_BLOCK;
+    int MC = M;                                     // sub-quantisers per block: split M while the grid is under ~3 blocks per CU
+    while (MC > 1 && nblk * ((M + MC - 1) / MC) < 3 * (int64_t)h->num_cus) MC = (MC + 1) / 2;
+    const unsigned nchunk = (unsigned)((M + MC - 1) / MC);
     const int kp = (dsub + 15) / 16 * 16;
     const size_t lds = (size_t)(dsub <= 32 ? 2 : 1) * ((size_t)RC_K * kp * 4 + RC_K * 16 + 32) + (size_t)MF_ROWS_PER_BLOCK * M;
     rc_prof_mark(h, RC_PROF_ASSIGN_NEAREST, s);
@@ -470,8 +485,8 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
         case DS: {                                                                                                       \
             auto kern = assign_mfma_kernel<DS>;                                                                          \
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, x, ldx, C, B, M, codes_u8, codes_i64,     \
-                               redo_count, redo, cap);                                                                   \
+            hipLaunchKernelGGL(kern, dim3((unsigned)nblk, nchunk), dim3(256), lds, s, x, ldx, C, B, M, codes_u8, codes_i64, \
+                               redo_count, redo, cap, MC);                                                                   \
             hipLaunchKernelGGL(assign_redo_kernel<DS>, dim3((unsigned)(h->num_cus * 4)), dim3(256), 0, s, x, ldx, C, M,  \
                                redo_count, redo, cap, codes_u8, codes_i64);                                              \
         } break;
