@@ -862,3 +862,25 @@ def test_c_index_handle_api_matches_oracle():
         assert lib.rc_index_reset(idx) == 0 and lib.rc_index_ntotal(idx) == 0
     finally:
         assert lib.rc_index_destroy(idx) == 0
+
+
+def test_index_build_scale_properties():
+    """Index-build path at scale (2 M x 768, M = 48, a quarter of the BASELINE corpus per pass): the MFMA-screened codes
+    equal the exact-order kernel's, and coding is idempotent — re-assigning decode(codes) returns the same codes
+    (a reconstructed vector sits ON its centroids, distance 0 in every sub-space, first minimum wins)."""
+    from repconc_amd import ops
+    N, M = 1 << 21, 48
+    g = torch.Generator(device=DEV).manual_seed(2024)
+    x = torch.randn((N, 768), device=DEV, generator=g)
+    C = x[torch.randperm(N, device=DEV, generator=g)[:256]].reshape(256, M, 16).transpose(0, 1).contiguous()
+    st = {}
+    fast = ops.assign_nearest(x, C, torch.uint8, method="mfma", stats=st)
+    exact = ops.assign_nearest(x, C, torch.uint8, method="exact")
+    assert torch.equal(fast, exact)
+    assert st["method"] == "mfma" and 0 < st["doubtful"] < N * M // 100
+    del x
+    rec = ops.decode_raw(fast, C)
+    again = ops.assign_nearest(rec, C, torch.uint8, method="mfma")
+    assert torch.equal(again, fast)
+    hist = ops.code_hist(fast)
+    assert int(hist.sum()) == N * M and hist.shape == (M, 256)
