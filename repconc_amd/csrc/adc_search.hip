@@ -451,6 +451,19 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_kernel(const uint8_t* 
     }
 }
 
+// XCD-aware block remap (guide T1).  The dispatcher places workgroup b on XCD b % 8 and every XCD has a private L2; the
+// grid is (query groups, row tiles) with the group index fastest, so by default the ~150 blocks that scan the same
+// row tile land on all 8 XCDs and the tile is fetched from HBM once per XCD.  The bijective remap hands each XCD a
+// contiguous range of (tile, group) pairs: all groups of a tile run on ONE XCD, whose L2 (4 MiB) keeps the 1.5 MiB tile.
+__device__ __forceinline__ void adc_xcd_remap(unsigned& group, unsigned& tile) {
+    const unsigned gx = gridDim.x, total = gx * gridDim.y;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned q = total / 8u, r = total % 8u, xcd = lin % 8u;
+    const unsigned virt = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + lin / 8u;
+    group = virt % gx;
+    tile = virt / gx;
+}
+
 // The same screen with the byte accumulation on the matrix cores (M % 8 == 0; 8 queries per group, 4 when M > 64).
 // PMC on adc_screen_kernel<48,8>: 9.3e9 VALU instructions per 1200-query launch = 95 % of the kernel's VALU cycles,
 // the LDS gathers active 12 of its 18 ms — the v_perm/v_add accumulation is the limiter.  Here a wave takes 32 rows;
@@ -477,9 +490,11 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma_kernel(const uint
     static_assert((QS == 8 || QS == 4) && HM % G == 0 && HM % 4 == 0, "unsupported (M, QS)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * QS;
+    unsigned bgroup, btile;
+    adc_xcd_remap(bgroup, btile);
+    const int q0 = (int)bgroup * QS;
     {
-        const uint4* src = reinterpret_cast<const uint4*>(qlut + (size_t)blockIdx.x * M * RC_K * QS);
+        const uint4* src = reinterpret_cast<const uint4*>(qlut + (size_t)bgroup * M * RC_K * QS);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (int i = tid; i < M * RC_K * QS / 16; i += ADC_THREADS) {
             uint4 v = src[i];
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma_kernel(const uint
         }
     }
     __syncthreads();
-    const int64_t t0 = (int64_t)blockIdx.y * ADC_TILE_DOCS;
+    const int64_t t0 = (int64_t)btile * ADC_TILE_DOCS;
     const int64_t t1 = (t0 + ADC_TILE_DOCS < N) ? t0 + ADC_TILE_DOCS : N;
     constexpr int NWAVES = ADC_THREADS / 64;
     const unsigned char* tabh = smem + (size_t)hh * HM * RC_K * QS;      // this half-wave's sub-quantisers
@@ -590,8 +605,10 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma2_kernel(const uin
     constexpr int ROUND = NWAVES * R * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * QS;
-    const uint8_t* qsrc = qlut + (size_t)blockIdx.x * M * RC_K * QS;
+    unsigned bgroup, btile;
+    adc_xcd_remap(bgroup, btile);
+    const int q0 = (int)bgroup * QS;
+    const uint8_t* qsrc = qlut + (size_t)bgroup * M * RC_K * QS;
     auto fill = [&](int phase) {
         const uint4* src = reinterpret_cast<const uint4*>(qsrc + (size_t)phase * PM * RC_K * QS);
         uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -614,7 +631,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma2_kernel(const uin
         bsel[d >> 2] = one;
         if constexpr (QS == 8) bsel[2 + (d >> 2)] = one;
     }
-    const int64_t t0 = (int64_t)blockIdx.y * ADC_TILE_DOCS;
+    const int64_t t0 = (int64_t)btile * ADC_TILE_DOCS;
     const int64_t t1 = (t0 + ADC_TILE_DOCS < N) ? t0 + ADC_TILE_DOCS : N;
     const unsigned char* tabh = smem + (size_t)hh * HM * RC_K * QS;
     int in_lds = -1;
