@@ -39,6 +39,9 @@
 #define SK_NG (SK_THREADS / SK_GROUP)  // 16 columns in flight per block
 #define SK_TB 11                       // exp table: 2^11 entries (16 KiB of LDS)
 #define SK_N (1 << SK_TB)
+#ifndef SK_RED_INFLIGHT
+#define SK_RED_INFLIGHT 24               // partial loads in flight in the last-block reducer
+#endif
 #define SK_MAX_CPB 512                 // columns per block (LDS holds their integer column exponents)
 #define SK_LN2 0.69314718055994530942
 
@@ -216,17 +219,17 @@ __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
     }
     __syncthreads();
     if (*last_flag) {
-        // reducer: the partials were stored write-through, read them with L1-bypassing (sc1) loads, in
-        // block order, 8 loads in flight
+        // reducer: the partials were stored write-through, read them with L1-bypassing (sc1) loads, summed in
+        // block order; SK_RED_INFLIGHT loads in flight (the reducer is the tail of every sweep: pure L2 latency)
         double acc = 0.0;
         unsigned i = 0;
-        for (; i + 8 <= nblk; i += 8) {
-            double v[8];
+        for (; i + SK_RED_INFLIGHT <= nblk; i += SK_RED_INFLIGHT) {
+            double v[SK_RED_INFLIGHT];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < SK_RED_INFLIGHT; ++j)
                 v[j] = __hip_atomic_load(pm + (size_t)(i + j) * RC_K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += v[j];
+            for (int j = 0; j < SK_RED_INFLIGHT; ++j) acc += v[j];
         }
         for (; i < nblk; ++i)
             acc += __hip_atomic_load(pm + (size_t)i * RC_K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
