@@ -38,7 +38,7 @@
 #define ADC_THREADS 1024
 #define ADC_SAMPLE_MAX 32768
 #define ADC_CAND_CAP 16384
-#define ADC_SELECT_SMALL 4096   // candidates the small-LDS launch of the select kernel sorts
+#define ADC_SELECT_SMALL ADC_CAND_CAP   // lists up to this length are sorted in LDS (measured: 128 KiB, one block per CU, 0.54 ms per 1200 queries; 64 KiB / two blocks per CU 0.95 ms; the typical list at k = 1000 holds ~5 k keys)
 #define ADC_TILE_DOCS 32768
 
 __device__ __forceinline__ unsigned adc_order_key(float s) {
@@ -241,9 +241,8 @@ __global__ __launch_bounds__(1024) void adc_threshold_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------ 5. select
 // One block per query.  Sort the candidate keys descending (bitonic, LDS), emit the first k.
 // status |= 1 if fewer than min(k,N) candidates were collected, |= 2 if the list overflowed.
-// Up to ADC_SELECT_SMALL candidates (the usual case: ~1.5 k for k = 1000) are sorted in 32 KiB of LDS, so several
-// blocks share a CU; longer lists (k > 2048, or a loose threshold) are sorted in place in the candidate buffer in global
-// memory — same network, same result, slower.
+// Lists of up to ADC_SELECT_SMALL keys are sorted in LDS; longer ones (only if that constant is set below ADC_CAND_CAP)
+// in place in the candidate buffer in global memory — same network, same result, slower.
 __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __restrict__ cand,
                                                           const unsigned* __restrict__ cand_count, int64_t N, int k,
                                                           int64_t id_offset, float* __restrict__ scores,
@@ -905,6 +904,8 @@ extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq,
 int rc_adc_launch_select(rc_handle_t h, unsigned long long* cand, const unsigned* cnt, int nq, int64_t N, int k,
                          int64_t id_offset, float* scores, int64_t* ids, int* status, hipStream_t s) {
     const size_t ss = (size_t)ADC_SELECT_SMALL * sizeof(unsigned long long);
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)adc_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)ss));
     hipLaunchKernelGGL(adc_select_kernel, dim3((unsigned)nq), dim3(1024), ss, s, cand, cnt, N, k, id_offset, scores, ids,
                        status);
     RC_LAUNCH_CHECK(h);
