@@ -261,9 +261,51 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __
         if (raw > ADC_CAND_CAP) st |= 2;
         if (st) atomicOr(status, st);
     }
+    // Long lists (the threshold of step 3 lets ~5 k rows through for k = 1000) are first cut down to the k best scores
+    // (+ every tie at the k-th score): radix select of the k-th largest 32-bit score key, then compaction into LDS.  The
+    // sort network then runs on ~k keys instead of the whole list.
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_rank, survivors;
+    int n = cnt;
+    if (in_lds && cnt > 2048 && cnt > 2 * k) {
+        if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)k; survivors = 0u; }
+        __syncthreads();
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0u;
+            __syncthreads();
+            const unsigned prefix = sel_prefix;
+            const unsigned himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int i = tid; i < cnt; i += 1024) {
+                const unsigned sk = (unsigned)(gk[i] >> 32);
+                if ((sk & himask) == prefix) atomicAdd(&hist[(sk >> shift) & 0xFFu], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned need = sel_rank, b = 255;
+                for (;; --b) {
+                    if (hist[b] >= need) break;
+                    need -= hist[b];
+                    if (b == 0) break;
+                }
+                sel_prefix = prefix | (b << shift);
+                sel_rank = need;
+            }
+            __syncthreads();
+        }
+        const unsigned kth = sel_prefix;                      // k-th largest score key
+        for (int i = tid; i < cnt; i += 1024) {
+            const unsigned long long key = gk[i];
+            if ((unsigned)(key >> 32) >= kth) keys[atomicAdd(&survivors, 1u)] = key;
+        }
+        __syncthreads();
+        n = (int)survivors;                                   // >= k
+    }
     int P = 1024;
-    while (P < cnt) P <<= 1;
-    if (in_lds) {
+    while (P < n) P <<= 1;
+    if (n != cnt) {
+        for (int i = n + tid; i < P; i += 1024) keys[i] = 0ull;
+    } else if (in_lds) {
         for (int i = tid; i < P; i += 1024) keys[i] = (i < cnt) ? gk[i] : 0ull;
     } else {
         for (int i = cnt + tid; i < P; i += 1024) gk[i] = 0ull;       // P <= ADC_CAND_CAP
@@ -284,7 +326,7 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __
     for (int j = tid; j < k; j += 1024) {
         float sc = -INFINITY;
         int64_t id = -1;
-        if (j < cnt) {
+        if (j < n) {
             const unsigned long long key = keys[j];
             sc = adc_unorder_key((unsigned)(key >> 32));
             id = (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) + id_offset;
