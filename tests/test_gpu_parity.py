@@ -884,3 +884,82 @@ def test_index_build_scale_properties():
     assert torch.equal(again, fast)
     hist = ops.code_hist(fast)
     assert int(hist.sum()) == N * M and hist.shape == (M, 256)
+
+
+def test_jpq_module_step_matches_plain_autograd_and_keeps_index_in_sync():
+    """Stage 2 (N1): JPQ.forward over the resident index — loss and gradients (query table, centroids) equal a plain
+    torch restatement of the same step; after an optimiser step + jpq_step_end the index scores with the NEW centroids
+    while its codes never moved."""
+    import random
+    from types import SimpleNamespace
+    from repconc_amd.index import PQIndex
+    from repconc_amd.models.jpq import JPQ, jpq_step_end
+    from repconc_amd.models.repconc import RepCONC
+    torch.manual_seed(7)
+    M, N, nq, k = 48, 20000, 12, 50
+    docs = torch.from_numpy(synth.clustered_embeddings(515, N)).to(DEV)
+    C = _t(synth.sample_centroids(516, docs[:4096].cpu().numpy(), M))
+    cfg = SimpleNamespace(MCQ_M=M, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_IP")
+
+    class _Enc(torch.nn.Module):
+        def __init__(self, table):
+            super().__init__()
+            self.table = torch.nn.Parameter(table.clone())
+            self.config = SimpleNamespace(hidden_size=768)
+
+        def forward(self, input_ids, attention_mask):
+            return self.table[input_ids[:, 0]]
+
+    qtable = docs[torch.randperm(N, device=DEV)[:64]] + 0.05 * torch.randn(64, 768, device=DEV)
+    model = RepCONC(cfg, _Enc(qtable), False, EPS, ITERS).to(DEV)
+    with torch.no_grad():
+        model.centroids.copy_(C)
+    index = PQIndex(768, M, device=DEV)
+    index.set_centroids(C)
+    index.add(docs)
+    codes_ptr = index.codes.data_ptr()
+    qrels = {q: [int(3 * q), int(3 * q + 1)] for q in range(64)}
+    jpq = JPQ(model, index, qrels, neg_top_k=k, temperature=1.0)
+    qids = torch.arange(nq, device=DEV)
+    ids = qids[:, None].repeat(1, 4)
+    random.seed(99)
+    loss = jpq(ids, torch.ones_like(ids), qids)["loss"]
+    loss.backward()
+    g_tab, g_cent = model.dense_encoder.table.grad.clone(), model.centroids.grad.clone()
+    # plain torch restatement with the same retrieved negatives / sampled positives
+    random.seed(99)
+    with torch.no_grad():
+        qe = qtable[:nq] @ model.rotation.T
+        neg = index.search(qe.contiguous(), k)[1]
+    pos = torch.tensor([random.choice(qrels[int(q)]) for q in qids.tolist()], device=DEV)
+    tab2 = qtable.clone().requires_grad_(True)
+    C2 = C.clone().requires_grad_(True)
+    codes_l = index.codes.long()
+
+    def dec(p):
+        rows = codes_l[p.reshape(-1)]
+        return torch.cat([C2[m, rows[:, m]] for m in range(M)], dim=1)
+
+    q2 = tab2[:nq] @ model.rotation.T
+    sn = (q2.unsqueeze(1) * dec(neg).reshape(nq, k, -1)).sum(-1)
+    sp = (q2 * dec(pos)).sum(-1, keepdim=True)
+    want = torch.nn.functional.cross_entropy(torch.hstack((sp, sn)), torch.zeros(nq, dtype=torch.long, device=DEV))
+    want.backward()
+    assert abs(float(loss.detach()) - float(want.detach())) < 1e-4 * max(1.0, abs(float(want.detach())))
+    torch.testing.assert_close(g_tab, tab2.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(g_cent, C2.grad, rtol=1e-4, atol=1e-5)
+    # optimiser step, then the callback work: the index must score with the new centroids, codes untouched
+    opt = torch.optim.SGD([model.centroids], lr=0.05)
+    opt.step()
+    jpq_step_end(jpq)
+    assert index.codes.data_ptr() == codes_ptr
+    sc, idn = index.search(qe.contiguous(), 10)
+    brute = qe @ ops_decode_all(index, model.centroids.detach()).T
+    ws, wi = brute.topk(10, dim=1)
+    torch.testing.assert_close(sc, ws, rtol=1e-4, atol=1e-4)
+    assert float((idn == wi).float().mean()) > 0.95          # ties / last-ulp order may differ from the dense GEMM
+
+
+def ops_decode_all(index, centroids):
+    from repconc_amd import ops
+    return ops.decode_raw(index.codes.contiguous(), centroids.contiguous())
