@@ -8,8 +8,8 @@ What the reference does per step (models/repconc/finetune_repconc.py:245-396, Ap
   4. second forward WITH grad, chunk by chunk, same dropout masks; the cached g is applied as a surrogate
      <g, x> to the continuous embedding (straight-through) and, for documents, <g, decode(codes)> (-> centroids) plus
      `mse_loss_weight * mean ||decode(codes) - x||^2` (:346-396).
-This module restates that recipe for ONE process (the cross-rank gather of representations, :331-335, is left to the
-caller) so that the kernels behind `quantize` / `decode` can be exercised inside a real optimisation step.  It is harness
+This module restates that recipe, including the cross-rank gather of representations (:296-303,:331-335) when
+torch.distributed is initialised, so that the kernels behind `quantize` / `decode` can be exercised inside a real optimisation step.  It is harness
 code: all arithmetic on the hot path is still `repconc_amd.ops`.
 """
 from __future__ import annotations
@@ -18,6 +18,7 @@ from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch
+import torch.distributed as dist
 import torch.nn.functional as F
 
 
@@ -95,9 +96,48 @@ def contrastive_loss(query_embeds, doc_embeds, qids, docids, qrels, cfg: Stage1C
     return F.cross_entropy(sim, labels)
 
 
+def _all_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate every rank's rows in rank order (the reference's `gather_tensors`, finetune_repconc.py:297-300)."""
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    return torch.cat(parts, 0)
+
+
+def global_loss_and_local_grads(q_rep, pos_quant, neg_quant, qids, pos_docids, neg_docids, qrels, cfg: "Stage1Config",
+                                metric, M: int, group=None):
+    """Loss of the GLOBAL batch and its gradient w.r.t. this rank's rows (finetune_repconc.py:296-303,325-341).
+
+    With torch.distributed initialised every rank contributes its query / quantised-document representations (and ids);
+    the contrastive loss runs over all queries x all documents (gathered positives first, then gathered negatives, as
+    the reference stacks them), and the slices of the gradient cache that belong to the local rows are returned:
+    (loss, g_query, g_pos, g_neg|None).  Equal row counts per rank, as the reference's DistributedSampler gives."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if multi else 0
+    g = (lambda t: _all_rows(t, group)) if multi else (lambda t: t)
+    nq, np_ = q_rep.shape[0], pos_quant.shape[0]
+    nn_ = 0 if neg_quant is None else neg_quant.shape[0]
+    q_leaf = g(q_rep.detach()).requires_grad_(True)
+    docs = g(pos_quant.detach())
+    docids = g(pos_docids)
+    if neg_quant is not None:
+        docs = torch.cat([docs, g(neg_quant.detach())], 0)
+        docids = torch.cat([docids, g(neg_docids)])
+    d_leaf = docs.requires_grad_(True)
+    loss = contrastive_loss(q_leaf, d_leaf, g(qids), docids, qrels, cfg, metric, M)
+    loss.backward()
+    world = dist.get_world_size(group) if multi else 1
+    g_q = q_leaf.grad[rank * nq:(rank + 1) * nq]
+    g_p = d_leaf.grad[rank * np_:(rank + 1) * np_]
+    g_n = d_leaf.grad[world * np_ + rank * nn_: world * np_ + (rank + 1) * nn_] if neg_quant is not None else None
+    return loss.detach(), g_q, g_p, g_n
+
+
 def stage1_training_step(model, query_input, pos_doc_input, qids, pos_docids, qrels, cfg: Stage1Config,
-                         neg_doc_input=None, neg_docids=None) -> float:
-    """One forward/backward of stage-1 training; gradients are left in `.grad` (call optimizer.step() after)."""
+                         neg_doc_input=None, neg_docids=None, group=None) -> float:
+    """One forward/backward of stage-1 training; gradients are left in `.grad` (call optimizer.step() after).
+    Under torch.distributed the constrained quantisation already spans the global batch (`model.quantize`) and the loss
+    is taken over the gathered representations (`global_loss_and_local_grads`)."""
     model.train()
     q_chunks = _chunks(query_input, cfg.cache_chunk_size)
     p_chunks = _chunks(pos_doc_input, cfg.cache_chunk_size)
@@ -113,17 +153,14 @@ def stage1_training_step(model, query_input, pos_doc_input, qids, pos_docids, qr
     with torch.no_grad():
         codes = model.quantize(docs)                                     # the hot path (constrained if enabled)
         quantized = model.decode(codes)
-    # loss on (query, quantised docs); gradients w.r.t. the representations only
-    q_leaf = q_rep.detach().requires_grad_(True)
-    d_leaf = quantized.detach().requires_grad_(True)
-    loss = contrastive_loss(q_leaf, d_leaf, qids, docids, qrels, cfg, getattr(model.config, "similarity_metric", None),
-                            model.config.MCQ_M)
-    loss.backward()
-    g_q, g_d = q_leaf.grad, d_leaf.grad
+    # loss on (query, quantised docs) of the global batch; gradients w.r.t. the local representations only
     np_ = p_rep.shape[0]
-    plan = [(q_chunks, g_q, q_rng, None), (p_chunks, g_d[:np_], p_rng, codes[:np_])]
+    loss, g_q, g_p, g_n = global_loss_and_local_grads(
+        q_rep, quantized[:np_], quantized[np_:] if n_chunks else None, qids, pos_docids, neg_docids if n_chunks else None,
+        qrels, cfg, getattr(model.config, "similarity_metric", None), model.config.MCQ_M, group)
+    plan = [(q_chunks, g_q, q_rng, None), (p_chunks, g_p, p_rng, codes[:np_])]
     if n_chunks:
-        plan.append((n_chunks, g_d[np_:], n_rng, codes[np_:]))
+        plan.append((n_chunks, g_n, n_rng, codes[np_:]))
     for chunks, grads, rngs, doc_codes in plan:
         off = 0
         for ch, rng in zip(chunks, rngs):

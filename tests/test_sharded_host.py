@@ -112,3 +112,47 @@ def test_gloo_kmeans_statistics_all_gather_is_rank_identical():
     sums, counts = pq_oracle.kmeans_stats(x[:n], codes, C.shape[0])
     assert np.array_equal(c0, counts)
     np.testing.assert_allclose(s0, sums, rtol=1e-12, atol=1e-12)
+
+
+def _loss_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from repconc_amd.train.stage1 import Stage1Config, global_loss_and_local_grads
+    data = _loss_case()
+    nq, np_, nn_ = data["q"].shape[0] // world, data["pos"].shape[0] // world, data["neg"].shape[0] // world
+    sl = lambda t, n: t[rank * n:(rank + 1) * n]
+    loss, gq, gp, gn = global_loss_and_local_grads(
+        sl(data["q"], nq), sl(data["pos"], np_), sl(data["neg"], nn_), sl(data["qids"], nq), sl(data["pos_ids"], np_),
+        sl(data["neg_ids"], nn_), data["qrels"], Stage1Config(dynamic_topk_hard_negative=5), "METRIC_IP", 8)
+    ret[rank] = (float(loss), gq.numpy().copy(), gp.numpy().copy(), gn.numpy().copy())
+    dist.destroy_process_group()
+
+
+def _loss_case():
+    g = torch.Generator().manual_seed(5)
+    nq, nn_ = 8, 16
+    return {"q": torch.randn(nq, 32, generator=g), "pos": torch.randn(nq, 32, generator=g),
+            "neg": torch.randn(nn_, 32, generator=g), "qids": torch.arange(nq), "pos_ids": torch.arange(100, 100 + nq),
+            "neg_ids": torch.tensor([100, 201, 202, 203, 204, 205, 206, 207, 208, 209, 210, 211, 212, 213, 214, 103]),
+            "qrels": {i: [100 + i, 300 + i] for i in range(nq)} | {0: [100, 201]}}
+
+
+def test_gloo_stage1_global_loss_local_gradient_slices():
+    """N2: two ranks each hold half of the queries / positives / negatives; the loss is the global-batch loss and every
+    rank's gradient slices equal the matching rows of the single-process gradients (finetune_repconc.py:296-303)."""
+    from repconc_amd.train.stage1 import Stage1Config, global_loss_and_local_grads
+    data = _loss_case()
+    loss, gq, gp, gn = global_loss_and_local_grads(data["q"], data["pos"], data["neg"], data["qids"], data["pos_ids"],
+                                                   data["neg_ids"], data["qrels"],
+                                                   Stage1Config(dynamic_topk_hard_negative=5), "METRIC_IP", 8)
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_loss_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        parts = [ret[r] for r in range(world)]
+    for r in range(world):
+        assert abs(parts[r][0] - float(loss)) < 1e-6
+    np.testing.assert_allclose(np.concatenate([p[1] for p in parts]), gq.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(np.concatenate([p[2] for p in parts]), gp.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(np.concatenate([p[3] for p in parts]), gn.numpy(), rtol=1e-6, atol=1e-7)
