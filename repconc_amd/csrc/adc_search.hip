@@ -16,14 +16,16 @@
 //   4. full scan, rows with score >= tau_q are appended (wave-aggregated atomics) to a per-query candidate
 //      list of 64-bit keys.  Two implementations with IDENTICAL output:
 //        a. adc_scan_kernel<FILTER>: exact fp32 scores for every row (small indexes);
-//        b. integer screening (N >= 2^18): adc_qlut_kernel quantises each query's tables to 8 bits with a
-//           common step Delta_q (l = floor((LUT - min_m)/Delta_q)); adc_screen_kernel sums the bytes of 8
-//           queries per LDS gather (one ds_read_b64 serves 8 queries instead of 2) and keeps every row with
-//           S_int >= T_q, where T_q = ceil((tau_q - sum_m min_m)/Delta_q) - (M+2) is a RIGOROUS lower bound
-//           (sum of the M floor errors < M, plus float rounding), so no row with exact score >= tau_q is ever
-//           lost; adc_rescore_kernel then computes the exact fp32 score of the survivors (~1.7x the final
-//           candidates) and applies the exact test.  The candidate set, hence the result, is the same as (a).
-//   5. adc_select_kernel     per query: bitonic sort of the candidates in LDS, emit top-k
+//        b. integer screening (N >= 2^18, k <= 2048): adc_qlut_kernel quantises each query's tables to 8 bits with a
+//           common step Delta_q (l = floor((LUT - min_m)/Delta_q)); the screen kernel sums the bytes of 8 queries per
+//           LDS gather (one ds_read_b64 serves 8 queries instead of 2) — adc_screen_mfma_kernel on the matrix cores
+//           (v_mfma_i32_32x32x32_i8 against a selection matrix; two table phases for M > 64), adc_screen_kernel on
+//           the VALU for M % 8 != 0 — and keeps every row with S_int >= T_q, where
+//           T_q = ceil((tau_q - sum_m min_m)/Delta_q) - (M+2) is a RIGOROUS lower bound (sum of the M floor errors
+//           < M, plus float rounding), so no row with exact score >= tau_q is ever lost; adc_rescore_kernel then
+//           computes the exact fp32 score of the survivors (~1.7x the final candidates) and applies the exact test.
+//           The candidate set, hence the result, is the same as (a).
+//   5. adc_select_kernel     per query: radix-select cut to the k best scores (+ties), bitonic sort in LDS, emit top-k
 //
 // The scan is the hot kernel.  A block keeps the LUTs of QT queries in LDS, interleaved
 // [m][k][QT] so ONE ds_read_b64 / b128 gather serves QT queries, and streams a tile of codes
