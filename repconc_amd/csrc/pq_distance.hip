@@ -94,7 +94,7 @@ __global__ __launch_bounds__(RC_K) void dist_table_kernel(const float* __restric
     for (int64_t b = b0; b < b1; ++b) {
         const float* xr = x + b * ldx + m * DSUB;  // wave-uniform address
         const float s = sqdist_exact<DSUB>(xr, c);
-        *drow = s;
+        __builtin_nontemporal_store(s, drow);              // 2.4 GB written once, next read by another kernel
         drow += RC_K;
         mx = fmaxf(mx, s);
         mn = fminf(mn, s);
@@ -155,12 +155,14 @@ __global__ __launch_bounds__(256) void centre_kernel(float* __restrict__ d, cons
     const int64_t n4 = per_m / 4;  // per_m = B*256 is a multiple of 4
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
-        float4 v = p[i];
+        typedef float c_f4 __attribute__((ext_vector_type(4)));
+        c_f4* pv = reinterpret_cast<c_f4*>(p + i);
+        c_f4 v = __builtin_nontemporal_load(pv);           // streamed: read once, written once
         v.x = (v.x - mid) / amp;
         v.y = (v.y - mid) / amp;
         v.z = (v.z - mid) / amp;
         v.w = (v.w - mid) / amp;
-        p[i] = v;
+        __builtin_nontemporal_store(v, pv);
     }
 }
 

