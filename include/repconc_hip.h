@@ -93,7 +93,8 @@ int rc_pq_assign_nearest_fast_overflow(rc_handle_t h, const void* ws, int64_t B,
 /* ------------------------------------------------------------------ a-1
  * Distance table d[M,B,K] fp32 (modeling_repconc.py:50) and, if minmax != NULL, the per-m
  * maximum (minmax[0..M)) and minimum (minmax[M..2M)) over (b,k) (:76-77).
- * ws: rc_pq_dist_table_ws_bytes(B, M) bytes of scratch (block partials). */
+ * ws: rc_pq_dist_table_ws_bytes(B, M) bytes of scratch (block partials).  x must be 16-byte aligned with ldx % 4 == 0
+ * (the same holds for the assign_sinkhorn entry points, which start with this table). */
 size_t rc_pq_dist_table_ws_bytes(int64_t B, int M);
 int rc_pq_dist_table(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
                      int M, int K, float* d, float* minmax, void* ws, size_t ws_bytes,
