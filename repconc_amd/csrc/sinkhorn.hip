@@ -61,16 +61,28 @@
 // added to n as an INTEGER; the residual factor 2^(rg/N), rg = g_b N/ln2 - gq, is common to the whole
 // column, cancels in w/colsum, and is restored when g is updated:
 //     log(colsum_true) = log(colsum_stored) + rg ln2/N.
-__device__ __forceinline__ double sk_exp2n(double u, int gq, const double* __restrict__ tab) {
+// gq8 = 8 * gq: the column exponent arrives pre-multiplied by the table's entry size, so that ONE v_lshl_add gives
+// 8 (n + gq), one v_and its byte offset into the table (which sits at LDS address 0 of the dynamic segment) and one
+// shift the power of two — 3 integer instructions per entry instead of 4 (add, and, lshl_add, ashr).
+__device__ __forceinline__ double sk_exp2n(double u, int gq8, const double* __restrict__ tab) {
     constexpr double Z = SK_LN2 / (double)SK_N;
     const double n = __builtin_rint(u);
     const double r = u - n;
-    const int ni = (int)n + gq;
-    const double T = tab[ni & (SK_N - 1)];
+    const int ni8 = ((int)n << 3) + gq8;
+    // the table is the first thing in the kernel's (dynamic-only) LDS segment, i.e. at LDS address 0 — checked once per
+    // block by sk_assert_table_at_lds0 — so the masked value IS the ds_read address (no base add)
+    (void)tab;
+    typedef const double __attribute__((address_space(3))) sk_lds_cd;
+    const double T = *reinterpret_cast<sk_lds_cd*>(static_cast<unsigned>(ni8 & ((SK_N - 1) << 3)));
     double q = __builtin_fma(Z * Z * Z / 6.0, r, Z * Z / 2.0);
     q = __builtin_fma(q, r, Z);
     q = q * r;
-    return __builtin_ldexp(__builtin_fma(T, q, T), ni >> SK_TB);
+    return __builtin_ldexp(__builtin_fma(T, q, T), ni8 >> (SK_TB + 3));
+}
+
+__device__ __forceinline__ void sk_assert_table_at_lds0(const double* tab) {
+    // a generic pointer into LDS is {shared aperture, byte offset}: the low 32 bits are the LDS address
+    if (static_cast<unsigned>(reinterpret_cast<uintptr_t>(tab)) != 0u) __builtin_trap();
 }
 
 __device__ __forceinline__ int sk_kidx(int lane, int i) { return ((i >> 2) << 6) + (lane << 2) + (i & 3); }
@@ -89,14 +101,14 @@ __device__ __forceinline__ void sk_load_col(const float* __restrict__ p, float (
 
 // One column step (t >= 1): exponentials, column sum, normalised row-sum update.
 __device__ __forceinline__ void sk_column(const float (&x)[SK_EPL], const double (&fk)[SK_EPL],
-                                          double (&R)[SK_EPL], int gq, double nscale_eps,
+                                          double (&R)[SK_EPL], int gq8, double nscale_eps,
                                           const double* __restrict__ tab, double* __restrict__ csum_out,
                                           bool writer) {
     double w[SK_EPL];
     double c = 0.0;
 #pragma unroll
     for (int i = 0; i < SK_EPL; ++i) {
-        w[i] = sk_exp2n(__builtin_fma((double)x[i], nscale_eps, fk[i]), gq, tab);
+        w[i] = sk_exp2n(__builtin_fma((double)x[i], nscale_eps, fk[i]), gq8, tab);
         c += w[i];
     }
     c = rc_row16_allreduce_sum(c);
@@ -139,6 +151,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
     const int64_t c1 = (c0 + cols_per_block < B) ? c0 + cols_per_block : B;
     const int ncols = (int)(c1 - c0);
 
+    sk_assert_table_at_lds0(tab);
     for (int i = tid; i < SK_N; i += SK_THREADS) tab[i] = exp2_tab[i];
     if constexpr (!FIRST) {
         // ---- updates that follow sweep t-1 (modeling_repconc.py:157-158 and :162) ----
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
                 bad |= !(c > 0.0) || !(c < INFINITY);
             }
             gm[j] = gn;
-            gq_lds[j] = (int)__builtin_rint(gn * scale);
+            gq_lds[j] = (int)__builtin_rint(gn * scale) << 3;     // pre-multiplied by 8 (sk_exp2n)
         }
         if (__any(bad) && (tid & 63) == 0) atomicOr(flags, RC_FLAG_NONFINITE);
     }
