@@ -7,7 +7,7 @@
 #include <new>
 
 // ------------------------------------------------------------------------------------------ handle
-extern "C" int rc_version(void) { return 100; }
+extern "C" int rc_version(void) { return 101; }   // 101: + rc_pq_assign_nearest_fast, rc_index_*, RC_ESELECT
 
 extern "C" const char* rc_error_string(int code) {
     switch (code) {
