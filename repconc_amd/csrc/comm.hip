@@ -187,7 +187,9 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
         RC_NCCL_CHECK(h, n->AllReduce(minmax, minmax, (size_t)M, ncclFloat, ncclMax, (ncclComm_t)h->comm[0], s0));
         RC_NCCL_CHECK(h, n->AllReduce(minmax + M, minmax + M, (size_t)M, ncclFloat, ncclMin, (ncclComm_t)h->comm[0], s0));
     }
-    if ((rc = rc_pq_centre(h, d, minmax, B, M, RC_K, (rc_stream_t)s0)) != RC_OK) return rc;
+    // centring: fused into the first sweep (one pass over the table less); RC_FUSE_CENTRE=0 keeps the separate kernel
+    static const bool fuse_centre = !(getenv("RC_FUSE_CENTRE") && atoi(getenv("RC_FUSE_CENTRE")) == 0);
+    if (!fuse_centre && (rc = rc_pq_centre(h, d, minmax, B, M, RC_K, (rc_stream_t)s0)) != RC_OK) return rc;
 
     hipStream_t st[2] = {s0, s0};
     if (L.nch == 2) {
@@ -208,9 +210,14 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
             double* out = gath + (size_t)(t & 1) * gsz;
             // one rank: the sweep writes its row sums straight into the "gathered" slot
             double* rows = (G > 1) ? (double*)(w + cw.rows) : out;
-            if ((rc = rc_sk_sweep(h, dc, prev, G, (double*)(w + cw.f2), (double*)(w + cw.g), (double*)(w + cw.colsum),
-                                  rows, B, mc, RC_K, eps, t, flags, w + cw.sweep, rc_sk_ws_bytes(B, mc, RC_K),
-                                  (rc_stream_t)st[c])) != RC_OK) return rc;
+            if (t == 0 && fuse_centre)
+                rc = rc_sk_sweep0_centre(h, d + (size_t)L.m0[c] * B * RC_K, minmax + L.m0[c], minmax + M + L.m0[c],
+                                         (double*)(w + cw.g), (double*)(w + cw.colsum), rows, B, mc, eps, flags,
+                                         w + cw.sweep, rc_sk_ws_bytes(B, mc, RC_K), st[c]);
+            else
+                rc = rc_sk_sweep(h, dc, prev, G, (double*)(w + cw.f2), (double*)(w + cw.g), (double*)(w + cw.colsum), rows,
+                                 B, mc, RC_K, eps, t, flags, w + cw.sweep, rc_sk_ws_bytes(B, mc, RC_K), (rc_stream_t)st[c]);
+            if (rc != RC_OK) return rc;
             if (G > 1)
                 RC_NCCL_CHECK(h, n->AllGather(rows, out, (size_t)mc * RC_K, ncclDouble, (ncclComm_t)h->comm[c], st[c]));
         }

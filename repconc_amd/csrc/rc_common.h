@@ -31,6 +31,9 @@ size_t rc_solve_ws_bytes(int64_t B, int M, int world);
 int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D, int M, double eps,
                     int iters, int world, uint8_t* codes_u8, int64_t* codes_i64, int* flags, void* ws, size_t ws_bytes,
                     hipStream_t s0);
+int rc_sk_sweep0_centre(rc_handle_t h, float* d, const float* mx, const float* mn, double* g, double* colsum,
+                        double* rows_out, int64_t B, int M, double eps, int* flags, void* ws, size_t ws_bytes,
+                        hipStream_t s);
 int rc_sk_argmax_strided(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2, int64_t B,
                          int M, double eps, int t, int code_stride, int m_offset, uint8_t* codes_u8,
                          int64_t* codes_i64, int* flags, hipStream_t s);

@@ -99,6 +99,20 @@ __device__ __forceinline__ void sk_load_col(const float* __restrict__ p, float (
     }
 }
 
+// centre 16 entries of a column in place and write them back (same addresses as sk_load_col)
+__device__ __forceinline__ void sk_centre_store(float* __restrict__ p, float (&v)[SK_EPL], float mid, float amp) {
+    typedef float sk_f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < SK_EPL / 4; ++j) {
+        sk_f4 a;
+        a.x = v[4 * j] = (v[4 * j] - mid) / amp;
+        a.y = v[4 * j + 1] = (v[4 * j + 1] - mid) / amp;
+        a.z = v[4 * j + 2] = (v[4 * j + 2] - mid) / amp;
+        a.w = v[4 * j + 3] = (v[4 * j + 3] - mid) / amp;
+        __builtin_nontemporal_store(a, reinterpret_cast<sk_f4*>(p) + 16 * j);
+    }
+}
+
 // One column step (t >= 1): exponentials, column sum, normalised row-sum update.
 __device__ __forceinline__ void sk_column(const float (&x)[SK_EPL], const double (&fk)[SK_EPL],
                                           double (&R)[SK_EPL], int gq8, double nscale_eps,
@@ -130,12 +144,18 @@ __device__ __forceinline__ double sk_row_potential(const double* __restrict__ ro
 }
 
 // One sweep.  grid = (blocks per m, M).  Dynamic LDS: tab[N] | red[16][256] | fk[256] | gq[cpb] | flag.
-template <bool FIRST>
+// CENTRE (first sweep only): d holds the RAW distance table; every entry is centred on the fly exactly like
+// centre_kernel — (d - mid)/amp, IEEE division, range from cmx/cmn (modeling_repconc.py:81-84) — stored back (the
+// later sweeps read the centred table) and used at once: one pass over the table instead of centre_kernel's
+// read + write followed by the first sweep's read.
+template <bool FIRST, bool CENTRE = false>
 __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
     const float* __restrict__ d, const double* __restrict__ rows_prev, int G, const double* __restrict__ f_in,
     double* __restrict__ f_out, double* __restrict__ g, double* __restrict__ colsum, double* __restrict__ part,
     unsigned* __restrict__ counters, double* __restrict__ rows_out, int64_t B, int cols_per_block,
-    double nscale_eps, double scale, const double* __restrict__ exp2_tab, int t, int* __restrict__ flags) {
+    double nscale_eps, double scale, const double* __restrict__ exp2_tab, int t, int* __restrict__ flags,
+    const float* __restrict__ cmx = nullptr, const float* __restrict__ cmn = nullptr) {
+    static_assert(FIRST || !CENTRE, "centring is fused into the first sweep only");
     extern __shared__ __attribute__((aligned(16))) double sk_smem[];
     double* tab = sk_smem;                                                   // [N]
     double(*red)[RC_K] = reinterpret_cast<double(*)[RC_K]>(sk_smem + SK_N);  // [16][256]
@@ -187,6 +207,12 @@ __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
     }
     const float* dm = d + (size_t)m * B * RC_K + lane * 4;
     double* cm = colsum + (size_t)m * B;
+    float cmid = 0.f, camp = 1.f;
+    if constexpr (CENTRE) {
+        const float mx = cmx[m], mn = cmn[m];
+        cmid = (mx + mn) / 2.0f;                                  // centre_kernel's arithmetic, pq_distance.hip
+        camp = (mx - cmid) + 1e-5f;
+    }
 
     // two columns per trip; the register buffers ping-pong so prefetched data is never copied
     float xa[SK_EPL], xb[SK_EPL];
@@ -196,6 +222,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
         const int64_t colb = col + SK_NG;
         if (colb < c1) sk_load_col(dm + colb * RC_K, xb);
         if constexpr (FIRST) {
+            if constexpr (CENTRE) sk_centre_store(const_cast<float*>(dm) + col * RC_K, xa, cmid, camp);
 #pragma unroll
             for (int i = 0; i < SK_EPL; ++i) R[i] += sk_exp2n((double)xa[i] * nscale_eps, 0, tab);
         } else {
@@ -205,6 +232,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
         const int64_t cola = colb + SK_NG;
         if (cola < c1) sk_load_col(dm + cola * RC_K, xa);
         if constexpr (FIRST) {
+            if constexpr (CENTRE) sk_centre_store(const_cast<float*>(dm) + colb * RC_K, xb, cmid, camp);
 #pragma unroll
             for (int i = 0; i < SK_EPL; ++i) R[i] += sk_exp2n((double)xb[i] * nscale_eps, 0, tab);
         } else {
@@ -375,6 +403,29 @@ extern "C" int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_pre
                            colsum, part, counters, rows_out, B, cpb, nse, scale, tab, t, flags);
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
     }
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+// First sweep with the centring fused in: d is the RAW table of M sub-quantisers, mx / mn their (global) maxima and
+// minima.  Equivalent to rc_pq_centre followed by rc_sk_sweep(t = 0).
+int rc_sk_sweep0_centre(rc_handle_t h, float* d, const float* mx, const float* mn, double* g, double* colsum,
+                        double* rows_out, int64_t B, int M, double eps, int* flags, void* ws, size_t ws_bytes,
+                        hipStream_t s) {
+    const sk_sweep_ws W = sk_ws(B, M);
+    if (!ws || ws_bytes < W.total) return RC_EWORKSPACE;
+    const double* tab = rc_exp2_table(h, SK_TB);
+    if (!tab) return RC_EHIP;
+    double* part = (double*)((char*)ws + W.part);
+    unsigned* counters = (unsigned*)((char*)ws + W.counters);
+    const int cpb = sk_cols_per_block(B, M);
+    const int64_t nblk = (B + cpb - 1) / cpb;
+    const double scale = sk_scale();
+    const size_t lds = ((size_t)SK_N + SK_NG * RC_K + RC_K) * sizeof(double) + (SK_MAX_CPB + 4) * sizeof(int);
+    RC_HIP_CHECK(h, hipMemsetAsync(counters, 0, (size_t)M * sizeof(unsigned), s));
+    hipLaunchKernelGGL((sk_sweep_kernel<true, true>), dim3((unsigned)nblk, (unsigned)M), dim3(SK_THREADS), lds, s,
+                       (const float*)d, (const double*)nullptr, 1, (const double*)nullptr, (double*)nullptr, g, colsum,
+                       part, counters, rows_out, B, cpb, -scale / eps, scale, tab, 0, flags, mx, mn);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
