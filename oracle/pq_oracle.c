@@ -248,10 +248,27 @@ void orc_adc_search(const uint8_t* codes, int64_t N, int M, int dsub, const floa
                     lut[m * K + kk] = s;
                 }
             int hn = 0;
+            /* four rows at a time (independent accumulators, like Faiss's PQ scanner): each row's sum keeps its own
+             * m-ascending order, so the scores are bit-identical to the one-row loop */
+            float s4[4];
             for (int64_t n = 0; n < N; ++n) {
-                const uint8_t* cp = codes + n * M;
-                float s = 0.f;
-                for (int m = 0; m < M; ++m) s = s + lut[m * K + cp[m]];
+                if ((n & 3) == 0) {
+                    const int64_t left = N - n < 4 ? N - n : 4;
+                    const uint8_t* c0 = codes + n * M;
+                    const uint8_t* c1 = c0 + (left > 1 ? M : 0);
+                    const uint8_t* c2 = c0 + (left > 2 ? 2 * M : 0);
+                    const uint8_t* c3 = c0 + (left > 3 ? 3 * M : 0);
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int m = 0; m < M; ++m) {
+                        const float* t = lut + m * K;
+                        a0 = a0 + t[c0[m]];
+                        a1 = a1 + t[c1[m]];
+                        a2 = a2 + t[c2[m]];
+                        a3 = a3 + t[c3[m]];
+                    }
+                    s4[0] = a0; s4[1] = a1; s4[2] = a2; s4[3] = a3;
+                }
+                const float s = s4[n & 3];
                 hit_t h = {s, n};
                 if (hn < k) {
                     heap[hn++] = h;
