@@ -359,6 +359,17 @@ def main():
                           "orc_adc_search (Faiss-style: per-query LUT, linear scan four rows at a time, size-k heap, one "
                           "query per thread)"}
             out["adc"]["speedup_vs_cpu_baseline"] = round(out["adc"]["value"] / qps_c, 1)
+            # the reference's own evaluation default is ONE Faiss thread (EvalArguments.threads = 1,
+            # evaluate_repconc.py:37; run_repconc_eval.py:149): 3 queries over the whole index on one core
+            c_oracle.set_num_threads(1)
+            t0 = time.perf_counter()
+            c_oracle.adc_search(sl, cent, qc[:3], k)
+            adt_1 = time.perf_counter() - t0
+            c_oracle.set_num_threads(cores)
+            out["adc"]["cpu_baseline_single_thread"] = {
+                "value": round(3 / adt_1, 3), "unit": "queries/s", "cores": 1, "kind": "port",
+                "sample": f"3 queries over the whole index on one thread ({adt_1:.1f} s) - the reference's eval default "
+                          "threads=1"}
 
     if use_dist:
         dist.destroy_process_group()

@@ -35,6 +35,11 @@ def num_threads():
     return lib().orc_num_threads()
 
 
+def set_num_threads(n: int):
+    """OpenMP thread count of the C restatement (the reference's eval default is ONE Faiss thread, evaluate_repconc.py:37)."""
+    lib().orc_set_num_threads(int(n))
+
+
 def quantize(x, centroids, use_constraint, eps=0.003, iters=100):
     x = np.ascontiguousarray(x, np.float32)
     Cn = np.ascontiguousarray(centroids, np.float32)
