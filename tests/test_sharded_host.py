@@ -156,3 +156,23 @@ def test_gloo_stage1_global_loss_local_gradient_slices():
     np.testing.assert_allclose(np.concatenate([p[1] for p in parts]), gq.numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(np.concatenate([p[2] for p in parts]), gp.numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(np.concatenate([p[3] for p in parts]), gn.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_merge_topk_order_and_ties_on_cpu():
+    """sharded_search.merge_topk is pure tensor bookkeeping: merged lists are (score desc, id asc), empty slots (-1) sort
+    last, and the result equals a brute-force sort of the union."""
+    from repconc_amd.sharded_search import merge_topk
+    g = torch.Generator().manual_seed(3)
+    G, nq, k = 3, 5, 7
+    scores = torch.randint(0, 6, (G, nq, k), generator=g).float()            # few distinct values: many ties
+    ids = torch.stack([torch.stack([torch.randperm(1000, generator=g)[:k] + 1000 * r for _ in range(nq)]) for r in range(G)])
+    scores, order = torch.sort(scores, dim=2, descending=True)
+    ids = torch.gather(ids, 2, order)
+    scores[2, :, 5:] = float("-inf")
+    ids[2, :, 5:] = -1                                                        # a short shard
+    ms, mi = merge_topk(scores, ids, k)
+    for qi in range(nq):
+        items = [(float(scores[r, qi, j]), int(ids[r, qi, j])) for r in range(G) for j in range(k) if int(ids[r, qi, j]) >= 0]
+        items.sort(key=lambda t: (-t[0], t[1]))
+        assert [int(v) for v in mi[qi]] == [t[1] for t in items[:k]]
+        assert [float(v) for v in ms[qi]] == [t[0] for t in items[:k]]
