@@ -215,7 +215,7 @@ def main():
         n_chains = 2 if (world > 1 and M >= 2 and os.environ.get("RC_SHARD_SPLIT", "1") != "0") else 1
     alg_bytes = bl * (M // n_chains) * K * 4
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if n_l.value else 0.0
-    roofline = {"kernel": "sk_sweep_kernel<false, false> (Sinkhorn sweep incl. fused row/column updates)", "bound": "hbm", "achieved": round(achieved, 1),
+    roofline = {"kernel": "sk_sweep_kernel<false, false, true> (Sinkhorn sweep incl. fused row/column updates; 4 waves/SIMD variant)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic("sk_sweep_kernel"), "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(sweep_ms, 4), "launches_timed": n_l.value,

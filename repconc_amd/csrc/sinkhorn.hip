@@ -114,15 +114,23 @@ __device__ __forceinline__ void sk_centre_store(float* __restrict__ p, float (&v
 }
 
 // One column step (t >= 1): exponentials, column sum, normalised row-sum update.
+// Row potentials either in registers (fk, 32 VGPRs: 152 in total, three waves per SIMD) or re-read from LDS at use
+// (FKLDS: 120 VGPRs, four waves per SIMD; with the reduction scratch aliased onto the exp table the block needs 36 KiB
+// of LDS, so four blocks fit a CU).  Measured at 49 152 x 48: 0.470 vs 0.480 ms per sweep; at 6 144 rows per rank the
+// register variant is the (slightly) faster one, so the host picks by grid size.
+template <bool FKLDS>
 __device__ __forceinline__ void sk_column(const float (&x)[SK_EPL], const double (&fk)[SK_EPL],
-                                          double (&R)[SK_EPL], int gq8, double nscale_eps,
-                                          const double* __restrict__ tab, double* __restrict__ csum_out,
-                                          bool writer) {
+                                          const double* __restrict__ fk_lds, int lane, double (&R)[SK_EPL], int gq8,
+                                          double nscale_eps, const double* __restrict__ tab,
+                                          double* __restrict__ csum_out, bool writer) {
     double w[SK_EPL];
     double c = 0.0;
+    int ln = lane;
+    if constexpr (FKLDS) asm volatile("" : "+v"(ln));     // re-read from LDS every column (keeps the loads un-hoisted)
 #pragma unroll
     for (int i = 0; i < SK_EPL; ++i) {
-        w[i] = sk_exp2n(__builtin_fma((double)x[i], nscale_eps, fk[i]), gq8, tab);
+        const double fki = FKLDS ? fk_lds[sk_kidx(ln, i)] : fk[i];
+        w[i] = sk_exp2n(__builtin_fma((double)x[i], nscale_eps, fki), gq8, tab);
         c += w[i];
     }
     c = rc_row16_allreduce_sum(c);
@@ -148,18 +156,20 @@ __device__ __forceinline__ double sk_row_potential(const double* __restrict__ ro
 // centre_kernel — (d - mid)/amp, IEEE division, range from cmx/cmn (modeling_repconc.py:81-84) — stored back (the
 // later sweeps read the centred table) and used at once: one pass over the table instead of centre_kernel's
 // read + write followed by the first sweep's read.
-template <bool FIRST, bool CENTRE = false>
-__global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
+template <bool FIRST, bool CENTRE = false, bool FKLDS = false>
+__global__ __launch_bounds__(SK_THREADS, (FKLDS ? 4 : 3)) void sk_sweep_kernel(
     const float* __restrict__ d, const double* __restrict__ rows_prev, int G, const double* __restrict__ f_in,
     double* __restrict__ f_out, double* __restrict__ g, double* __restrict__ colsum, double* __restrict__ part,
     unsigned* __restrict__ counters, double* __restrict__ rows_out, int64_t B, int cols_per_block,
     double nscale_eps, double scale, const double* __restrict__ exp2_tab, int t, int* __restrict__ flags,
     const float* __restrict__ cmx = nullptr, const float* __restrict__ cmn = nullptr) {
     static_assert(FIRST || !CENTRE, "centring is fused into the first sweep only");
+    static_assert(!(FIRST && FKLDS), "the first sweep has no row potentials");
     extern __shared__ __attribute__((aligned(16))) double sk_smem[];
     double* tab = sk_smem;                                                   // [N]
-    double(*red)[RC_K] = reinterpret_cast<double(*)[RC_K]>(sk_smem + SK_N);  // [16][256]
-    double* fk_lds = sk_smem + SK_N + SK_NG * RC_K;                          // [256]
+    // FKLDS: the reduction scratch reuses the table's LDS (the table is dead by then): 36 KiB per block, 4 blocks per CU
+    double(*red)[RC_K] = reinterpret_cast<double(*)[RC_K]>(sk_smem + (FKLDS ? 0 : SK_N));   // [16][256]
+    double* fk_lds = sk_smem + (FKLDS ? 0 : SK_N) + SK_NG * RC_K;                           // [256]
     int* gq_lds = reinterpret_cast<int*>(fk_lds + RC_K);                     // [SK_MAX_CPB]
     int* last_flag = gq_lds + SK_MAX_CPB;
 
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
 #pragma unroll
             for (int i = 0; i < SK_EPL; ++i) R[i] += sk_exp2n((double)xa[i] * nscale_eps, 0, tab);
         } else {
-            sk_column(xa, fk, R, gq_lds[col - c0], nscale_eps, tab, cm + col, lane == 0);
+            sk_column<FKLDS>(xa, fk, fk_lds, lane, R, gq_lds[col - c0], nscale_eps, tab, cm + col, lane == 0);
         }
         if (colb >= c1) break;
         const int64_t cola = colb + SK_NG;
@@ -236,12 +246,13 @@ __global__ __launch_bounds__(SK_THREADS) void sk_sweep_kernel(
 #pragma unroll
             for (int i = 0; i < SK_EPL; ++i) R[i] += sk_exp2n((double)xb[i] * nscale_eps, 0, tab);
         } else {
-            sk_column(xb, fk, R, gq_lds[colb - c0], nscale_eps, tab, cm + colb, lane == 0);
+            sk_column<FKLDS>(xb, fk, fk_lds, lane, R, gq_lds[colb - c0], nscale_eps, tab, cm + colb, lane == 0);
         }
         col = cola;
     }
 
     // ---- block reduction of the row sums, fixed order over the 16 column groups ----
+    if constexpr (FKLDS) __syncthreads();                                    // every wave is done with the table
 #pragma unroll
     for (int i = 0; i < SK_EPL; ++i) red[grp][sk_kidx(lane, i)] = R[i];
     __syncthreads();
@@ -398,9 +409,17 @@ extern "C" int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_pre
     } else {
         const double* f_in = f2 + (size_t)((t - 1) & 1) * M * RC_K;
         double* f_out = f2 + (size_t)(t & 1) * M * RC_K;
+        // grids of >= 4 resident rounds' worth of blocks take the four-waves-per-SIMD variant (potentials from LDS)
+        static const int force_fklds = getenv("RC_SK_FKLDS") ? atoi(getenv("RC_SK_FKLDS")) : -1;
+        const bool fklds = force_fklds >= 0 ? force_fklds != 0 : (nblk * M >= 4096);
+        const size_t lds4 = ((size_t)SK_NG * RC_K + RC_K) * sizeof(double) + (SK_MAX_CPB + 4) * sizeof(int);
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
-        hipLaunchKernelGGL(sk_sweep_kernel<false>, grid, dim3(SK_THREADS), lds, s, d, rows_prev, G, f_in, f_out, g,
-                           colsum, part, counters, rows_out, B, cpb, nse, scale, tab, t, flags);
+        if (fklds)
+            hipLaunchKernelGGL((sk_sweep_kernel<false, false, true>), grid, dim3(SK_THREADS), lds4, s, d, rows_prev, G, f_in,
+                               f_out, g, colsum, part, counters, rows_out, B, cpb, nse, scale, tab, t, flags);
+        else
+            hipLaunchKernelGGL((sk_sweep_kernel<false, false, false>), grid, dim3(SK_THREADS), lds, s, d, rows_prev, G, f_in,
+                               f_out, g, colsum, part, counters, rows_out, B, cpb, nse, scale, tab, t, flags);
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
     }
     RC_LAUNCH_CHECK(h);

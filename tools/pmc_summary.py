@@ -10,7 +10,7 @@ raw = json.load(open(sys.argv[1]))
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 B, M, K, NC, NQ, NB = 49152, 48, 256, 8841823, 1200, 1 << 20
 ALG = {  # SURVEY 8(d) per-unit bytes x units per launch
-    "sk_sweep_kernel": ("sk_sweep_kernel<false, false>", B * M * K * 4),
+    "sk_sweep_kernel": ("sk_sweep_kernel<false, false, true>", B * M * K * 4),
     "adc_screen_mfma_kernel": ("adc_screen_mfma_kernel<48, 8>", NQ * NC * M),
     "assign_mfma_kernel": ("assign_mfma_kernel<16>", NB * (768 * 4 + M)),
 }
