@@ -47,6 +47,9 @@ extern "C" {
 #define RC_FLAG_NONFINITE 1 /* a row/column sum became 0, inf or NaN — the reference's   */
                             /* "Sinkhorn Algorithm returns nan/inf values" warning,      */
                             /* models/repconc/modeling_repconc.py:64-65                  */
+#define RC_FLAG_RANGE 2     /* |(L + f) N/ln2| left the range the sweep's integer split  */
+                            /* covers (eps < ~3e-4 on centred distances: the reference's */
+                            /* own exp(1/eps) overflows fp64 long before, at eps < 1.4e-3) */
 
 typedef struct rc_handle_s* rc_handle_t;
 typedef void* rc_stream_t;
@@ -123,7 +126,10 @@ int rc_pq_centre(rc_handle_t h, float* d, const float* minmax, int64_t B, int M,
  * constants /K, /B, the global normalisation of :152 and the last column normalisation cancel in the argmax.
  *
  * f2:       [2,M,K] fp64, potentials double-buffered by sweep parity (owned by the solve, no init needed)
- * g,colsum: [M,B] fp64 (no init needed)
+ * g,colsum: [M,B] fp64-sized scratch each (no init needed).  The column potentials never reach the result (w/colsum and
+ *           the argmax are independent of g), so the default sweep keeps them as int32 column exponents inside `g` and
+ *           leaves `colsum` untouched; the round-1 sweep (RC_SK_V1=1) stores fp64 g and colsum.  d must be a CENTRED
+ *           table (|d| <= 1, rc_pq_centre) — a wider table is rescaled together with eps by a power of two first.
  * rows_out: [M,K] fp64, this rank's row sums of the sweep
  * ws:       rc_sk_ws_bytes(B, M, K) bytes (block partials + arrival counters; sweep 0 resets the counters)
  * flags:    one int, OR-ed with RC_FLAG_* (caller zeroes it before sweep 0)
@@ -215,6 +221,22 @@ int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, 
                   int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,
                   float* scores, int64_t* ids, int* status, void* ws, size_t ws_bytes,
                   rc_stream_t stream);
+/* The same search with the index's PERMUTED CODE IMAGE supplied by the caller.  For M in {16,32,48,64,96} and
+ * N >= 2^18 the integer screen reads a second copy of the code matrix in which the bytes of row n are stored in the
+ * order its lanes visit the sub-quantisers (a fixed permutation that depends on n mod 16; csrc/adc_search.hip,
+ * "conflict-free screen": every LDS gather of the byte tables is then bank-conflict-free whatever the codes).
+ * rc_adc_scan_image_bytes(N, M): size of that image (0 = this M does not use one); rc_adc_scan_image converts rows
+ * [n0, n0+n) (call it after appending rows — evaluate_repconc.py:89-98); rc_adc_search_img takes it (NULL = rebuild it
+ * in the workspace on every call, which is what rc_adc_search does).  Results are identical with or without an image. */
+size_t rc_adc_scan_image_bytes(int64_t N, int M);
+/* layout introspection (host only, for tests): slot / phase-relative sub-quantiser read by `lane` in gather `step` */
+int rc_adc_cf_describe(int M, int lane, int step, int* slot, int* m, int* slots_per_code, int* phases);
+int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
+                      rc_stream_t stream);
+size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, int k);
+int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
+                      const float* C, int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,
+                      float* scores, int64_t* ids, int* status, void* ws, size_t ws_bytes, rc_stream_t stream);
 /* the look-up tables alone (test hook): lut [nq,M,K] fp32 */
 int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K,
                float* lut, rc_stream_t stream);

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("REPCONC_HIP_LIB") or os.path.join(_HERE, "lib", "libr
 RC_OK, RC_EINVAL, RC_ESHAPE, RC_EHIP, RC_EWORKSPACE, RC_ECOMM, RC_ESELECT = 0, -1, -2, -3, -4, -5, -6
 RC_CODE_U8, RC_CODE_I64 = 0, 1
 RC_FLAG_NONFINITE = 1
+RC_FLAG_RANGE = 2
 PROF_SK_PASS, PROF_ADC_SCAN, PROF_ASSIGN_NEAREST, PROF_DIST_TABLE = 0, 1, 2, 3
 
 _vp, _i, _i64, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double
@@ -56,6 +57,11 @@ PROTOTYPES = {
     "rc_kmeans_update": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rc_adc_search_ws_bytes": (_sz, [_i64, _i, _i, _i, _i]),
     "rc_adc_search": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rc_adc_scan_image_bytes": (_sz, [_i64, _i]),
+    "rc_adc_cf_describe": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "rc_adc_scan_image": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp]),
+    "rc_adc_search_img_ws_bytes": (_sz, [_i64, _i, _i, _i, _i]),
+    "rc_adc_search_img": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_ivf_search_ws_bytes": (_sz, [_i, _i64]),
     "rc_ivf_search": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_adc_lut": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

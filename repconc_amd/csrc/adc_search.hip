@@ -754,6 +754,272 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_mfma2_kernel(const uin
     }
 }
 
+// ---------------------------------------------------------------------------------- 4b'. conflict-free screen
+// Round-1 PMC on adc_screen_mfma_kernel<48,8>: 68 % of the LDS cycles of its random 8-byte gathers were bank conflicts
+// (6.3 cycles per ds_read_b64 instead of 2) and the selection-matrix MFMA (32x32x32, 8 useful columns of 32) kept the
+// matrix pipe busy half of the time.  Both go away with two observations:
+//
+//  * the sum over sub-quantisers is commutative (integer adds), so the lanes of a wave need not visit the sub-quantisers
+//    in the same order.  The byte tables are laid out [code][slot][8 queries] with one 8-byte SLOT per sub-quantiser —
+//    a slot's LDS bank pair is slot mod 32 whatever the code — and in every step the 32 lanes that the LDS services
+//    together (a ds_read_b64 is processed as lanes 0-31, then 32-63) read 32 DIFFERENT slots mod 32: lane (r, g) of a
+//    16-row chunk (r = row, g = lane quarter) walks block-relative sub-quantiser (r + (S/4) tau(g) + j) mod S in step j,
+//    S = 32 or 16 = size of the block of sub-quantisers, tau(g) = 2 (g & 1) + (g >> 1); a 16-block is stored twice
+//    (slots 16 apart) and lanes 16-31 of the group use the second copy.  The gathers are conflict-free BY CONSTRUCTION,
+//    for any codes.  The lane's codes must then arrive in its own visiting order: the index keeps a second, permuted
+//    image of the code matrix (rc_adc_scan_image; the permutation of row n depends on n mod 16 only), 1 byte per code.
+//  * v_mfma_i32_16x16x64_i8 takes 16 rows x 64 k-bytes (8 gathered entries per row) per 16 cycles instead of 32 rows x 32
+//    k-bytes (4 entries) per 32: twice the entries per matrix-pipe cycle for the same selection-matrix trick.
+//
+// Supported: sub-quantisers per table phase PM = 16, 32, 48, 64 (M = 96 runs two phases of 48, accumulators of 8 chunks
+// kept in registers across the table swap, phases visited in alternating order).  Everything downstream (rigorous integer
+// threshold, exact fp32 rescoring of the survivors from the canonical codes) is unchanged, so results stay bit-identical.
+template <int PM>
+struct adc_cf {
+    static_assert(PM % 16 == 0 && PM >= 16 && PM <= 64, "table phase of 16/32/48/64 sub-quantisers");
+    static constexpr int N32 = PM / 32, HAS16 = (PM % 32) / 16;
+    static constexpr int SLOTS = 32 * (N32 + HAS16);       // 8-byte slots per code: LDS row of SLOTS * 8 bytes
+    static constexpr int STEPS = PM / 4;                   // gathers per lane per 16-row chunk
+    static constexpr int TABLE_BYTES = RC_K * SLOTS * 8;
+};
+// step s (0 .. PM/4-1) of a lane -> size of the block of sub-quantisers it falls in, the block's first sub-quantiser
+// (= its first slot) and the step index inside the block.  32-blocks first, then the 16-block.
+__host__ __device__ constexpr int adc_cf_bsize(int PM, int s) { return s < 8 * (PM / 32) ? 32 : 16; }
+__host__ __device__ constexpr int adc_cf_bbase(int PM, int s) { return s < 8 * (PM / 32) ? 32 * (s / 8) : 32 * (PM / 32); }
+__host__ __device__ constexpr int adc_cf_bstep(int PM, int s) { return s < 8 * (PM / 32) ? s % 8 : s - 8 * (PM / 32); }
+// block-relative sub-quantiser that lane (r, g) reads in step j of a block of size S
+__host__ __device__ inline int adc_cf_mloc(int S, int j, int r, int g) {
+    return (r + (S >> 2) * (2 * (g & 1) + (g >> 1)) + j) & (S - 1);
+}
+// slot (within the phase's table) and sub-quantiser (within the phase) of step s for lane (r, g)
+__host__ __device__ inline void adc_cf_step(int PM, int s, int r, int g, int& slot, int& m) {
+    const int S = adc_cf_bsize(PM, s), base = adc_cf_bbase(PM, s), j = adc_cf_bstep(PM, s);
+    const int ml = adc_cf_mloc(S, j, r, g);
+    const int lam = r + 16 * (g & 1);                      // lane index inside the 32 lanes the LDS services together
+    m = base + ml;
+    slot = base + ml + S * (lam / S);                      // S = 16: second copy for lanes 16-31
+}
+
+// image[n][phase][g][s] = codes[n][phase * PM + m(s; n mod 16, g)] for rows n0 <= n < n0 + cnt
+__global__ __launch_bounds__(256) void adc_scan_image_kernel(const uint8_t* __restrict__ codes, int64_t n0, int64_t cnt,
+                                                             int M, int PM, uint8_t* __restrict__ image) {
+    const int64_t total = cnt * M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = n0 + i / M;
+        const int pos = (int)(i % M);
+        const int phase = pos / PM, rem = pos % PM;
+        const int g = rem / (PM / 4), st = rem % (PM / 4);
+        int slot, m;
+        adc_cf_step(PM, st, (int)(n & 15), g, slot, m);
+        image[n * M + pos] = codes[n * M + phase * PM + m];
+    }
+}
+
+// Byte tables of the conflict-free screen: [group of 8 queries][phase][code][slot][8], every copy of a 16-block filled.
+// One block per query, thread = code; quantisation exactly as adc_qlut_kernel.
+__global__ __launch_bounds__(RC_K) void adc_qlut_cf_kernel(const float* __restrict__ lut, const float* __restrict__ thr,
+                                                           int M, int PM, int slots, uint8_t* __restrict__ qlut,
+                                                           int* __restrict__ tint) {
+    __shared__ float lo_m[128];
+    __shared__ float red_lo[4], red_hi[4];
+    __shared__ float s_delta;
+    const int qi = blockIdx.x, c = threadIdx.x;
+    const float* lq = lut + (size_t)qi * M * RC_K;
+    float maxrange = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float v = lq[m * RC_K + c];
+        float lo = v, hi = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if ((c & 63) == 0) { red_lo[c >> 6] = lo; red_hi[c >> 6] = hi; }
+        __syncthreads();
+        lo = fminf(fminf(red_lo[0], red_lo[1]), fminf(red_lo[2], red_lo[3]));
+        hi = fmaxf(fmaxf(red_hi[0], red_hi[1]), fmaxf(red_hi[2], red_hi[3]));
+        if (c == 0) lo_m[m] = lo;
+        maxrange = fmaxf(maxrange, hi - lo);
+        __syncthreads();
+    }
+    if (c == 0) {
+        float delta = maxrange / 255.0f;
+        if (!(delta > 0.f)) delta = 1.0f;
+        s_delta = delta;
+        double A = 0.0;
+        for (int m = 0; m < M; ++m) A += (double)lo_m[m];
+        const float t = thr[qi];
+        int T;
+        if (t == -INFINITY) {
+            T = INT_MIN;
+        } else {
+            const double v = ceil(((double)t - A) / (double)delta) - (double)(M + 2);
+            T = v < -2.0e9 ? INT_MIN : (v > 2.0e9 ? INT_MAX : (int)v);
+        }
+        tint[qi] = T;
+    }
+    __syncthreads();
+    const float delta = s_delta;
+    const int NP = M / PM;
+    uint8_t* dst = qlut + (size_t)(qi / 8) * NP * RC_K * slots * 8 + (qi % 8);
+    for (int m = 0; m < M; ++m) {
+        const float v = (lq[m * RC_K + c] - lo_m[m]) / delta;
+        int l = (int)floorf(v);
+        l = l < 0 ? 0 : (l > 255 ? 255 : l);
+        const int phase = m / PM, mp = m % PM;
+        const int n32 = PM / 32;
+        uint8_t* row = dst + ((size_t)(phase * RC_K + c) * slots) * 8;
+        if (mp < 32 * n32) {
+            row[mp * 8] = (uint8_t)l;                                  // 32-block: slot = sub-quantiser
+        } else {
+            row[mp * 8] = (uint8_t)l;                                  // 16-block: two copies, 16 slots apart
+            row[(mp + 16) * 8] = (uint8_t)l;
+        }
+    }
+}
+
+typedef int adc_i32x4v __attribute__((ext_vector_type(4)));
+
+// grid (groups of 8 queries, row tiles of ADC_TILE_DOCS rows), XCD-remapped like the other screens.
+// A wave owns R chunks of 16 rows per round; lanes (r = l & 15, g = l >> 4).
+template <int M, int NP, int R>
+__global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_t* __restrict__ image, int64_t N,
+                                                                    const uint8_t* __restrict__ qlut,
+                                                                    const int* __restrict__ tint, int nq,
+                                                                    unsigned* __restrict__ id_count,
+                                                                    unsigned* __restrict__ ids) {
+    constexpr int PM = M / NP;
+    using L = adc_cf<PM>;
+    constexpr int STEPS = L::STEPS, NW = STEPS / 4;        // code dwords per lane per chunk and phase
+    static_assert(STEPS % 4 == 0, "whole dwords of codes per lane");
+    constexpr int NWAVES = ADC_THREADS / 64;
+    constexpr int ROUND = NWAVES * R * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    unsigned bgroup, btile;
+    adc_xcd_remap(bgroup, btile);
+    const int q0 = (int)bgroup * 8;
+    const uint8_t* qsrc = qlut + (size_t)bgroup * NP * L::TABLE_BYTES;
+    auto fill = [&](int phase) {
+        const uint4* src = reinterpret_cast<const uint4*>(qsrc + (size_t)phase * L::TABLE_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < L::TABLE_BYTES / 16; i += ADC_THREADS) {
+            uint4 v = src[i];
+            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;   // l -> l - 128 (signed)
+            dst[i] = v;
+        }
+    };
+    const int l = tid & 63, wv = tid >> 6;
+    const int r = l & 15, g = l >> 4;
+    int tq = INT_MAX;                                        // this lane's query = D column (l & 15)
+    if (r < 8 && q0 + r < nq) {
+        const int t = tint[q0 + r];
+        tq = (t == INT_MIN) ? INT_MIN : t - 128 * M;
+    }
+    adc_i32x4v bsel = {0, 0, 0, 0};                          // B[k][j = r] = [k % 8 == r], same bytes in every lane quarter
+    if (r < 8) {
+        const int one = 1 << (8 * (r & 3));
+        bsel[r >> 2] = one;
+        bsel[2 + (r >> 2)] = one;
+    }
+    unsigned off[STEPS];                                     // byte offset of this lane's slot in step s
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        int slot, m;
+        adc_cf_step(PM, s, r, g, slot, m);
+        off[s] = (unsigned)slot * 8u;
+    }
+    const int64_t t0 = (int64_t)btile * ADC_TILE_DOCS;
+    const int64_t t1 = (t0 + ADC_TILE_DOCS < N) ? t0 + ADC_TILE_DOCS : N;
+    // Flat sequence of steps it = round * NP + i; a round covers ROUND rows and visits the NP table phases, odd rounds in
+    // reverse order, so the tables already in LDS are used first (NP - 1 refills per round).  The codes of step it + 1 are
+    // loaded while step it is gathered (NP == 1; with two phases the eight chunks' codes are loaded at the start of the
+    // step — registers).
+    const int nrounds = (int)((t1 - t0 + ROUND - 1) / ROUND);
+    const int nsteps = nrounds * NP;
+    auto phase_of = [&](int it) { const int rd = it / NP, i = it % NP; return (rd & 1) ? NP - 1 - i : i; };
+    auto load_step = [&](int it, unsigned (&dst)[R][NW]) {
+        const int64_t r0 = t0 + (int64_t)(it / NP) * ROUND;
+        const int ph = phase_of(it);
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int64_t n = r0 + (int64_t)(wv * R + c) * 16 + r;
+            const unsigned* cp = reinterpret_cast<const unsigned*>(image + (n < t1 ? n : (t1 - 1)) * M + ph * PM + g * STEPS);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) dst[c][j] = cp[j];
+        }
+    };
+    constexpr bool PREFETCH = (NP == 1);
+    unsigned w[R][NW], wn[PREFETCH ? R : 1][NW];
+    int in_lds = -1;
+    if constexpr (PREFETCH) load_step(0, w);
+    adc_i32x4v acc[R];
+    for (int it = 0; it < nsteps; ++it) {                     // block-uniform
+        const int64_t r0 = t0 + (int64_t)(it / NP) * ROUND;
+        const int phase = phase_of(it);
+        if (it % NP == 0) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) acc[c] = adc_i32x4v{0, 0, 0, 0};
+        }
+        if (in_lds != phase) {
+            if (in_lds >= 0) __syncthreads();                 // every wave is done gathering from the old tables
+            fill(phase);
+            __syncthreads();
+            in_lds = phase;
+        }
+        if constexpr (PREFETCH) {
+            if (it + 1 < nsteps) load_step(it + 1, wn);
+        } else {
+            load_step(it, w);
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            if (r0 + (int64_t)(wv * R + c) * 16 < t1) {       // wave-uniform
+#pragma unroll
+                for (int s2 = 0; s2 < STEPS / 2; ++s2) {
+                    adc_i32x4v a;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int s = 2 * s2 + e;
+                        const unsigned code = (w[c][s >> 2] >> (8 * (s & 3))) & 0xFFu;
+                        const uint2 v = *reinterpret_cast<const uint2*>(smem + code * (L::SLOTS * 8) + off[s]);
+                        a[2 * e] = (int)v.x;
+                        a[2 * e + 1] = (int)v.y;
+                    }
+                    acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int c = 0; c < R; ++c)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) w[c][j] = wn[c][j];
+        }
+        if (it % NP == NP - 1) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const int64_t i0 = r0 + (int64_t)(wv * R + c) * 16;
+                if (i0 < t1) {
+                    bool any = false;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) any |= (acc[c][e] >= tq);
+                    if (__ballot(any)) {                      // rare: ~2e-4 of the (row, query) pairs pass
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int64_t n = i0 + 4 * g + e; // D[row = 4 g + e][column = r]
+                            if (acc[c][e] >= tq && n < t1) {
+                                const unsigned slot = atomicAdd(id_count + q0 + r, 1u);
+                                if (slot < ADC_ID_CAP) ids[(size_t)(q0 + r) * ADC_ID_CAP + slot] = (unsigned)n;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One block per query: exact fp32 score (m ascending, from 0) of every screened row; rows with score >= tau go
 // to the key list exactly as adc_scan_kernel<FILTER> would have put them.
 template <int M>
@@ -804,11 +1070,21 @@ __global__ __launch_bounds__(256) void adc_rescore_kernel(const uint8_t* __restr
 
 // ------------------------------------------------------------------------------------------ host
 struct adc_ws_layout {
-    size_t lut, sample, thr, cnt, cand, qlut, tint, idcnt, ids, total;
+    size_t lut, sample, thr, cnt, cand, qlut, tint, idcnt, ids, image, total;
     int64_t S;
 };
 static int adc_qs_for(int M) { (void)M; return 16; }   // table groups are sized for 16 queries (covers the 8- and 4-query kernels)
-static adc_ws_layout adc_layout(int64_t N, int M, int nq) {
+// conflict-free screen (adc_screen_cf_kernel): M = 16, 32, 48, 64 in one table phase, 96 in two
+static bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M == 64 || M == 96; }
+static int adc_cf_phase_m(int M) { return M == 96 ? 48 : M; }
+static size_t adc_cf_table_bytes(int M) {                  // per group of 8 queries, all phases
+    const int PM = adc_cf_phase_m(M);
+    return (size_t)(M / PM) * RC_K * (32 * (PM / 32 + (PM % 32) / 16)) * 8;
+}
+static bool adc_use_cf(int64_t N, int M) {
+    return N >= (1 << 18) && adc_cf_supported(M) && !rc_env_set("RC_ADC_VALU_SCREEN") && !rc_env_set("RC_ADC_OLD_SCREEN");
+}
+static adc_ws_layout adc_layout(int64_t N, int M, int nq, bool own_image = true) {
     adc_ws_layout L;
     L.S = N < ADC_SAMPLE_MAX ? N : ADC_SAMPLE_MAX;
     size_t o = 0;
@@ -820,18 +1096,61 @@ static adc_ws_layout adc_layout(int64_t N, int M, int nq) {
     L.qlut = L.tint = L.idcnt = L.ids = o;
     if (N >= ADC_SCREEN_MIN_N) {
         const int QS = adc_qs_for(M);
-        L.qlut = o;  o += rc_align_up((size_t)((nq + QS - 1) / QS) * M * RC_K * QS, 256);
+        size_t qb = (size_t)((nq + QS - 1) / QS) * M * RC_K * QS;
+        if (adc_cf_supported(M)) {
+            const size_t cb = (size_t)((nq + 7) / 8) * adc_cf_table_bytes(M);
+            if (cb > qb) qb = cb;
+        }
+        L.qlut = o;  o += rc_align_up(qb, 256);
         L.tint = o;  o += rc_align_up((size_t)nq * sizeof(int), 256);
         L.idcnt = o; o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
         L.ids = o;   o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
     }
+    L.image = o;
+    if (own_image && N >= ADC_SCREEN_MIN_N && adc_cf_supported(M)) o += rc_align_up((size_t)N * M, 256);
     L.total = o;
     return L;
 }
 
 extern "C" size_t rc_adc_search_ws_bytes(int64_t N, int M, int K, int nq, int k) {
     if (N <= 0 || M <= 0 || K != RC_K || nq <= 0 || k <= 0) return 0;
-    return adc_layout(N, M, nq).total;
+    return adc_layout(N, M, nq, true).total;
+}
+// workspace when the caller keeps the permuted code image itself (rc_adc_search_img with image != NULL)
+extern "C" size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, int k) {
+    if (N <= 0 || M <= 0 || K != RC_K || nq <= 0 || k <= 0) return 0;
+    return adc_layout(N, M, nq, false).total;
+}
+// bytes of the permuted code image of an N-row index (0: this M has no conflict-free screen, no image is used)
+extern "C" size_t rc_adc_scan_image_bytes(int64_t N, int M) {
+    if (N < 0 || !adc_cf_supported(M)) return 0;
+    return (size_t)N * M;
+}
+// Host-side description of the conflict-free layout (no GPU involved; what tests/test_abi.py checks): for lane `lane`
+// (0..63) of a wave and gather step `step` (0 .. steps_per_lane-1) of one table phase: the 8-byte LDS slot it reads and the
+// phase-relative sub-quantiser that slot belongs to.  Returns the number of steps per lane, or RC_ESHAPE.
+extern "C" int rc_adc_cf_describe(int M, int lane, int step, int* slot, int* m, int* slots_per_code, int* phases) {
+    if (!adc_cf_supported(M)) return RC_ESHAPE;
+    const int PM = adc_cf_phase_m(M);
+    if (lane < 0 || lane > 63 || step < 0 || step >= PM / 4 || !slot || !m) return RC_EINVAL;
+    adc_cf_step(PM, step, lane & 15, lane >> 4, *slot, *m);
+    if (slots_per_code) *slots_per_code = 32 * (PM / 32 + (PM % 32) / 16);
+    if (phases) *phases = M / PM;
+    return PM / 4;
+}
+
+// (Re)build rows [n0, n0 + n) of the image from the canonical codes [N, M] (both pointers = row 0 of the index).
+extern "C" int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
+                                 rc_stream_t stream) {
+    if (!h || !codes || !image || n0 < 0 || n < 0) return RC_EINVAL;
+    if (!adc_cf_supported(M)) return RC_ESHAPE;
+    if (n == 0) return RC_OK;
+    int64_t blocks = (n * M + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(adc_scan_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, codes, n0, n, M,
+                       adc_cf_phase_m(M), image);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
 }
 
 static int adc_qt_for(int M) {
@@ -846,8 +1165,8 @@ struct adc_bufs {
 };
 
 template <int M, int QT>
-static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int nq, int64_t S, const adc_bufs& b, int r, int k,
-                            int* status, hipStream_t s) {
+static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* image, int64_t N, int nq, int64_t S,
+                            const adc_bufs& b, int r, int k, int* status, hipStream_t s) {
     const size_t lds = (size_t)M * RC_K * QT * sizeof(float);
     const unsigned qg = (unsigned)((nq + QT - 1) / QT);
     auto ksample = adc_scan_kernel<M, QT, ADC_SAMPLE>;
@@ -862,9 +1181,8 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
     hipLaunchKernelGGL(adc_threshold_kernel, dim3((unsigned)nq), dim3(1024), tl, s, b.sample, S, r, b.thr);
     RC_LAUNCH_CHECK(h);
     const unsigned tiles = (unsigned)((N + ADC_TILE_DOCS - 1) / ADC_TILE_DOCS);
-    // screening inflates the candidate list ~1.7x: beyond k = 2048 (Faiss-GPU's own limit) the id buffer could
-    // overflow, so large k keeps the exact scan
-    if (N < ADC_SCREEN_MIN_N || k > 2048) {
+    // small indexes: exact scan (the screen's fixed costs do not pay)
+    if (N < ADC_SCREEN_MIN_N) {
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kfilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         hipLaunchKernelGGL(kfilter, dim3(qg, tiles), dim3(ADC_THREADS), lds, s, codes, N, b.lut, nq, S, b.sample, b.thr,
@@ -876,8 +1194,8 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
     RC_HIP_CHECK(h, hipMemsetAsync(b.idcnt, 0, (size_t)nq * sizeof(unsigned), s));
     // Screen variant: 8 queries per gather on the matrix cores (tables in LDS: one pass for M <= 64, two half-table
     // phases above); M % 8 != 0 and the A/B switches RC_ADC_VALU_SCREEN / RC_ADC_ONE_PHASE use the older kernels.
-    static const bool valu_screen = getenv("RC_ADC_VALU_SCREEN") != nullptr;
-    static const bool one_phase = getenv("RC_ADC_ONE_PHASE") != nullptr;
+    const bool valu_screen = rc_env_set("RC_ADC_VALU_SCREEN");
+    const bool one_phase = rc_env_set("RC_ADC_ONE_PHASE");
     auto screen = [&](auto kern, int QS, size_t sl) -> int {
         hipLaunchKernelGGL(adc_qlut_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, QS, b.qlut, b.tint);
         RC_LAUNCH_CHECK(h);
@@ -891,7 +1209,23 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
     };
     constexpr int QS1 = (M <= 64) ? 8 : 4;                  // one-pass kernels: M * 256 * QS bytes of LDS
     int src = RC_OK;
-    if constexpr (M % 8 == 0 && M > 64) {
+    constexpr bool CF = (M == 16 || M == 32 || M == 48 || M == 64 || M == 96);
+    if (CF && image != nullptr) {
+        if constexpr (CF) {
+            constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP, R = (NP == 1) ? 4 : 8;
+            auto kern = adc_screen_cf_kernel<M, NP, R>;
+            constexpr int sl = adc_cf<PM>::TABLE_BYTES;
+            hipLaunchKernelGGL(adc_qlut_cf_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, PM,
+                               adc_cf<PM>::SLOTS, b.qlut, b.tint);
+            RC_LAUNCH_CHECK(h);
+            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 7) / 8), tiles), dim3(ADC_THREADS), sl, s, image, N, b.qlut,
+                               b.tint, nq, b.idcnt, b.ids);
+            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+            RC_LAUNCH_CHECK(h);
+        }
+    } else if constexpr (M % 8 == 0 && M > 64) {
         if (!valu_screen && !one_phase) src = screen(adc_screen_mfma2_kernel<M, 8, 2>, 8, (size_t)(M / 2) * RC_K * 8);
         else if (!valu_screen) src = screen(adc_screen_mfma_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
         else src = screen(adc_screen_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
@@ -899,7 +1233,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
         // 16 queries per ds_read_b128 in two phases: measured SLOWER than the one-pass 8-query kernel at M = 48
         // (66-70 k vs 75-78 k queries/s: a b128 gather costs as many LDS cycles per query as a b64 one, and the
         // table refills come on top); kept behind RC_ADC_Q16 for experiments.
-        static const bool q16 = getenv("RC_ADC_Q16") != nullptr;
+        const bool q16 = rc_env_set("RC_ADC_Q16");
         if (!valu_screen && q16) src = screen(adc_screen_mfma2_kernel<M, 16, 2>, 16, (size_t)(M / 2) * RC_K * 16);
         else if (!valu_screen) src = screen(adc_screen_mfma_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
         else src = screen(adc_screen_kernel<M, QS1>, QS1, (size_t)M * RC_K * QS1);
@@ -920,7 +1254,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, int64_t N, int 
 }
 
 #define ADC_CASE(MM, QQ) \
-    case MM: rc = adc_launch_scans<MM, QQ>(h, codes, N, nq, L.S, bufs, r, k, status, s); break;
+    case MM: rc = adc_launch_scans<MM, QQ>(h, codes, image, N, nq, L.S, bufs, r, k, status, s); break;
 
 extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K, float* lut,
                           rc_stream_t stream) {
@@ -959,13 +1293,32 @@ int rc_adc_launch_select(rc_handle_t h, unsigned long long* cand, const unsigned
 extern "C" int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, const float* C, int D,
                              const float* q, int nq, int k, int64_t id_offset, double sel_slack, float* scores,
                              int64_t* ids, int* status, void* ws, size_t ws_bytes, rc_stream_t stream) {
+    return rc_adc_search_img(h, codes, nullptr, N, M, K, C, D, q, nq, k, id_offset, sel_slack, scores, ids, status, ws,
+                             ws_bytes, stream);
+}
+
+// The search proper.  scan_image: the index's permuted code image (rc_adc_scan_image) or NULL — then, where the
+// conflict-free screen applies, the image is rebuilt in the workspace on every call (one extra pass over the codes).
+extern "C" int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
+                                 const float* C, int D, const float* q, int nq, int k, int64_t id_offset,
+                                 double sel_slack, float* scores, int64_t* ids, int* status, void* ws, size_t ws_bytes,
+                                 rc_stream_t stream) {
     if (!h || !codes || !C || !q || !scores || !ids || !status || N <= 0 || nq < 0 || k <= 0 || M <= 0 || D <= 0)
         return RC_EINVAL;
     if (K != RC_K || D % M != 0 || N > 0xFFFFFFFFll || k > ADC_CAND_CAP / 2) return RC_ESHAPE;
     if (nq == 0) return RC_OK;
-    const adc_ws_layout L = adc_layout(N, M, nq);
+    const adc_ws_layout L = adc_layout(N, M, nq, scan_image == nullptr);
     if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
     char* w = (char*)ws;
+    const uint8_t* image = nullptr;
+    if (adc_use_cf(N, M)) {
+        image = scan_image;
+        if (!image) {
+            const int irc = rc_adc_scan_image(h, codes, 0, N, M, (uint8_t*)(w + L.image), stream);
+            if (irc != RC_OK) return irc;
+            image = (const uint8_t*)(w + L.image);
+        }
+    }
     float* lut = (float*)(w + L.lut);
     unsigned* cnt = (unsigned*)(w + L.cnt);
     unsigned long long* cand = (unsigned long long*)(w + L.cand);
@@ -984,6 +1337,10 @@ extern "C" int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int
     } else {
         const double mu = (double)k * (double)L.S / (double)N;
         r = (int)(mu + sel_slack * sqrt(mu + 1.0) + 4.0) + 1;
+        // large k: keep the expected candidate count (r N / S) below ~80 % of the list capacity as long as that still
+        // leaves 2.5 sigma of head-room over k
+        const double r_cap = 0.8 * (double)ADC_CAND_CAP * (double)L.S / (double)N;
+        if ((double)r > r_cap && r_cap >= mu + 2.5 * sqrt(mu + 1.0) + 2.0) r = (int)r_cap;
         if (r > L.S) r = (int)L.S;
     }
     switch (M) {

@@ -188,7 +188,7 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
         RC_NCCL_CHECK(h, n->AllReduce(minmax + M, minmax + M, (size_t)M, ncclFloat, ncclMin, (ncclComm_t)h->comm[0], s0));
     }
     // centring: fused into the first sweep (one pass over the table less); RC_FUSE_CENTRE=0 keeps the separate kernel
-    static const bool fuse_centre = !(getenv("RC_FUSE_CENTRE") && atoi(getenv("RC_FUSE_CENTRE")) == 0);
+    const bool fuse_centre = rc_env_int("RC_FUSE_CENTRE", 1) != 0;
     if (!fuse_centre && (rc = rc_pq_centre(h, d, minmax, B, M, RC_K, (rc_stream_t)s0)) != RC_OK) return rc;
 
     hipStream_t st[2] = {s0, s0};

@@ -16,6 +16,7 @@ struct rc_index_s {
     int D, M, K;
     float* C;            // [M, K, D/M]
     uint8_t* codes;      // [cap, M]
+    uint8_t* image;      // [cap, M] permuted copy for the conflict-free ADC screen (NULL when this M uses none)
     int64_t n, cap;
     void* ws;
     size_t ws_bytes;
@@ -35,7 +36,7 @@ extern "C" int rc_index_create(rc_handle_t h, int D, int M, int K, rc_index_t* o
     rc_index_s* idx = new (std::nothrow) rc_index_s();
     if (!idx) return RC_EINVAL;
     idx->h = h; idx->D = D; idx->M = M; idx->K = K;
-    idx->C = nullptr; idx->codes = nullptr; idx->n = 0; idx->cap = 0; idx->ws = nullptr; idx->ws_bytes = 0;
+    idx->C = nullptr; idx->codes = nullptr; idx->image = nullptr; idx->n = 0; idx->cap = 0; idx->ws = nullptr; idx->ws_bytes = 0;
     idx->status = nullptr; idx->have_centroids = false;
     hipError_t e = hipMalloc((void**)&idx->C, (size_t)M * K * (D / M) * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&idx->status, 256);
@@ -53,6 +54,7 @@ extern "C" int rc_index_destroy(rc_index_t idx) {
     if (!idx) return RC_EINVAL;
     if (idx->C) (void)hipFree(idx->C);
     if (idx->codes) (void)hipFree(idx->codes);
+    if (idx->image) (void)hipFree(idx->image);
     if (idx->ws) (void)hipFree(idx->ws);
     if (idx->status) (void)hipFree(idx->status);
     delete idx;
@@ -76,15 +78,30 @@ extern "C" int rc_index_reserve(rc_index_t idx, int64_t rows, rc_stream_t stream
     if (rows <= idx->cap) return RC_OK;
     if (rows > 0xFFFFFFFFll) return RC_ESHAPE;
     uint8_t* fresh = nullptr;
+    uint8_t* fresh_img = nullptr;
+    const bool with_image = rc_adc_scan_image_bytes(1, idx->M) > 0;
     RC_IDX_HIP(idx, hipMalloc((void**)&fresh, (size_t)rows * idx->M));
+    if (with_image) {
+        hipError_t e = hipMalloc((void**)&fresh_img, (size_t)rows * idx->M);
+        if (e != hipSuccess) { (void)hipFree(fresh); idx->h->last_hip_error = (int)e; return RC_EHIP; }
+    }
     hipStream_t s = (hipStream_t)stream;
     if (idx->n > 0) {
         hipError_t e = hipMemcpyAsync(fresh, idx->codes, (size_t)idx->n * idx->M, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);            // the old block is freed right below
-        if (e != hipSuccess) { (void)hipFree(fresh); idx->h->last_hip_error = (int)e; return RC_EHIP; }
+        if (e == hipSuccess && with_image)
+            e = hipMemcpyAsync(fresh_img, idx->image, (size_t)idx->n * idx->M, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);            // the old blocks are freed right below
+        if (e != hipSuccess) {
+            (void)hipFree(fresh);
+            if (fresh_img) (void)hipFree(fresh_img);
+            idx->h->last_hip_error = (int)e;
+            return RC_EHIP;
+        }
     }
     if (idx->codes) (void)hipFree(idx->codes);
+    if (idx->image) (void)hipFree(idx->image);
     idx->codes = fresh;
+    idx->image = fresh_img;
     idx->cap = rows;
     return RC_OK;
 }
@@ -102,6 +119,10 @@ extern "C" int rc_index_add_codes(rc_index_t idx, const uint8_t* codes, int64_t 
     }
     RC_IDX_HIP(idx, hipMemcpyAsync(idx->codes + (size_t)idx->n * idx->M, codes, (size_t)n * idx->M,
                                    hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (idx->image) {                                    // keep the permuted image in step, row for row
+        const int rc = rc_adc_scan_image(idx->h, idx->codes, idx->n, n, idx->M, idx->image, stream);
+        if (rc != RC_OK) return rc;
+    }
     idx->n += n;
     return RC_OK;
 }
@@ -132,7 +153,8 @@ extern "C" int rc_index_search(rc_index_t idx, const float* q, int nq, int k, fl
         if (e != hipSuccess) { idx->h->last_hip_error = (int)e; return RC_EHIP; }
         return RC_OK;
     }
-    const size_t need = rc_adc_search_ws_bytes(idx->n, idx->M, idx->K, nq, k);
+    const size_t need = idx->image ? rc_adc_search_img_ws_bytes(idx->n, idx->M, idx->K, nq, k)
+                                   : rc_adc_search_ws_bytes(idx->n, idx->M, idx->K, nq, k);
     if (need == 0) return RC_ESHAPE;
     if (need > idx->ws_bytes) {
         if (idx->ws) (void)hipFree(idx->ws);
@@ -144,8 +166,8 @@ extern "C" int rc_index_search(rc_index_t idx, const float* q, int nq, int k, fl
     int st = 0;
     for (int attempt = 0; attempt < 4; ++attempt) {
         RC_IDX_HIP(idx, hipMemsetAsync(idx->status, 0, sizeof(int), s));
-        const int rc = rc_adc_search(idx->h, idx->codes, idx->n, idx->M, idx->K, idx->C, idx->D, q, nq, k, 0, slack, scores,
-                                     ids, idx->status, idx->ws, idx->ws_bytes, stream);
+        const int rc = rc_adc_search_img(idx->h, idx->codes, idx->image, idx->n, idx->M, idx->K, idx->C, idx->D, q, nq, k, 0,
+                                         slack, scores, ids, idx->status, idx->ws, idx->ws_bytes, stream);
         if (rc != RC_OK) return rc;
         RC_IDX_HIP(idx, hipMemcpyAsync(&st, idx->status, sizeof(int), hipMemcpyDeviceToHost, s));
         RC_IDX_HIP(idx, hipStreamSynchronize(s));

@@ -34,7 +34,7 @@ extern "C" int rc_create(rc_handle_t* out, int device) {
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->last_hip_error = 0;
     h->profile_on = 0;
-    h->exp2_tab[0] = h->exp2_tab[1] = nullptr;
+    h->exp2_tab[0] = h->exp2_tab[1] = h->exp2_tab[2] = nullptr;
     h->comm[0] = h->comm[1] = nullptr;
     h->comm_rank = 0;
     h->comm_world = 0;
@@ -60,8 +60,8 @@ extern "C" int rc_destroy(rc_handle_t h) {
 
 // 2^(j/N) correctly rounded to double via long-double exp2l (64-bit significand), uploaded once.
 const double* rc_exp2_table(rc_handle_t h, int tb) {
-    if (!h || (tb != 8 && tb != 11)) return nullptr;
-    const int slot = (tb == 8) ? 0 : 1;
+    if (!h || (tb != 8 && tb != 11 && tb != 12)) return nullptr;
+    const int slot = (tb == 8) ? 0 : (tb == 11) ? 1 : 2;
     if (h->exp2_tab[slot]) return h->exp2_tab[slot];
     const int N = 1 << tb;
     std::vector<double> host(N);

@@ -17,7 +17,7 @@ struct rc_handle_s {
     int last_hip_error;
     int profile_on;
     std::vector<hipEvent_t> prof_ev[RC_PROF_NSLOT];  // start, stop, start, stop, ...
-    double* exp2_tab[2];                             // device tables 2^(j/N): [0] N=256, [1] N=2048
+    double* exp2_tab[3];                             // device tables 2^(j/N): [0] N=256, [1] N=2048, [2] N=4096
     // RCCL state of rc_comm_init (comm.hip): two communicators so two independent chains of collectives can be
     // in flight on two streams
     void* comm[2];
@@ -38,7 +38,7 @@ int rc_sk_argmax_strided(rc_handle_t h, const float* d, const double* rows_prev,
                          int M, double eps, int t, int code_stride, int m_offset, uint8_t* codes_u8,
                          int64_t* codes_i64, int* flags, hipStream_t s);
 
-// device pointer to the table 2^(j/2^tb), j < 2^tb (tb = 8 or 11), created on first use
+// device pointer to the table 2^(j/2^tb), j < 2^tb (tb = 8, 11 or 12), created on first use
 const double* rc_exp2_table(rc_handle_t h, int tb);
 
 // Record a start / stop event around one launch of a profiled kernel class (no-ops unless
@@ -64,6 +64,18 @@ static inline bool rc_dsub_supported(int dsub) {
 }
 
 static inline size_t rc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Development / test switches (RC_SK_FKLDS, RC_SK_CPB, RC_FUSE_CENTRE, RC_DIST_SPLIT, RC_ADC_*) are read from the
+// environment on EVERY call, never cached: a test that sets one between two calls gets what it asked for.
+#include <stdlib.h>
+static inline int rc_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+static inline bool rc_env_set(const char* name) {
+    const char* e = getenv(name);
+    return e && *e;
+}
 
 // dispatch a template<int DSUB> callable over the supported sub-vector widths
 #define RC_DISPATCH_DSUB(dsub, ...)             \

@@ -345,6 +345,260 @@ __global__ __launch_bounds__(SK_THREADS) void sk_argmax_kernel(const float* __re
     }
 }
 
+// ================================================================================================ sweep, version 2
+// Same mathematics, restructured around three observations (round 2):
+//
+//  (1) The column potential g_b never reaches the result: rows_k = sum_b w_kb / c_b with w_kb = exp(L_kb + f_k + g_b) and
+//      c_b = sum_k w_kb is independent of g_b, and so is the final argmax_k (L_kb + f_k).  g only keeps w inside the fp64
+//      range (w <= ~1).  So it is carried as an INTEGER number of 1/N octaves per column (gq8 = 8 gq, one int32 per
+//      (m, b), read and written by the column's owner lanes inside the main loop) and updated with the crudest log2 there
+//      is — the exponent and top mantissa bits of c_b as an integer, |error| < 0.09 octave: no fp64 g / colsum arrays, no
+//      per-column fp64 log, no staging of a chunk's exponents in LDS, no limit on the columns of a block.
+//  (2) exp costs 8 fp64-rate instructions instead of 10: the argument is kept non-negative by a power-of-two offset that
+//      the prologue derives from the smallest row potential (u' = (L + f) N/ln2 + OFF >= 0 for every |L| <= 1/eps), so
+//      v_fract_f64 / v_cvt_i32_f64 split it directly (no rndne + sub); with N = 4096 table entries a degree-2 minimax
+//      polynomial on [0,1) reproduces 2^(r/N) to 2.5e-14 (the rounding of u' itself is 8e-14, as in version 1).  The column
+//      normalisation multiplies by a Newton-refined v_rcp_f64 instead of dividing.
+//  (3) Work partition: the M*B columns are split into gridDim.x EQUAL contiguous ranges of the flattened (m, b) index, one
+//      per block, gridDim.x = resident blocks (4 per CU): every block does the same work in ONE round (version 1 ran
+//      4608 blocks on 1024 slots = 4.5 rounds), loads the exp table once, and pays the prologue once (twice when its range
+//      straddles two sub-quantisers).  A block's row sums go to slot (block - first block of m) of that m's partial list;
+//      the last block of an m to arrive adds the slots in order.
+//
+// LDS (static): table 32 KiB (the block-reduction scratch aliases it) + 256 offset potentials + a few words: 34 KiB, four
+// blocks per CU.  Order of every sum is fixed by (B, M, gridDim.x): results are identical run to run.
+#define SK2_TB 12
+#define SK2_N (1 << SK2_TB)
+#define SK2_C0 0x1.0000000000072p+0      // minimax of 2^(r/4096) on [0,1], degree 2 (tools/exp2_minimax.py): max error 2.52e-14
+#define SK2_C1 0x1.62e42fdfa7202p-13
+#define SK2_C2 0x1.ec06883f312a2p-27
+#define SK2_MAX_BLOCKS 2048
+#define SK2_UMAX 134217728.0             // 2^27: bound on u' (n << 3 must stay inside int32)
+
+__device__ __forceinline__ double sk2_exp(double u, int goff8, const double* __restrict__ s_tab) {
+    const double rf = __builtin_amdgcn_fract(u);             // u >= 0: u = n + rf
+    const int n = (int)u;                                    // v_cvt_i32_f64 truncates = floor for u >= 0
+    const int ni8 = (n << 3) + goff8;
+    const double T = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_tab) + (ni8 & ((SK2_N - 1) << 3)));
+    const double p = __builtin_fma(__builtin_fma(SK2_C2, rf, SK2_C1), rf, SK2_C0);
+    return __builtin_ldexp(T * p, ni8 >> (SK2_TB + 3));
+}
+
+// position of potential (lane, i) in s_fk: pairs (i, i+1) of one lane are adjacent and the 16 lanes of a column group
+// read 16 consecutive 16-byte slots (one conflict-free ds_read_b128 per pair)
+__device__ __forceinline__ int sk2_fkpos(int lane, int i) { return (((i >> 1) << 4) + lane) * 2 + (i & 1); }
+
+template <bool FIRST, bool FKLDS>
+__device__ __forceinline__ void sk2_column(const float (&x)[SK_EPL], const double (&fk)[SK_EPL],
+                                           const double* __restrict__ s_fk, const double* __restrict__ s_tab, int lane,
+                                           double (&R)[SK_EPL], int g8, int off8, double offd, double nse,
+                                           int* __restrict__ gq_out, bool writer, bool& bad) {
+    const int goff8 = g8 - off8;
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int i = 0; i < SK_EPL; ++i) R[i] += sk2_exp(__builtin_fma((double)x[i], nse, offd), goff8, s_tab);
+    } else {
+        double w[SK_EPL];
+        double c = 0.0;
+        int ln = lane;
+        if constexpr (FKLDS) asm volatile("" : "+v"(ln));    // re-read from LDS every column (keeps the loads un-hoisted)
+#pragma unroll
+        for (int i = 0; i < SK_EPL; i += 2) {
+            double f0, f1;
+            if constexpr (FKLDS) {
+                const double2 p = *reinterpret_cast<const double2*>(s_fk + sk2_fkpos(ln, i));
+                f0 = p.x; f1 = p.y;
+            } else {
+                f0 = fk[i]; f1 = fk[i + 1];
+            }
+            w[i] = sk2_exp(__builtin_fma((double)x[i], nse, f0), goff8, s_tab);
+            c += w[i];
+            w[i + 1] = sk2_exp(__builtin_fma((double)x[i + 1], nse, f1), goff8, s_tab);
+            c += w[i + 1];
+        }
+        c = rc_row16_allreduce_sum(c);
+        double y = __builtin_amdgcn_rcp(c);                   // 2^-24 relative; two Newton steps -> rounding level
+        double e = __builtin_fma(-c, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-c, y, 1.0);
+        y = __builtin_fma(y, e, y);
+#pragma unroll
+        for (int i = 0; i < SK_EPL; ++i) R[i] = __builtin_fma(w[i], y, R[i]);
+        bad |= !(c > 0.0) || !(c < INFINITY);
+        // new column exponent: log2(c) N ~ (high word of c - high word of 1.0) >> (20 - TB), kept pre-multiplied by 8
+        if (writer) *gq_out = g8 - (((__double2hiint(c) - 0x3FF00000) >> (20 - SK2_TB - 3)) & ~7);
+    }
+}
+
+// The T = M*B flattened columns are split into nb contiguous ranges, the first r = T % nb of them one column longer
+// (q + 1 = T / nb + 1 columns).  32-bit arithmetic throughout (the host rejects T >= 2^31).
+__device__ __forceinline__ unsigned sk2_range_lo(unsigned i, unsigned q, unsigned r) { return i * q + (i < r ? i : r); }
+__device__ __forceinline__ unsigned sk2_block_of(unsigned x, unsigned q, unsigned r) {
+    const unsigned big = r * (q + 1u);
+    return x < big ? x / (q + 1u) : r + (x - big) / q;
+}
+
+// MODE 0: first sweep on a centred table; 1: first sweep, centring fused (d holds the raw table); 2: sweep t >= 1.
+template <int MODE, bool FKLDS>
+__global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_sweep2_kernel(
+    float* __restrict__ d, const double* __restrict__ rows_prev, int G, const double* __restrict__ f_in,
+    double* __restrict__ f_out, int* __restrict__ gq, double* __restrict__ part, unsigned* __restrict__ counters,
+    double* __restrict__ rows_out, unsigned B, int M, unsigned rq, unsigned rr, int part_stride, double nse, double scale,
+    double lmax, const double* __restrict__ exp2_tab, int t, int* __restrict__ flags, const float* __restrict__ cmx,
+    const float* __restrict__ cmn) {
+    constexpr bool FIRST = MODE != 2;
+    static_assert(!(FIRST && FKLDS), "the first sweep has no row potentials");
+    __shared__ __attribute__((aligned(16))) double s_tab[SK2_N];      // red[16][256] aliases it after the main loop
+    __shared__ __attribute__((aligned(16))) double s_fk[RC_K];
+    __shared__ double s_mm[8];
+    __shared__ int s_last;
+    double(*red)[RC_K] = reinterpret_cast<double(*)[RC_K]>(s_tab);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (SK_GROUP - 1);
+    const int grp = tid / SK_GROUP;
+    const unsigned bi = blockIdx.x;
+    const unsigned lo = sk2_range_lo(bi, rq, rr), hi = sk2_range_lo(bi + 1u, rq, rr);
+    bool bad = false, range = false;
+    if (lo >= hi) return;                                     // the host never launches more blocks than columns / 32
+    for (unsigned m = lo / B; m * B < hi; ++m) {
+        const unsigned mb = m * B;
+        const unsigned c0 = (lo > mb ? lo : mb) - mb;
+        const unsigned c1 = (hi < mb + B ? hi : mb + B) - mb;
+        // ---- (a) everything with a long latency first: the table, the first column
+        double2 tv[SK2_N / 2 / SK_THREADS];
+#pragma unroll
+        for (int j = 0; j < SK2_N / 2 / SK_THREADS; ++j)
+            tv[j] = reinterpret_cast<const double2*>(exp2_tab)[j * SK_THREADS + tid];
+        float* dm = d + (size_t)m * B * RC_K + lane * 4;
+        int* gm = gq + (size_t)m * B;
+        float xa[SK_EPL], xb[SK_EPL];
+        int ga = 0, gb = 0;
+        unsigned col = c0 + grp;
+        if (col < c1) {
+            sk_load_col(dm + (size_t)col * RC_K, xa);
+            if (!FIRST && t > 1) ga = gm[col];
+        }
+        // ---- (b) row potentials of this m after the update that follows sweep t-1 (modeling_repconc.py:157-158):
+        // f = f_prev - log(sum over ranks of rows_prev), ranks ascending; the loads go out before the table is parked in
+        // LDS, the logarithm comes after (the table registers are dead by then)
+        double rs = 1.0, fo = 0.0;
+        if constexpr (!FIRST) {
+            rs = 0.0;
+            for (int r = 0; r < G; ++r) rs += rows_prev[((size_t)r * M + m) * RC_K + tid];
+            bad |= !(rs > 0.0) || !(rs < INFINITY);
+            if (t > 1) fo = f_in[(size_t)m * RC_K + tid];
+        }
+#pragma unroll
+        for (int j = 0; j < SK2_N / 2 / SK_THREADS; ++j)
+            reinterpret_cast<double2*>(s_tab)[j * SK_THREADS + tid] = tv[j];
+        double fn = 0.0;
+        if constexpr (!FIRST) fn = fo - log(rs);
+        double flo = fn, fhi = fn;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            flo = fmin(flo, __shfl_xor(flo, o));
+            fhi = fmax(fhi, __shfl_xor(fhi, o));
+        }
+        if ((tid & 63) == 0) { s_mm[tid >> 6] = flo; s_mm[4 + (tid >> 6)] = fhi; }
+        __syncthreads();
+        flo = fmin(fmin(s_mm[0], s_mm[1]), fmin(s_mm[2], s_mm[3]));
+        fhi = fmax(fmax(s_mm[4], s_mm[5]), fmax(s_mm[6], s_mm[7]));
+        // offset: smallest power of two that makes (L + f) scale + OFF >= 0 for every |L| <= lmax
+        const double need = (lmax - flo) * scale * (1.0 + 1e-9) + 4.0;
+        int ex = 0;
+        (void)frexp(need, &ex);
+        const double offd = ldexp(1.0, ex);
+        range |= !(need < SK2_UMAX / 2) || !((lmax + fhi) * scale + offd < SK2_UMAX);
+        const int off8 = (int)offd << 3;
+        {
+            const int ki = ((tid >> 6) << 2) | (tid & 3), kl = (tid >> 2) & 15;     // tid = sk_kidx(kl, ki)
+            s_fk[sk2_fkpos(kl, ki)] = __builtin_fma(fn, scale, offd);
+        }
+        __syncthreads();
+
+        double fk[SK_EPL], R[SK_EPL];
+#pragma unroll
+        for (int i = 0; i < SK_EPL; ++i) {
+            fk[i] = (FIRST || FKLDS) ? 0.0 : s_fk[sk2_fkpos(lane, i)];
+            R[i] = 0.0;
+        }
+        float cmid = 0.f, camp = 1.f;
+        if constexpr (MODE == 1) {
+            const float mx = cmx[m], mn = cmn[m];
+            cmid = (mx + mn) / 2.0f;                              // centre_kernel's arithmetic, pq_distance.hip
+            camp = (mx - cmid) + 1e-5f;
+        }
+        // ---- (c) main loop, two columns per trip (ping-pong register buffers, next column always in flight)
+        while (col < c1) {
+            const unsigned colb = col + SK_NG;
+            if (colb < c1) {
+                sk_load_col(dm + (size_t)colb * RC_K, xb);
+                if (!FIRST && t > 1) gb = gm[colb];
+            }
+            if constexpr (MODE == 1) sk_centre_store(dm + (size_t)col * RC_K, xa, cmid, camp);
+            sk2_column<FIRST, FKLDS>(xa, fk, s_fk, s_tab, lane, R, ga, off8, offd, nse, gm + col, lane == 0, bad);
+            if (colb >= c1) break;
+            const unsigned cola = colb + SK_NG;
+            if (cola < c1) {
+                sk_load_col(dm + (size_t)cola * RC_K, xa);
+                if (!FIRST && t > 1) ga = gm[cola];
+            }
+            if constexpr (MODE == 1) sk_centre_store(dm + (size_t)colb * RC_K, xb, cmid, camp);
+            sk2_column<FIRST, FKLDS>(xb, fk, s_fk, s_tab, lane, R, gb, off8, offd, nse, gm + colb, lane == 0, bad);
+            col = cola;
+        }
+        // ---- (d) block reduction of the row sums, fixed order over the 16 column groups (scratch = the dead table)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SK_EPL; ++i) red[grp][sk_kidx(lane, i)] = R[i];
+        __syncthreads();
+        double s = red[0][tid];
+#pragma unroll
+        for (int q = 1; q < SK_NG; ++q) s += red[q][tid];
+        // ---- (e) hand the partial to whichever block of this m arrives last: write-through (sc1) 8-byte stores, every
+        // wave drains them, one relaxed agent-scope counter add; the reducer reads with L1-bypassing loads.
+        const unsigned first = sk2_block_of(mb, rq, rr);
+        const unsigned cnt = sk2_block_of(mb + B - 1u, rq, rr) - first + 1u;
+        const unsigned slot = bi - first;
+        double* pm = part + (size_t)m * part_stride * RC_K;
+        __hip_atomic_store(pm + (size_t)slot * RC_K + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!FIRST && slot == 0) f_out[(size_t)m * RC_K + tid] = fn;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(counters + m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = ((old + 1u) % cnt == 0u);
+        }
+        __syncthreads();
+        if (s_last) {
+            // slots in order, 8 loads in flight (the reducer is the tail of the sweep: pure L2 latency)
+            double acc = 0.0;
+            unsigned i = 0;
+            for (; i + 8 <= cnt; i += 8) {
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = __hip_atomic_load(pm + (size_t)(i + j) * RC_K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += v[j];
+            }
+            for (; i < cnt; ++i)
+                acc += __hip_atomic_load(pm + (size_t)i * RC_K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rows_out[(size_t)m * RC_K + tid] = acc;
+        }
+        __syncthreads();      // s_last, red (= the table) are rewritten by the next segment
+    }
+    const int fl = (bad ? RC_FLAG_NONFINITE : 0) | (range ? RC_FLAG_RANGE : 0);
+    const unsigned long long anyb = __ballot(fl != 0);
+    if (anyb) {
+        int all = fl;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) all |= __shfl_xor(all, o);
+        if ((tid & 63) == 0) atomicOr(flags, all);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 // columns per block: every block pays a fixed prologue (16 KiB table, 256 potentials, its columns' g) and
 // the partial hand-off, so blocks should be as long as the grid allows while still filling the chip once:
@@ -354,8 +608,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_argmax_kernel(const float* __re
 // 192 -> 39 [768], 256 -> 46 [576];  B = 12288, M = 48: 192 -> 163, 384 -> 155 [1536], 512 -> 158 [1152];
 // B >= 24576 -> 512.
 static int sk_cols_per_block(int64_t B, int M) {
-    static int forced = -1;   // development override
-    if (forced < 0) { const char* e = getenv("RC_SK_CPB"); forced = e ? atoi(e) : 0; }
+    const int forced = rc_env_int("RC_SK_CPB", 0);   // development / test override, read per call
     if (forced >= 16 && forced <= SK_MAX_CPB) return forced;
     static const int cand[] = {512, 384, 256, 192, 128, 96, 64};
     for (int c : cand)
@@ -364,6 +617,20 @@ static int sk_cols_per_block(int64_t B, int M) {
 }
 static double sk_scale() { return (double)SK_N / SK_LN2; }
 
+// version 2 (default) unless RC_SK_V1=1 (the round-1 kernel, kept for A/B runs and as a cross-check in the tests)
+static bool sk_use_v2() { return rc_env_int("RC_SK_V1", 0) == 0; }
+// blocks of the version-2 sweep: `per_cu` resident blocks per CU, never fewer than ~32 columns per block
+static int sk2_num_blocks(rc_handle_t h, int64_t B, int M, int per_cu) {
+    const int64_t T = (int64_t)M * B;
+    int64_t nb = rc_env_int("RC_SK_NB", 0);
+    if (nb <= 0) nb = (int64_t)per_cu * (h && h->num_cus > 0 ? h->num_cus : 256);
+    const int64_t cap = T / 32 > 0 ? T / 32 : 1;
+    if (nb > cap) nb = cap;
+    if (nb > SK2_MAX_BLOCKS) nb = SK2_MAX_BLOCKS;
+    return (int)nb;
+}
+static int sk2_part_stride(int nb, int M) { return nb / M + 2; }   // partial slots per sub-quantiser (>= blocks touching it)
+
 struct sk_sweep_ws {
     size_t part, counters, total;
 };
@@ -371,10 +638,62 @@ static sk_sweep_ws sk_ws(int64_t B, int M) {
     sk_sweep_ws w;
     const int cpb = sk_cols_per_block(B, M);
     const int64_t nblk = (B + cpb - 1) / cpb;
+    size_t slots = (size_t)M * nblk;                                               // version 1
+    const size_t slots2 = (size_t)M * sk2_part_stride(SK2_MAX_BLOCKS, M);         // version 2, any grid
+    if (slots2 > slots) slots = slots2;
     w.part = 0;
-    w.counters = rc_align_up((size_t)M * nblk * RC_K * sizeof(double), 256);
+    w.counters = rc_align_up(slots * RC_K * sizeof(double), 256);
     w.total = w.counters + rc_align_up((size_t)M * sizeof(unsigned), 256);
     return w;
+}
+
+// launch of the version-2 sweep.  mode 0 / 1 / 2 as in sk_sweep2_kernel; g is the caller's [M,B] fp64 scratch, used as
+// int32 [M*B] column exponents.
+static int sk2_launch(rc_handle_t h, int mode, float* d, const double* rows_prev, int G, double* f2, double* g,
+                      double* rows_out, int64_t B, int M, double eps, int t, int* flags, void* ws, const float* mx,
+                      const float* mn, hipStream_t s) {
+    const sk_sweep_ws W = sk_ws(B, M);
+    const double* tab = rc_exp2_table(h, SK2_TB);
+    if (!tab) return RC_EHIP;
+    double* part = (double*)((char*)ws + W.part);
+    unsigned* counters = (unsigned*)((char*)ws + W.counters);
+    const double scale = (double)SK2_N / SK_LN2;
+    const double nse = -scale / eps;
+    const double lmax = (1.0 + 1e-6) / eps;                // |centred distance| < 1 (amp = half range + 1e-5)
+    int* gq = reinterpret_cast<int*>(g);
+    if ((int64_t)M * B >= (1ll << 31)) return RC_ESHAPE;
+    const unsigned Tc = (unsigned)((int64_t)M * B), Bu = (unsigned)B;
+    const double* f_in = (mode == 2) ? f2 + (size_t)((t - 1) & 1) * M * RC_K : nullptr;
+    double* f_out = (mode == 2) ? f2 + (size_t)(t & 1) * M * RC_K : nullptr;
+    if (mode != 2) {
+        const int nb = sk2_num_blocks(h, B, M, 4);
+        RC_HIP_CHECK(h, hipMemsetAsync(counters, 0, (size_t)M * sizeof(unsigned), s));
+        if (mode == 0)
+            hipLaunchKernelGGL((sk_sweep2_kernel<0, false>), dim3((unsigned)nb), dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
+                               f_out, gq, part, counters, rows_out, Bu, M, Tc / (unsigned)nb, Tc % (unsigned)nb, sk2_part_stride(nb, M), nse, scale, lmax, tab, t,
+                               flags, mx, mn);
+        else
+            hipLaunchKernelGGL((sk_sweep2_kernel<1, false>), dim3((unsigned)nb), dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
+                               f_out, gq, part, counters, rows_out, Bu, M, Tc / (unsigned)nb, Tc % (unsigned)nb, sk2_part_stride(nb, M), nse, scale, lmax, tab, t,
+                               flags, mx, mn);
+    } else {
+        // default: potentials re-read from LDS (120 VGPRs, four blocks per CU); RC_SK_FKLDS=0: potentials in registers,
+        // three blocks per CU
+        const bool fklds = rc_env_int("RC_SK_FKLDS", 1) != 0;
+        const int nb = sk2_num_blocks(h, B, M, fklds ? 4 : 3);
+        rc_prof_mark(h, RC_PROF_SK_PASS, s);
+        if (fklds)
+            hipLaunchKernelGGL((sk_sweep2_kernel<2, true>), dim3((unsigned)nb), dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
+                               f_out, gq, part, counters, rows_out, Bu, M, Tc / (unsigned)nb, Tc % (unsigned)nb, sk2_part_stride(nb, M), nse, scale, lmax, tab, t,
+                               flags, mx, mn);
+        else
+            hipLaunchKernelGGL((sk_sweep2_kernel<2, false>), dim3((unsigned)nb), dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
+                               f_out, gq, part, counters, rows_out, Bu, M, Tc / (unsigned)nb, Tc % (unsigned)nb, sk2_part_stride(nb, M), nse, scale, lmax, tab, t,
+                               flags, mx, mn);
+        rc_prof_mark(h, RC_PROF_SK_PASS, s);
+    }
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
 }
 
 extern "C" size_t rc_sk_ws_bytes(int64_t B, int M, int K) {
@@ -390,6 +709,9 @@ extern "C" int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_pre
     if (K != RC_K) return RC_ESHAPE;
     const sk_sweep_ws W = sk_ws(B, M);
     if (!ws || ws_bytes < W.total) return RC_EWORKSPACE;
+    if (sk_use_v2())
+        return sk2_launch(h, t == 0 ? 0 : 2, const_cast<float*>(d), rows_prev, G, f2, g, rows_out, B, M, eps, t, flags, ws,
+                          nullptr, nullptr, (hipStream_t)stream);
     const double* tab = rc_exp2_table(h, SK_TB);
     if (!tab) return RC_EHIP;
     hipStream_t s = (hipStream_t)stream;
@@ -410,7 +732,7 @@ extern "C" int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_pre
         const double* f_in = f2 + (size_t)((t - 1) & 1) * M * RC_K;
         double* f_out = f2 + (size_t)(t & 1) * M * RC_K;
         // grids of >= 4 resident rounds' worth of blocks take the four-waves-per-SIMD variant (potentials from LDS)
-        static const int force_fklds = getenv("RC_SK_FKLDS") ? atoi(getenv("RC_SK_FKLDS")) : -1;
+        const int force_fklds = rc_env_int("RC_SK_FKLDS", -1);
         const bool fklds = force_fklds >= 0 ? force_fklds != 0 : (nblk * M >= 4096);
         const size_t lds4 = ((size_t)SK_NG * RC_K + RC_K) * sizeof(double) + (SK_MAX_CPB + 4) * sizeof(int);
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
@@ -433,6 +755,8 @@ int rc_sk_sweep0_centre(rc_handle_t h, float* d, const float* mx, const float* m
                         hipStream_t s) {
     const sk_sweep_ws W = sk_ws(B, M);
     if (!ws || ws_bytes < W.total) return RC_EWORKSPACE;
+    if (sk_use_v2())
+        return sk2_launch(h, 1, d, nullptr, 1, nullptr, g, rows_out, B, M, eps, 0, flags, ws, mx, mn, s);
     const double* tab = rc_exp2_table(h, SK_TB);
     if (!tab) return RC_EHIP;
     double* part = (double*)((char*)ws + W.part);

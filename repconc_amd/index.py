@@ -38,6 +38,9 @@ class PQIndex:
         self.id_offset = 0       # global id of local row 0 (row-sharded indexes)
         self._centroids = torch.zeros((M, 256, d // M), dtype=torch.float32, device=self.device)
         self._codes = torch.empty((0, M), dtype=torch.uint8, device=self.device)
+        # permuted copy of the codes streamed by the conflict-free ADC screen (csrc/adc_search.hip), kept in step
+        # with `_codes` row for row; None for the M that do not use one
+        self._image = torch.empty((0, M), dtype=torch.uint8, device=self.device) if ops.adc_image_supported(M) else None
         self.pq = SimpleNamespace(d=d, M=M, nbits=nbits, code_size=M, ksub=256, dsub=d // M, centroids=self._centroids)
 
     # ---- Faiss-like attributes
@@ -70,7 +73,13 @@ class PQIndex:
                                 device=self.device)
             grown[: self.ntotal] = self._codes[: self.ntotal]
             self._codes = grown
+            if self._image is not None:
+                gi = torch.empty_like(grown)
+                gi[: self.ntotal] = self._image[: self.ntotal]
+                self._image = gi
         self._codes[self.ntotal:need] = c.to(self.device)
+        if self._image is not None and n > 0:
+            ops.adc_scan_image_(self._codes, self._image, self.ntotal, n)
         self.ntotal = need
 
     def add(self, x):
@@ -85,8 +94,9 @@ class PQIndex:
         as_numpy = not isinstance(x, torch.Tensor)
         q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if as_numpy else x
         q = q.to(self.device, torch.float32)
-        scores, ids = ops.adc_search(self._codes[: self.ntotal].contiguous() if self.ntotal != self._codes.shape[0]
-                                     else self._codes, self._centroids, q, int(k), id_offset=self.id_offset)
+        # prefixes of the row-major buffers are contiguous views: nothing is copied
+        scores, ids = ops.adc_search(self._codes[: self.ntotal], self._centroids, q, int(k), id_offset=self.id_offset,
+                                     scan_image=None if self._image is None else self._image[: self.ntotal])
         if as_numpy:
             return scores.cpu().numpy(), ids.cpu().numpy()
         return scores, ids

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 from transformers.modeling_outputs import ModelOutput
 
-from ... import ops
+from ... import _lib, ops
 from ...sharded import SingleComm, TorchDistComm, assign_sinkhorn_sharded
 
 logger = logging.getLogger(__name__)
@@ -76,7 +76,11 @@ class RepCONC(nn.Module):
         else:
             codes, flags = assign_sinkhorn_sharded(continuous_embeds, self.centroids, self.sk_epsilon,
                                                    self.sk_iters, comm)
-        if int(flags.item()) != 0:
+        fl = int(flags.item())
+        if fl & _lib.RC_FLAG_RANGE:
+            raise _lib.RepconcHipError(f"sk_epsilon={self.sk_epsilon} is outside the range the Sinkhorn kernels cover "
+                                       "(the reference's own exp(1/eps) overflows fp64 below 1.4e-3)")
+        if fl != 0:
             logger.warning("Sinkhorn Algorithm returns nan/inf values.")
         return codes
 
@@ -149,11 +153,23 @@ def sinkhorn_algorithm(out: Tensor, epsilon: float, sinkhorn_iterations: int, us
     d = (-out).transpose(1, 2).contiguous().float()
     if not torch.equal(d.double(), (-out).transpose(1, 2)):
         raise NotImplementedError("sinkhorn_algorithm: the cost matrix must be exactly representable in fp32")
+    # the sweeps take a centred table (|d| <= 1, as center_distance_for_constraint produces): a wider one is rescaled
+    # together with eps by a power of two — L = d/eps is unchanged, bit for bit
+    amax = float(d.abs().max()) if d.numel() else 0.0
+    eps_k = epsilon
+    if use_distrib_train and dist.get_world_size() > 1:
+        t = torch.tensor([amax], dtype=torch.float64, device=d.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        amax = float(t.item())
+    if amax > 1.0:
+        import math
+        sc = 2.0 ** math.ceil(math.log2(amax))
+        d, eps_k = d / sc, epsilon / sc
     comm = TorchDistComm() if (use_distrib_train and dist.get_world_size() > 1) else SingleComm()
     st = ops.SinkhornState(d)
-    rows = st.sweep(epsilon, 0, None)
+    rows = st.sweep(eps_k, 0, None)
     for t in range(1, sinkhorn_iterations):
-        rows = st.sweep(epsilon, t, comm.allgather(rows))
+        rows = st.sweep(eps_k, t, comm.allgather(rows))
     f = st.potentials(sinkhorn_iterations, comm.allgather(rows))
     return torch.softmax(out / epsilon + f[:, :, None], dim=1)
 

@@ -390,14 +390,39 @@ def adc_lut(centroids: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
     return lut
 
 
+def adc_image_supported(M: int) -> bool:
+    """True when the ADC screen of this M reads a permuted code image (rc_adc_scan_image)."""
+    return _lib.load().rc_adc_scan_image_bytes(1, int(M)) > 0
+
+
+def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Optional[int] = None) -> torch.Tensor:
+    """(Re)build rows [n0, n0+n) of the permuted code image of an index (both tensors uint8 [>=n0+n, M], contiguous).
+    The image is what the conflict-free ADC screen streams; see include/repconc_hip.h rc_adc_scan_image."""
+    _need_cuda(codes, image)
+    if codes.dtype != torch.uint8 or image.dtype != torch.uint8 or not codes.is_contiguous() or not image.is_contiguous():
+        raise ValueError("codes and image must be contiguous uint8 [N, M]")
+    M = codes.shape[1]
+    if n is None:
+        n = codes.shape[0] - n0
+    if n0 < 0 or n < 0 or n0 + n > codes.shape[0] or n0 + n > image.shape[0] or image.shape[1] != M:
+        raise ValueError("row range outside the code / image buffers")
+    lib, h, s, _ = _ctx(codes)
+    _lib.check(lib.rc_adc_scan_image(h, _p(codes), int(n0), int(n), M, _p(image), s), "rc_adc_scan_image", h)
+    return image
+
+
 def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k: int, id_offset: int = 0,
-               sel_slack: float = 6.0, max_retries: int = 3):
+               sel_slack: float = 6.0, max_retries: int = 3, scan_image: Optional[torch.Tensor] = None):
     """Top-k inner-product ADC search of `q` [nq,D] against uint8 `codes` [N,M].
     Returns (scores [nq,k] fp32, ids [nq,k] int64), sorted (score desc, id asc).
-    evaluate_repconc.py:180-185 / finetune_jpq.py:176."""
-    _need_cuda(codes, centroids, q)
+    evaluate_repconc.py:180-185 / finetune_jpq.py:176.
+    scan_image: the index's permuted code image (adc_scan_image_), kept by PQIndex; None = rebuilt per call."""
+    _need_cuda(codes, centroids, q, scan_image)
     if codes.dtype != torch.uint8 or not codes.is_contiguous():
         raise ValueError("index codes must be contiguous uint8 [N, M]")
+    if scan_image is not None and (scan_image.dtype != torch.uint8 or not scan_image.is_contiguous()
+                                   or scan_image.shape[0] < codes.shape[0] or scan_image.shape[1] != codes.shape[1]):
+        raise ValueError("scan_image must be contiguous uint8 [>=N, M]")
     c, q = _centroids(centroids), _rows_f32(q).contiguous()
     N, M = codes.shape
     nq, D = q.shape
@@ -410,14 +435,15 @@ def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k:
         return scores, ids
     if N == 0:
         return scores.fill_(float("-inf")), ids.fill_(-1)
-    wsb = lib.rc_adc_search_ws_bytes(N, M, K, nq, k)
+    wsb = (lib.rc_adc_search_img_ws_bytes if scan_image is not None else lib.rc_adc_search_ws_bytes)(N, M, K, nq, k)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
     status = torch.zeros((1,), dtype=torch.int32, device=q.device)
     slack = float(sel_slack)
     for _ in range(max_retries + 1):
         status.zero_()
-        _lib.check(lib.rc_adc_search(h, _p(codes), N, M, K, _p(c), D, _p(q), nq, int(k), int(id_offset), slack,
-                                     _p(scores), _p(ids), _p(status), _p(ws), wsb, s), "rc_adc_search", h)
+        _lib.check(lib.rc_adc_search_img(h, _p(codes), _p(scan_image), N, M, K, _p(c), D, _p(q), nq, int(k),
+                                         int(id_offset), slack, _p(scores), _p(ids), _p(status), _p(ws), wsb, s),
+                   "rc_adc_search_img", h)
         st = int(status.item())
         if st == 0:
             return scores, ids

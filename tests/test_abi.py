@@ -42,3 +42,37 @@ def test_cpu_tensors_are_rejected_loudly():
     from repconc_amd import _lib, ops
     with pytest.raises(_lib.RepconcHipError):
         ops.assign_nearest(torch.zeros(4, 768), torch.zeros(48, 256, 16))
+
+
+def test_adc_conflict_free_layout_properties():
+    """Host-side check of the layout the conflict-free ADC screen relies on (csrc/adc_search.hip, rc_adc_cf_describe):
+    (a) the four lanes of a row visit every sub-quantiser of a table phase exactly once, (b) in every gather step the 32
+    lanes the LDS services together (0-31 and 32-63) read 32 different slots modulo 32 — distinct bank pairs whatever
+    the codes — and (c) a slot always belongs to one sub-quantiser (copies of a 16-block are 16 slots apart)."""
+    import ctypes as C
+    from repconc_amd import _lib
+    lib = _lib.load()
+    for M in (16, 32, 48, 64, 96):
+        slot, m, spc, nph = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        steps = lib.rc_adc_cf_describe(M, 0, 0, C.byref(slot), C.byref(m), C.byref(spc), C.byref(nph))
+        PM = M // nph.value
+        assert steps == PM // 4 and spc.value % 32 == 0 and spc.value * 8 * 256 <= 160 * 1024
+        owner = {}
+        for row in range(16):
+            seen = []
+            for g in range(4):
+                for s in range(steps):
+                    assert lib.rc_adc_cf_describe(M, row + 16 * g, s, C.byref(slot), C.byref(m), None, None) == steps
+                    assert 0 <= slot.value < spc.value and 0 <= m.value < PM
+                    assert owner.setdefault(slot.value, m.value) == m.value                     # (c)
+                    seen.append(m.value)
+            assert sorted(seen) == list(range(PM)), (M, row)                                    # (a)
+        for s in range(steps):
+            for half in (0, 1):
+                banks = set()
+                for lane in range(32 * half, 32 * half + 32):
+                    lib.rc_adc_cf_describe(M, lane, s, C.byref(slot), C.byref(m), None, None)
+                    banks.add(slot.value % 32)
+                assert len(banks) == 32, (M, s, half)                                           # (b)
+    assert lib.rc_adc_cf_describe(24, 0, 0, C.byref(slot), C.byref(m), None, None) == -2     # RC_ESHAPE: no image for M=24
+    assert lib.rc_adc_scan_image_bytes(1000, 48) == 48000 and lib.rc_adc_scan_image_bytes(1000, 24) == 0

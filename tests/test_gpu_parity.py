@@ -963,3 +963,128 @@ def test_jpq_module_step_matches_plain_autograd_and_keeps_index_in_sync():
 def ops_decode_all(index, centroids):
     from repconc_amd import ops
     return ops.decode_raw(index.codes.contiguous(), centroids.contiguous())
+
+
+# ------------------------------------------------------------------------------------------- round 2
+SK_VARIANTS = [  # (RC_SK_V1, RC_SK_FKLDS, RC_SK_NB, RC_SK_CPB, RC_FUSE_CENTRE)
+    ("0", "1", "", "", "1"),      # default: version-2 sweep, potentials from LDS, 4 blocks per CU
+    ("0", "0", "", "", "1"),      # potentials in registers
+    ("0", "1", "", "", "0"),      # separate centring kernel
+    ("0", "1", "7", "", "1"),     # few blocks: every block straddles several sub-quantisers
+    ("0", "1", "333", "", "0"),   # odd grid
+    ("0", "0", "2048", "", "1"),  # as many blocks as the workspace allows
+    ("1", "1", "", "64", "1"),    # round-1 kernel, LDS potentials, short blocks
+    ("1", "0", "", "192", "0"),   # round-1 kernel, register potentials
+    ("1", "1", "", "512", "1"),   # round-1 kernel as timed in round 1
+]
+
+
+@pytest.mark.parametrize("variant", SK_VARIANTS, ids=lambda v: "v1=%s,fklds=%s,nb=%s,cpb=%s,fuse=%s" % v)
+@pytest.mark.parametrize("name", ["m48_b6144_sample", "m48_b1000_ragged", "m96_b512_blend", "m8_b2048_sample",
+                                  "m24_b1024_sample"])
+def test_every_sweep_variant_reproduces_the_golden_codes(name, variant, monkeypatch):
+    """The environment switches are read on every call (csrc/rc_common.h rc_env_int), so each kernel variant — among
+    them the one bench.py times — runs against the reference's own codes (fixtures generated by importing the reference,
+    oracle/gen_golden.py)."""
+    from repconc_amd import ops
+    for key, val in zip(("RC_SK_V1", "RC_SK_FKLDS", "RC_SK_NB", "RC_SK_CPB", "RC_FUSE_CENTRE"), variant):
+        if val == "":
+            monkeypatch.delenv(key, raising=False)
+        else:
+            monkeypatch.setenv(key, val)
+    g, x, C = load_case(name)
+    codes, flags = ops.assign_sinkhorn(_t(x), _t(C), EPS, ITERS, torch.uint8)
+    assert int(flags.item()) == 0
+    assert int((codes.cpu().numpy() != g["codes_constrained"]).sum()) == 0
+
+
+@pytest.mark.parametrize("kind", ["sampled", "lloyd"])
+def test_full_training_batch_against_the_oracle_49152_m48(kind):
+    """BASELINE configs[1]: ONE whole 49 152 x 768 training batch, M = 48, eps 0.003, T = 100 — every one of the
+    2 359 296 constrained codes (and the nearest codes) against the C restatement of the reference (~35 s of host time on
+    the GPU box per case).  Runs the default sweep at the grid bench.py times."""
+    from repconc_amd import ops
+    B, M = 49152, 48
+    x = synth.clustered_embeddings(777, B, n_clusters=512)
+    C = synth.sample_centroids(778, x, M)
+    xt = _t(x)
+    if kind == "lloyd":
+        Ct = _t(C)
+        for _ in range(5):                                      # Lloyd refinement on the GPU kernels
+            codes = ops.assign_nearest(xt, Ct, torch.uint8)
+            sums, counts = ops.kmeans_stats(xt, codes)
+            ops.kmeans_update_(sums, counts, Ct)
+        C = Ct.cpu().numpy()
+    want, fl = c_oracle.quantize(x, C, True, EPS, ITERS)
+    got, flags = ops.assign_sinkhorn(xt, _t(C), EPS, ITERS, torch.uint8)
+    assert fl == 0 and int(flags.item()) == 0
+    got = got.cpu().numpy()
+    assert int((got != want).sum()) == 0
+    hist = np.stack([np.bincount(got[:, m], minlength=256) for m in range(M)])
+    assert hist.min() > 0.8 * B / 256 and hist.max() < 1.2 * B / 256
+    near = ops.assign_nearest(xt, _t(C), torch.uint8).cpu().numpy()
+    assert np.array_equal(near, c_oracle.quantize(x, C, False)[0])
+
+
+def test_per_rank_shape_6144_against_the_oracle():
+    """BASELINE configs[2] per-rank shape (6144 x 768, M = 48) as a stand-alone batch vs the oracle, default sweep and
+    the register-potential variant (the grid of this shape is the one the 8-GPU recipe runs per rank)."""
+    from repconc_amd import ops
+    x = synth.clustered_embeddings(4242, 6144)
+    C = synth.sample_centroids(4243, x, 48)
+    want, _ = c_oracle.quantize(x, C, True, EPS, ITERS)
+    got, flags = ops.assign_sinkhorn(_t(x), _t(C), EPS, ITERS, torch.uint8)
+    assert int(flags.item()) == 0 and np.array_equal(got.cpu().numpy(), want)
+
+
+def test_epsilon_outside_the_supported_range_is_reported():
+    """eps far below anything the reference itself can run (its exp(1/eps) overflows at eps < 1.4e-3): the range flag."""
+    from repconc_amd import _lib, ops
+    g, x, C = load_case("m8_b300_gauss")
+    codes, flags = ops.assign_sinkhorn(_t(x), _t(C), 1e-5, 5, torch.uint8)
+    assert int(flags.item()) & _lib.RC_FLAG_RANGE
+
+
+@pytest.mark.parametrize("M,N,nq,k", [(48, 300017, 9, 1000), (96, 270001, 5, 10), (64, 262144, 4, 50),
+                                      (32, 400003, 3, 200), (16, 300000, 11, 100), (48, 1_000_003, 17, 3000)])
+def test_adc_conflict_free_screen_equals_oracle_and_old_screen(M, N, nq, k, monkeypatch):
+    """The conflict-free screen (permuted code image, rotated sub-quantiser order, 16x16x64 i8 MFMA): ids and score
+    bits equal the brute-force oracle — with the image rebuilt per call (ops.adc_search), with the image kept by an index
+    that was filled in ragged chunks (PQIndex.add_codes), and they equal the round-1 screen (RC_ADC_OLD_SCREEN=1)."""
+    from repconc_amd import ops
+    from repconc_amd.index import PQIndex
+    C, codes, q = _adc_case(M, N, nq, seed=M * 13 + N)
+    codes[N // 3: N // 3 + 500] = codes[:500]          # duplicated rows: ties across the candidate boundary
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    ct = _t(codes)
+    s1, i1 = ops.adc_search(ct, _t(C), _t(q), k)
+    assert np.array_equal(i1.cpu().numpy(), wi)
+    assert np.array_equal(s1.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    idx = PQIndex(768, M)
+    idx.set_centroids(C)
+    cuts = [0, 7, 7 + 16 * 1000 + 3, N // 2 + 5, N]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        idx.add_codes(ct[a:b])
+    assert idx._image is not None and torch.equal(idx.codes, ct)
+    s2, i2 = idx.search(_t(q), k)
+    assert torch.equal(i2, i1) and torch.equal(s2, s1)
+    monkeypatch.setenv("RC_ADC_OLD_SCREEN", "1")
+    s3, i3 = ops.adc_search(ct, _t(C), _t(q), k)
+    assert torch.equal(i3, i1) and torch.equal(s3, s1)
+
+
+def test_adc_scan_image_is_a_row_permutation():
+    """Every row of the image holds exactly the bytes of the canonical row, permuted by a rule that depends on
+    n mod 16 only; converting a row range leaves the other rows of the image alone."""
+    from repconc_amd import ops
+    for M in (16, 32, 48, 64, 96):
+        base = synth.uniform_codes(5 + M, 16, M)
+        codes = _t(np.concatenate([base] * 40 + [synth.uniform_codes(6 + M, 3, M)], 0))        # 643 rows, period 16
+        img = ops.adc_scan_image_(codes, torch.full_like(codes, 255))
+        a, b = np.sort(codes.cpu().numpy(), axis=1), np.sort(img.cpu().numpy(), axis=1)
+        assert np.array_equal(a, b)
+        assert torch.equal(img[:16], img[16:32]) and torch.equal(img[:16], img[624:640])
+        part = torch.full_like(codes, 255)
+        ops.adc_scan_image_(codes, part, 100, 37)
+        assert torch.equal(part[100:137], img[100:137])
+        assert bool((part[:100] == 255).all()) and bool((part[137:] == 255).all())
