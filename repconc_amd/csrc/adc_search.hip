@@ -42,6 +42,11 @@
 #define ADC_CAND_CAP 16384
 #define ADC_SELECT_SMALL ADC_CAND_CAP   // lists up to this length are sorted in LDS (measured: 128 KiB, one block per CU, 0.54 ms per 1200 queries; 64 KiB / two blocks per CU 0.95 ms; the typical list at k = 1000 holds ~5 k keys)
 #define ADC_TILE_DOCS 32768
+#ifndef RC_ADC_IMG16
+#define RC_ADC_IMG16 0         // 1: the permuted code image holds 16-bit codes (one v_mad_u32_u16 per gather address instead of bfe + lshl_add)
+#endif
+#define ADC_IMG_ES (RC_ADC_IMG16 ? 2 : 1)   // bytes per code in the image
+#define ADC_CF_TILE 65536     // rows per block of the conflict-free screen: a 65536 x 48 B tile (3 MiB) still fits the XCD's 4 MiB L2; half the table fills
 
 __device__ __forceinline__ unsigned adc_order_key(float s) {
     const unsigned u = __float_as_uint(s);
@@ -811,7 +816,9 @@ __global__ __launch_bounds__(256) void adc_scan_image_kernel(const uint8_t* __re
         const int g = rem / (PM / 4), st = rem % (PM / 4);
         int slot, m;
         adc_cf_step(PM, st, (int)(n & 15), g, slot, m);
-        image[n * M + pos] = codes[n * M + phase * PM + m];
+        const uint8_t c = codes[n * M + phase * PM + m];
+        if (ADC_IMG_ES == 2) reinterpret_cast<uint16_t*>(image)[n * M + pos] = c;
+        else image[n * M + pos] = c;
     }
 }
 
@@ -880,7 +887,7 @@ __global__ __launch_bounds__(RC_K) void adc_qlut_cf_kernel(const float* __restri
 
 typedef int adc_i32x4v __attribute__((ext_vector_type(4)));
 
-// grid (groups of 8 queries, row tiles of ADC_TILE_DOCS rows), XCD-remapped like the other screens.
+// grid (groups of 8 queries, row tiles of ADC_CF_TILE rows), XCD-remapped like the other screens.
 // A wave owns R chunks of 16 rows per round; lanes (r = l & 15, g = l >> 4).
 template <int M, int NP, int R>
 __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_t* __restrict__ image, int64_t N,
@@ -890,7 +897,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_
                                                                     unsigned* __restrict__ ids) {
     constexpr int PM = M / NP;
     using L = adc_cf<PM>;
-    constexpr int STEPS = L::STEPS, NW = STEPS / 4;        // code dwords per lane per chunk and phase
+    constexpr int STEPS = L::STEPS, NW = STEPS * ADC_IMG_ES / 4;   // code dwords per lane per chunk and phase
     static_assert(STEPS % 4 == 0, "whole dwords of codes per lane");
     constexpr int NWAVES = ADC_THREADS / 64;
     constexpr int ROUND = NWAVES * R * 16;
@@ -927,35 +934,38 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_
     for (int s = 0; s < STEPS; ++s) {
         int slot, m;
         adc_cf_step(PM, s, r, g, slot, m);
-        off[s] = (unsigned)slot * 8u;
+        // absolute LDS address of the slot in table row 0 (a generic pointer into LDS is {aperture, byte offset}: the low
+        // 32 bits are the LDS address), so the gather address below needs no further base add
+        off[s] = (unsigned)slot * 8u + static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     }
-    const int64_t t0 = (int64_t)btile * ADC_TILE_DOCS;
-    const int64_t t1 = (t0 + ADC_TILE_DOCS < N) ? t0 + ADC_TILE_DOCS : N;
+    const int64_t t0 = (int64_t)btile * ADC_CF_TILE;
+    const int64_t t1 = (t0 + ADC_CF_TILE < N) ? t0 + ADC_CF_TILE : N;
     // Flat sequence of steps it = round * NP + i; a round covers ROUND rows and visits the NP table phases, odd rounds in
     // reverse order, so the tables already in LDS are used first (NP - 1 refills per round).  The codes of step it + 1 are
     // loaded while step it is gathered (NP == 1; with two phases the eight chunks' codes are loaded at the start of the
-    // step — registers).
-    const int nrounds = (int)((t1 - t0 + ROUND - 1) / ROUND);
+    // step — registers).  All row arithmetic is 32-bit and relative to the tile (<= 32768 rows x M bytes).
+    const unsigned nrows = (unsigned)(t1 - t0);
+    const int nrounds = (int)((nrows + ROUND - 1) / ROUND);
     const int nsteps = nrounds * NP;
+    const uint8_t* __restrict__ tile = image + t0 * M * ADC_IMG_ES;
     auto phase_of = [&](int it) { const int rd = it / NP, i = it % NP; return (rd & 1) ? NP - 1 - i : i; };
+    const unsigned lane_off = (unsigned)(g * STEPS * ADC_IMG_ES), lane_row = (unsigned)(wv * R * 16 + r);
     auto load_step = [&](int it, unsigned (&dst)[R][NW]) {
-        const int64_t r0 = t0 + (int64_t)(it / NP) * ROUND;
-        const int ph = phase_of(it);
+        const unsigned base = (unsigned)(it / NP) * ROUND + lane_row;
+        const unsigned col = (unsigned)phase_of(it) * (PM * ADC_IMG_ES) + lane_off;
 #pragma unroll
         for (int c = 0; c < R; ++c) {
-            const int64_t n = r0 + (int64_t)(wv * R + c) * 16 + r;
-            const unsigned* cp = reinterpret_cast<const unsigned*>(image + (n < t1 ? n : (t1 - 1)) * M + ph * PM + g * STEPS);
+            unsigned n = base + 16u * c;
+            n = n < nrows ? n : nrows - 1u;                    // rows past the end of the tile: the last row again
+            const unsigned* cp = reinterpret_cast<const unsigned*>(tile + (n * (unsigned)(M * ADC_IMG_ES) + col));
 #pragma unroll
             for (int j = 0; j < NW; ++j) dst[c][j] = cp[j];
         }
     };
     constexpr bool PREFETCH = (NP == 1);
-    unsigned w[R][NW], wn[PREFETCH ? R : 1][NW];
-    int in_lds = -1;
-    if constexpr (PREFETCH) load_step(0, w);
     adc_i32x4v acc[R];
-    for (int it = 0; it < nsteps; ++it) {                     // block-uniform
-        const int64_t r0 = t0 + (int64_t)(it / NP) * ROUND;
+    // one step: gather + fold the R chunks of step `it` from the codes in `w`; the next step's codes go to `wn`
+    auto run_step = [&](int it, unsigned (&w)[R][NW], unsigned (&wn)[PREFETCH ? R : 1][NW], int& in_lds) {
         const int phase = phase_of(it);
         if (it % NP == 0) {
 #pragma unroll
@@ -972,51 +982,78 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_
         } else {
             load_step(it, w);
         }
+        // Software pipeline over the R chunks of the step: all STEPS gathers of chunk c + 1 are issued before the MFMAs
+        // of chunk c, so a wave keeps a whole chunk of LDS reads in flight.  Address of a gather: two VALU instructions,
+        // v_bfe_u32 (the code byte) + v_lshl_add_u32 (code * row bytes + this lane's slot offset).
+        uint2 ea[STEPS], eb[STEPS];
+        const unsigned rowbytes = L::SLOTS * 8;
+        (void)rowbytes;
+        auto gather = [&](int c, uint2 (&e)[STEPS]) {
 #pragma unroll
-        for (int c = 0; c < R; ++c) {
-            if (r0 + (int64_t)(wv * R + c) * 16 < t1) {       // wave-uniform
-#pragma unroll
-                for (int s2 = 0; s2 < STEPS / 2; ++s2) {
-                    adc_i32x4v a;
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int s = 2 * s2 + e;
-                        const unsigned code = (w[c][s >> 2] >> (8 * (s & 3))) & 0xFFu;
-                        const uint2 v = *reinterpret_cast<const uint2*>(smem + code * (L::SLOTS * 8) + off[s]);
-                        a[2 * e] = (int)v.x;
-                        a[2 * e + 1] = (int)v.y;
-                    }
-                    acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
-                }
+            for (int s = 0; s < STEPS; ++s) {
+                unsigned addr;
+#if RC_ADC_IMG16
+                if (s & 1)
+                    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(addr) : "v"(w[c][s >> 1]), "s"(rowbytes), "v"(off[s]));
+                else
+                    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(addr) : "v"(w[c][s >> 1]), "s"(rowbytes), "v"(off[s]));
+#else
+                asm("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_add_u32 %0, %0, %3, %4"
+                    : "=&v"(addr)
+                    : "v"(w[c][s >> 2]), "n"(8 * (s & 3)), "n"(__builtin_ctz(L::SLOTS * 8)), "v"(off[s]));
+#endif
+                typedef unsigned adc_u32x2 __attribute__((ext_vector_type(2)));
+                const adc_u32x2 v = *reinterpret_cast<const adc_u32x2 __attribute__((address_space(3)))*>(addr);
+                e[s] = make_uint2(v.x, v.y);
             }
-        }
-        if constexpr (PREFETCH) {
+        };
+        auto fold = [&](int c, const uint2 (&e)[STEPS]) {
 #pragma unroll
-            for (int c = 0; c < R; ++c)
+            for (int s2 = 0; s2 < STEPS / 2; ++s2) {
+                const adc_i32x4v a = {(int)e[2 * s2].x, (int)e[2 * s2].y, (int)e[2 * s2 + 1].x, (int)e[2 * s2 + 1].y};
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
+            }
+        };
+        gather(0, ea);
 #pragma unroll
-                for (int j = 0; j < NW; ++j) w[c][j] = wn[c][j];
+        for (int c = 0; c < R; c += 2) {
+            if (c + 1 < R) gather(c + 1, eb);
+            fold(c, ea);
+            if (c + 2 < R) gather(c + 2, ea);
+            if (c + 1 < R) fold(c + 1, eb);
         }
         if (it % NP == NP - 1) {
+            // survivors are rare (~2e-4 of the (row, query) pairs): one max over the round's accumulators decides
+            int top = INT_MIN;
 #pragma unroll
-            for (int c = 0; c < R; ++c) {
-                const int64_t i0 = r0 + (int64_t)(wv * R + c) * 16;
-                if (i0 < t1) {
-                    bool any = false;
+            for (int c = 0; c < R; ++c) top = max(top, max(max(acc[c][0], acc[c][1]), max(acc[c][2], acc[c][3])));
+            if (__ballot(top >= tq)) {
+                const unsigned r0 = (unsigned)(it / NP) * ROUND + (unsigned)(wv * R * 16);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) any |= (acc[c][e] >= tq);
-                    if (__ballot(any)) {                      // rare: ~2e-4 of the (row, query) pairs pass
+                for (int c = 0; c < R; ++c) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int64_t n = i0 + 4 * g + e; // D[row = 4 g + e][column = r]
-                            if (acc[c][e] >= tq && n < t1) {
-                                const unsigned slot = atomicAdd(id_count + q0 + r, 1u);
-                                if (slot < ADC_ID_CAP) ids[(size_t)(q0 + r) * ADC_ID_CAP + slot] = (unsigned)n;
-                            }
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned n = r0 + 16u * c + 4u * g + e;   // D[row = 4 g + e][column = r]
+                        if (acc[c][e] >= tq && n < nrows) {
+                            const unsigned slot = atomicAdd(id_count + q0 + r, 1u);
+                            if (slot < ADC_ID_CAP) ids[(size_t)(q0 + r) * ADC_ID_CAP + slot] = (unsigned)(t0 + n);
                         }
                     }
                 }
             }
         }
+    };
+    unsigned wa[R][NW], wb[PREFETCH ? R : 1][NW];
+    int in_lds = -1;
+    if constexpr (PREFETCH) {
+        // ping-pong over the two code buffers: no register copies between steps
+        load_step(0, wa);
+        for (int it = 0; it < nsteps; it += 2) {              // block-uniform
+            run_step(it, wa, wb, in_lds);
+            if (it + 1 < nsteps) run_step(it + 1, wb, wa, in_lds);
+        }
+    } else {
+        for (int it = 0; it < nsteps; ++it) run_step(it, wa, wb, in_lds);
     }
 }
 
@@ -1107,7 +1144,7 @@ static adc_ws_layout adc_layout(int64_t N, int M, int nq, bool own_image = true)
         L.ids = o;   o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
     }
     L.image = o;
-    if (own_image && N >= ADC_SCREEN_MIN_N && adc_cf_supported(M)) o += rc_align_up((size_t)N * M, 256);
+    if (own_image && N >= ADC_SCREEN_MIN_N && adc_cf_supported(M)) o += rc_align_up((size_t)N * M * ADC_IMG_ES, 256);
     L.total = o;
     return L;
 }
@@ -1124,7 +1161,7 @@ extern "C" size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, in
 // bytes of the permuted code image of an N-row index (0: this M has no conflict-free screen, no image is used)
 extern "C" size_t rc_adc_scan_image_bytes(int64_t N, int M) {
     if (N < 0 || !adc_cf_supported(M)) return 0;
-    return (size_t)N * M;
+    return (size_t)N * M * ADC_IMG_ES;
 }
 // Host-side description of the conflict-free layout (no GPU involved; what tests/test_abi.py checks): for lane `lane`
 // (0..63) of a wave and gather step `step` (0 .. steps_per_lane-1) of one table phase: the 8-byte LDS slot it reads and the
@@ -1212,7 +1249,8 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
     constexpr bool CF = (M == 16 || M == 32 || M == 48 || M == 64 || M == 96);
     if (CF && image != nullptr) {
         if constexpr (CF) {
-            constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP, R = (NP == 1) ? 4 : 8;
+            constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP;
+            constexpr int R = (NP == 2) ? 8 : ((M == 64 || (ADC_IMG_ES == 2 && M == 48)) ? 2 : 4);   // register budget
             auto kern = adc_screen_cf_kernel<M, NP, R>;
             constexpr int sl = adc_cf<PM>::TABLE_BYTES;
             hipLaunchKernelGGL(adc_qlut_cf_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, PM,
@@ -1220,7 +1258,8 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             RC_LAUNCH_CHECK(h);
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 7) / 8), tiles), dim3(ADC_THREADS), sl, s, image, N, b.qlut,
+            const unsigned cf_tiles = (unsigned)((N + ADC_CF_TILE - 1) / ADC_CF_TILE);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 7) / 8), cf_tiles), dim3(ADC_THREADS), sl, s, image, N, b.qlut,
                                b.tint, nq, b.idcnt, b.ids);
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             RC_LAUNCH_CHECK(h);

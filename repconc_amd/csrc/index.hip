@@ -82,14 +82,14 @@ extern "C" int rc_index_reserve(rc_index_t idx, int64_t rows, rc_stream_t stream
     const bool with_image = rc_adc_scan_image_bytes(1, idx->M) > 0;
     RC_IDX_HIP(idx, hipMalloc((void**)&fresh, (size_t)rows * idx->M));
     if (with_image) {
-        hipError_t e = hipMalloc((void**)&fresh_img, (size_t)rows * idx->M);
+        hipError_t e = hipMalloc((void**)&fresh_img, rc_adc_scan_image_bytes(rows, idx->M));
         if (e != hipSuccess) { (void)hipFree(fresh); idx->h->last_hip_error = (int)e; return RC_EHIP; }
     }
     hipStream_t s = (hipStream_t)stream;
     if (idx->n > 0) {
         hipError_t e = hipMemcpyAsync(fresh, idx->codes, (size_t)idx->n * idx->M, hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess && with_image)
-            e = hipMemcpyAsync(fresh_img, idx->image, (size_t)idx->n * idx->M, hipMemcpyDeviceToDevice, s);
+            e = hipMemcpyAsync(fresh_img, idx->image, rc_adc_scan_image_bytes(idx->n, idx->M), hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);            // the old blocks are freed right below
         if (e != hipSuccess) {
             (void)hipFree(fresh);

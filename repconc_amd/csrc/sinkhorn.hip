@@ -359,11 +359,11 @@ __global__ __launch_bounds__(SK_THREADS) void sk_argmax_kernel(const float* __re
 //      v_fract_f64 / v_cvt_i32_f64 split it directly (no rndne + sub); with N = 4096 table entries a degree-2 minimax
 //      polynomial on [0,1) reproduces 2^(r/N) to 2.5e-14 (the rounding of u' itself is 8e-14, as in version 1).  The column
 //      normalisation multiplies by a Newton-refined v_rcp_f64 instead of dividing.
-//  (3) Work partition: the M*B columns are split into gridDim.x EQUAL contiguous ranges of the flattened (m, b) index, one
-//      per block, gridDim.x = resident blocks (4 per CU): every block does the same work in ONE round (version 1 ran
-//      4608 blocks on 1024 slots = 4.5 rounds), loads the exp table once, and pays the prologue once (twice when its range
-//      straddles two sub-quantisers).  A block's row sums go to slot (block - first block of m) of that m's partial list;
-//      the last block of an m to arrive adds the slots in order.
+//  (3) Work partition: grid (nbm, M) with nbm = floor(resident blocks / M) equal column ranges per sub-quantiser (M = 48:
+//      21 x 48 = 1008 blocks on the chip's 1024 slots at 4 per CU): every block does the same work in ONE round (version 1
+//      ran 4608 blocks on 1024 slots = 4.5 rounds), loads the exp table once and pays the prologue once.  A block's row
+//      sums go to slot blockIdx.x of its sub-quantiser's partial list; the last block of an m to arrive adds the slots in
+//      order and re-arms the arrival counter.
 //
 // LDS (static): table 32 KiB (the block-reduction scratch aliases it) + 256 offset potentials + a few words: 34 KiB, four
 // blocks per CU.  Order of every sum is fixed by (B, M, gridDim.x): results are identical run to run.
@@ -430,21 +430,17 @@ __device__ __forceinline__ void sk2_column(const float (&x)[SK_EPL], const doubl
     }
 }
 
-// The T = M*B flattened columns are split into nb contiguous ranges, the first r = T % nb of them one column longer
-// (q + 1 = T / nb + 1 columns).  32-bit arithmetic throughout (the host rejects T >= 2^31).
+// The B columns of a sub-quantiser are split into gridDim.x contiguous ranges, the first r = B % gridDim.x of them one
+// column longer (q + 1 = B / gridDim.x + 1 columns).
 __device__ __forceinline__ unsigned sk2_range_lo(unsigned i, unsigned q, unsigned r) { return i * q + (i < r ? i : r); }
-__device__ __forceinline__ unsigned sk2_block_of(unsigned x, unsigned q, unsigned r) {
-    const unsigned big = r * (q + 1u);
-    return x < big ? x / (q + 1u) : r + (x - big) / q;
-}
 
 // MODE 0: first sweep on a centred table; 1: first sweep, centring fused (d holds the raw table); 2: sweep t >= 1.
 template <int MODE, bool FKLDS>
 __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_sweep2_kernel(
     float* __restrict__ d, const double* __restrict__ rows_prev, int G, const double* __restrict__ f_in,
     double* __restrict__ f_out, int* __restrict__ gq, double* __restrict__ part, unsigned* __restrict__ counters,
-    double* __restrict__ rows_out, unsigned B, int M, unsigned rq, unsigned rr, int part_stride, double nse, double scale,
-    double lmax, const double* __restrict__ exp2_tab, int t, int* __restrict__ flags, const float* __restrict__ cmx,
+    double* __restrict__ rows_out, unsigned B, int M, unsigned rq, unsigned rr, double nse, double scale, double lmax,
+    const double* __restrict__ exp2_tab, int t, int* __restrict__ flags, const float* __restrict__ cmx,
     const float* __restrict__ cmn) {
     constexpr bool FIRST = MODE != 2;
     static_assert(!(FIRST && FKLDS), "the first sweep has no row potentials");
@@ -457,14 +453,10 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
     const int tid = threadIdx.x;
     const int lane = tid & (SK_GROUP - 1);
     const int grp = tid / SK_GROUP;
-    const unsigned bi = blockIdx.x;
-    const unsigned lo = sk2_range_lo(bi, rq, rr), hi = sk2_range_lo(bi + 1u, rq, rr);
-    bool bad = false, range = false;
-    if (lo >= hi) return;                                     // the host never launches more blocks than columns / 32
-    for (unsigned m = lo / B; m * B < hi; ++m) {
-        const unsigned mb = m * B;
-        const unsigned c0 = (lo > mb ? lo : mb) - mb;
-        const unsigned c1 = (hi < mb + B ? hi : mb + B) - mb;
+    const unsigned bi = blockIdx.x, m = blockIdx.y;
+    const unsigned c0 = sk2_range_lo(bi, rq, rr), c1 = sk2_range_lo(bi + 1u, rq, rr);
+    bool bad = false;
+    {
         // ---- (a) everything with a long latency first: the table, the first column
         double2 tv[SK2_N / 2 / SK_THREADS];
 #pragma unroll
@@ -493,7 +485,10 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
         for (int j = 0; j < SK2_N / 2 / SK_THREADS; ++j)
             reinterpret_cast<double2*>(s_tab)[j * SK_THREADS + tid] = tv[j];
         double fn = 0.0;
-        if constexpr (!FIRST) fn = fo - log(rs);
+        if constexpr (!FIRST) {
+            fn = fo - log(rs);
+            if (bi == 0) f_out[(size_t)m * RC_K + tid] = fn;
+        }
         double flo = fn, fhi = fn;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -509,7 +504,8 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
         int ex = 0;
         (void)frexp(need, &ex);
         const double offd = ldexp(1.0, ex);
-        range |= !(need < SK2_UMAX / 2) || !((lmax + fhi) * scale + offd < SK2_UMAX);
+        // reported at once (a value kept for the end of the kernel would sit in scratch for the whole main loop)
+        if ((!(need < SK2_UMAX / 2) || !((lmax + fhi) * scale + offd < SK2_UMAX)) && tid == 0) atomicOr(flags, RC_FLAG_RANGE);
         const int off8 = (int)offd << 3;
         {
             const int ki = ((tid >> 6) << 2) | (tid & 3), kl = (tid >> 2) & 15;     // tid = sk_kidx(kl, ki)
@@ -553,22 +549,26 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
 #pragma unroll
         for (int i = 0; i < SK_EPL; ++i) red[grp][sk_kidx(lane, i)] = R[i];
         __syncthreads();
-        double s = red[0][tid];
+        // an opaque copy of the thread index: the epilogue's addresses are formed here, not before the main loop (where
+        // the compiler would park them in scratch for the duration — the kernel sits exactly at its 128-VGPR budget)
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        double s = red[0][tid_e];
 #pragma unroll
-        for (int q = 1; q < SK_NG; ++q) s += red[q][tid];
+        for (int q = 1; q < SK_NG; ++q) s += red[q][tid_e];
         // ---- (e) hand the partial to whichever block of this m arrives last: write-through (sc1) 8-byte stores, every
         // wave drains them, one relaxed agent-scope counter add; the reducer reads with L1-bypassing loads.
-        const unsigned first = sk2_block_of(mb, rq, rr);
-        const unsigned cnt = sk2_block_of(mb + B - 1u, rq, rr) - first + 1u;
-        const unsigned slot = bi - first;
-        double* pm = part + (size_t)m * part_stride * RC_K;
-        __hip_atomic_store(pm + (size_t)slot * RC_K + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!FIRST && slot == 0) f_out[(size_t)m * RC_K + tid] = fn;
+        const unsigned cnt = gridDim.x, slot = bi;
+        double* pm = part + (size_t)m * cnt * RC_K;
+        __hip_atomic_store(pm + (size_t)slot * RC_K + tid_e, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
+        if (tid_e == 0) {
             const unsigned old = __hip_atomic_fetch_add(counters + m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = ((old + 1u) % cnt == 0u);
+            s_last = (old + 1u == cnt);
+            // the last arriver re-arms the counter: the next sweep may use another grid (first sweep: 4 blocks per CU,
+            // register-potential sweeps: 3), so nothing may depend on the count left behind
+            if (old + 1u == cnt) __hip_atomic_store(counters + m, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (s_last) {
@@ -579,24 +579,16 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
                 double v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    v[j] = __hip_atomic_load(pm + (size_t)(i + j) * RC_K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[j] = __hip_atomic_load(pm + (size_t)(i + j) * RC_K + tid_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc += v[j];
             }
             for (; i < cnt; ++i)
-                acc += __hip_atomic_load(pm + (size_t)i * RC_K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            rows_out[(size_t)m * RC_K + tid] = acc;
+                acc += __hip_atomic_load(pm + (size_t)i * RC_K + tid_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rows_out[(size_t)m * RC_K + tid_e] = acc;
         }
-        __syncthreads();      // s_last, red (= the table) are rewritten by the next segment
     }
-    const int fl = (bad ? RC_FLAG_NONFINITE : 0) | (range ? RC_FLAG_RANGE : 0);
-    const unsigned long long anyb = __ballot(fl != 0);
-    if (anyb) {
-        int all = fl;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) all |= __shfl_xor(all, o);
-        if ((tid & 63) == 0) atomicOr(flags, all);
-    }
+    if (__any(bad) && (tid & 63) == 0) atomicOr(flags, RC_FLAG_NONFINITE);
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -619,17 +611,18 @@ static double sk_scale() { return (double)SK_N / SK_LN2; }
 
 // version 2 (default) unless RC_SK_V1=1 (the round-1 kernel, kept for A/B runs and as a cross-check in the tests)
 static bool sk_use_v2() { return rc_env_int("RC_SK_V1", 0) == 0; }
-// blocks of the version-2 sweep: `per_cu` resident blocks per CU, never fewer than ~32 columns per block
-static int sk2_num_blocks(rc_handle_t h, int64_t B, int M, int per_cu) {
-    const int64_t T = (int64_t)M * B;
+// blocks per sub-quantiser of the version-2 sweep: the chip's resident slots (`per_cu` per CU) divided by M, never fewer
+// than ~32 columns per block.  RC_SK_NB overrides the TOTAL number of blocks (tests).
+static int sk2_blocks_per_m(rc_handle_t h, int64_t B, int M, int per_cu) {
     int64_t nb = rc_env_int("RC_SK_NB", 0);
     if (nb <= 0) nb = (int64_t)per_cu * (h && h->num_cus > 0 ? h->num_cus : 256);
-    const int64_t cap = T / 32 > 0 ? T / 32 : 1;
-    if (nb > cap) nb = cap;
     if (nb > SK2_MAX_BLOCKS) nb = SK2_MAX_BLOCKS;
-    return (int)nb;
+    int64_t nbm = nb / M;
+    const int64_t cap = B / 32;
+    if (nbm > cap) nbm = cap;
+    if (nbm < 1) nbm = 1;
+    return (int)nbm;
 }
-static int sk2_part_stride(int nb, int M) { return nb / M + 2; }   // partial slots per sub-quantiser (>= blocks touching it)
 
 struct sk_sweep_ws {
     size_t part, counters, total;
@@ -639,7 +632,7 @@ static sk_sweep_ws sk_ws(int64_t B, int M) {
     const int cpb = sk_cols_per_block(B, M);
     const int64_t nblk = (B + cpb - 1) / cpb;
     size_t slots = (size_t)M * nblk;                                               // version 1
-    const size_t slots2 = (size_t)M * sk2_part_stride(SK2_MAX_BLOCKS, M);         // version 2, any grid
+    const size_t slots2 = (size_t)SK2_MAX_BLOCKS + M;                              // version 2, any grid (M * nbm <= max blocks)
     if (slots2 > slots) slots = slots2;
     w.part = 0;
     w.counters = rc_align_up(slots * RC_K * sizeof(double), 256);
@@ -661,34 +654,34 @@ static int sk2_launch(rc_handle_t h, int mode, float* d, const double* rows_prev
     const double nse = -scale / eps;
     const double lmax = (1.0 + 1e-6) / eps;                // |centred distance| < 1 (amp = half range + 1e-5)
     int* gq = reinterpret_cast<int*>(g);
-    if ((int64_t)M * B >= (1ll << 31)) return RC_ESHAPE;
-    const unsigned Tc = (unsigned)((int64_t)M * B), Bu = (unsigned)B;
+    if (B >= (1ll << 31)) return RC_ESHAPE;
+    const unsigned Bu = (unsigned)B;
     const double* f_in = (mode == 2) ? f2 + (size_t)((t - 1) & 1) * M * RC_K : nullptr;
     double* f_out = (mode == 2) ? f2 + (size_t)(t & 1) * M * RC_K : nullptr;
+    // default: potentials re-read from LDS (120 VGPRs, four blocks per CU); RC_SK_FKLDS=0: potentials in registers, three
+    // blocks per CU.  The first sweep uses the same grid.
+    const bool fklds = rc_env_int("RC_SK_FKLDS", 1) != 0;
+    const unsigned nbm = (unsigned)sk2_blocks_per_m(h, B, M, fklds ? 4 : 3);
+    const dim3 grid(nbm, (unsigned)M);
     if (mode != 2) {
-        const int nb = sk2_num_blocks(h, B, M, 4);
         RC_HIP_CHECK(h, hipMemsetAsync(counters, 0, (size_t)M * sizeof(unsigned), s));
         if (mode == 0)
-            hipLaunchKernelGGL((sk_sweep2_kernel<0, false>), dim3((unsigned)nb), dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
-                               f_out, gq, part, counters, rows_out, Bu, M, Tc / (unsigned)nb, Tc % (unsigned)nb, sk2_part_stride(nb, M), nse, scale, lmax, tab, t,
+            hipLaunchKernelGGL((sk_sweep2_kernel<0, false>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
+                               f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
                                flags, mx, mn);
         else
-            hipLaunchKernelGGL((sk_sweep2_kernel<1, false>), dim3((unsigned)nb), dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
-                               f_out, gq, part, counters, rows_out, Bu, M, Tc / (unsigned)nb, Tc % (unsigned)nb, sk2_part_stride(nb, M), nse, scale, lmax, tab, t,
+            hipLaunchKernelGGL((sk_sweep2_kernel<1, false>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
+                               f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
                                flags, mx, mn);
     } else {
-        // default: potentials re-read from LDS (120 VGPRs, four blocks per CU); RC_SK_FKLDS=0: potentials in registers,
-        // three blocks per CU
-        const bool fklds = rc_env_int("RC_SK_FKLDS", 1) != 0;
-        const int nb = sk2_num_blocks(h, B, M, fklds ? 4 : 3);
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
         if (fklds)
-            hipLaunchKernelGGL((sk_sweep2_kernel<2, true>), dim3((unsigned)nb), dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
-                               f_out, gq, part, counters, rows_out, Bu, M, Tc / (unsigned)nb, Tc % (unsigned)nb, sk2_part_stride(nb, M), nse, scale, lmax, tab, t,
+            hipLaunchKernelGGL((sk_sweep2_kernel<2, true>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
+                               f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
                                flags, mx, mn);
         else
-            hipLaunchKernelGGL((sk_sweep2_kernel<2, false>), dim3((unsigned)nb), dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
-                               f_out, gq, part, counters, rows_out, Bu, M, Tc / (unsigned)nb, Tc % (unsigned)nb, sk2_part_stride(nb, M), nse, scale, lmax, tab, t,
+            hipLaunchKernelGGL((sk_sweep2_kernel<2, false>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
+                               f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
                                flags, mx, mn);
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
     }

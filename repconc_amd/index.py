@@ -40,7 +40,8 @@ class PQIndex:
         self._codes = torch.empty((0, M), dtype=torch.uint8, device=self.device)
         # permuted copy of the codes streamed by the conflict-free ADC screen (csrc/adc_search.hip), kept in step
         # with `_codes` row for row; None for the M that do not use one
-        self._image = torch.empty((0, M), dtype=torch.uint8, device=self.device) if ops.adc_image_supported(M) else None
+        self._image = (torch.empty((0, ops.adc_image_row_bytes(M)), dtype=torch.uint8, device=self.device)
+                       if ops.adc_image_supported(M) else None)
         self.pq = SimpleNamespace(d=d, M=M, nbits=nbits, code_size=M, ksub=256, dsub=d // M, centroids=self._centroids)
 
     # ---- Faiss-like attributes
@@ -74,7 +75,7 @@ class PQIndex:
             grown[: self.ntotal] = self._codes[: self.ntotal]
             self._codes = grown
             if self._image is not None:
-                gi = torch.empty_like(grown)
+                gi = torch.empty((grown.shape[0], self._image.shape[1]), dtype=torch.uint8, device=self.device)
                 gi[: self.ntotal] = self._image[: self.ntotal]
                 self._image = gi
         self._codes[self.ntotal:need] = c.to(self.device)

@@ -390,21 +390,26 @@ def adc_lut(centroids: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
     return lut
 
 
+def adc_image_row_bytes(M: int) -> int:
+    """Bytes per row of the permuted code image the ADC screen of this M streams (rc_adc_scan_image); 0 = none."""
+    return int(_lib.load().rc_adc_scan_image_bytes(1, int(M)))
+
+
 def adc_image_supported(M: int) -> bool:
-    """True when the ADC screen of this M reads a permuted code image (rc_adc_scan_image)."""
-    return _lib.load().rc_adc_scan_image_bytes(1, int(M)) > 0
+    return adc_image_row_bytes(M) > 0
 
 
 def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Optional[int] = None) -> torch.Tensor:
-    """(Re)build rows [n0, n0+n) of the permuted code image of an index (both tensors uint8 [>=n0+n, M], contiguous).
-    The image is what the conflict-free ADC screen streams; see include/repconc_hip.h rc_adc_scan_image."""
+    """(Re)build rows [n0, n0+n) of the permuted code image of an index: codes uint8 [>=n0+n, M], image uint8
+    [>=n0+n, adc_image_row_bytes(M)], both contiguous.  The image is what the conflict-free ADC screen streams; see
+    include/repconc_hip.h rc_adc_scan_image."""
     _need_cuda(codes, image)
     if codes.dtype != torch.uint8 or image.dtype != torch.uint8 or not codes.is_contiguous() or not image.is_contiguous():
-        raise ValueError("codes and image must be contiguous uint8 [N, M]")
+        raise ValueError("codes and image must be contiguous uint8")
     M = codes.shape[1]
     if n is None:
         n = codes.shape[0] - n0
-    if n0 < 0 or n < 0 or n0 + n > codes.shape[0] or n0 + n > image.shape[0] or image.shape[1] != M:
+    if n0 < 0 or n < 0 or n0 + n > codes.shape[0] or n0 + n > image.shape[0] or image.shape[1] != adc_image_row_bytes(M):
         raise ValueError("row range outside the code / image buffers")
     lib, h, s, _ = _ctx(codes)
     _lib.check(lib.rc_adc_scan_image(h, _p(codes), int(n0), int(n), M, _p(image), s), "rc_adc_scan_image", h)
@@ -421,8 +426,9 @@ def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k:
     if codes.dtype != torch.uint8 or not codes.is_contiguous():
         raise ValueError("index codes must be contiguous uint8 [N, M]")
     if scan_image is not None and (scan_image.dtype != torch.uint8 or not scan_image.is_contiguous()
-                                   or scan_image.shape[0] < codes.shape[0] or scan_image.shape[1] != codes.shape[1]):
-        raise ValueError("scan_image must be contiguous uint8 [>=N, M]")
+                                   or scan_image.shape[0] < codes.shape[0]
+                                   or scan_image.shape[1] != adc_image_row_bytes(codes.shape[1])):
+        raise ValueError("scan_image must be contiguous uint8 [>=N, adc_image_row_bytes(M)]")
     c, q = _centroids(centroids), _rows_f32(q).contiguous()
     N, M = codes.shape
     nq, D = q.shape

@@ -1080,11 +1080,14 @@ def test_adc_scan_image_is_a_row_permutation():
     for M in (16, 32, 48, 64, 96):
         base = synth.uniform_codes(5 + M, 16, M)
         codes = _t(np.concatenate([base] * 40 + [synth.uniform_codes(6 + M, 3, M)], 0))        # 643 rows, period 16
-        img = ops.adc_scan_image_(codes, torch.full_like(codes, 255))
-        a, b = np.sort(codes.cpu().numpy(), axis=1), np.sort(img.cpu().numpy(), axis=1)
+        rb = ops.adc_image_row_bytes(M)
+        blank = torch.full((codes.shape[0], rb), 255, dtype=torch.uint8, device=DEV)
+        img = ops.adc_scan_image_(codes, blank.clone())
+        vals = img.cpu().numpy() if rb == M else img.cpu().numpy().view(np.uint16)     # 8- or 16-bit codes
+        a, b = np.sort(codes.cpu().numpy(), axis=1), np.sort(vals, axis=1)
         assert np.array_equal(a, b)
         assert torch.equal(img[:16], img[16:32]) and torch.equal(img[:16], img[624:640])
-        part = torch.full_like(codes, 255)
+        part = blank.clone()
         ops.adc_scan_image_(codes, part, 100, 37)
         assert torch.equal(part[100:137], img[100:137])
         assert bool((part[:100] == 255).all()) and bool((part[137:] == 255).all())
