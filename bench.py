@@ -195,12 +195,21 @@ def main():
         codes, flags = step(i)
     barrier()
     import ctypes
-    lib.rc_profile_enable(h, 1)
+    # N = 1: every sweep launch of the timed region is bracketed by HIP events (rc_profile_*; the event marks select
+    # the eager launch loop).  N > 1: the timed region runs the product default — sweeps t >= 2 and their all-gathers
+    # replayed from the captured hipGraph — and the per-launch kernel time comes from ONE extra, untimed, profiled step.
+    profile_timed = not use_dist
+    if profile_timed:
+        lib.rc_profile_enable(h, 1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         codes, flags = step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    if not profile_timed:
+        lib.rc_profile_enable(h, 1)
+        step(args.warmup + args.steps)
+        barrier()
     lib.rc_profile_enable(h, 0)
     n_l, ms_l = ctypes.c_int(0), ctypes.c_double(0.0)
     lib.rc_profile_collect(h, _lib.PROF_SK_PASS, ctypes.byref(n_l), ctypes.byref(ms_l))
@@ -215,7 +224,11 @@ def main():
         n_chains = 2 if (world > 1 and M >= 2 and os.environ.get("RC_SHARD_SPLIT", "1") != "0") else 1
     alg_bytes = bl * (M // n_chains) * K * 4
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if n_l.value else 0.0
-    roofline = {"kernel": "sk_sweep_kernel<false, false, true> (Sinkhorn sweep incl. fused row/column updates; 4 waves/SIMD variant)", "bound": "hbm", "achieved": round(achieved, 1),
+    roofline = {"kernel": "sk_sweep2_kernel<2, true> (Sinkhorn sweep t >= 1 incl. fused row-potential update and integer "
+                          "column exponents; potentials from LDS, 4 blocks per CU, one equal column range per block)",
+                "measured_in": "timed region, HIP events around every launch" if profile_timed else
+                               "one extra profiled step after the timed region (the timed region replays the hipGraph)",
+                "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic("sk_sweep_kernel"), "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(sweep_ms, 4), "launches_timed": n_l.value,
@@ -246,6 +259,33 @@ def main():
     if dist_check is not None:
         out["multi_gpu_check"] = dist_check
 
+    # ------------------------------------------------------------------ the 8-GPU recipe's per-rank shape on this GPU
+    if not use_dist and B == B_GLOBAL:
+        blr = B_GLOBAL // 8
+        xr = pool[0][:blr].contiguous()
+        for _ in range(2):
+            ops.assign_sinkhorn(xr, C, EPS, ITERS, torch.uint8)
+        torch.cuda.synchronize()
+        lib.rc_profile_enable(h, 1)
+        t0 = time.perf_counter()
+        nrep = 10
+        for _ in range(nrep):
+            ops.assign_sinkhorn(xr, C, EPS, ITERS, torch.uint8)
+        torch.cuda.synchronize()
+        rdt = (time.perf_counter() - t0) / nrep
+        lib.rc_profile_enable(h, 0)
+        lib.rc_profile_collect(h, _lib.PROF_SK_PASS, ctypes.byref(n_l), ctypes.byref(ms_l))
+        rs_ms = ms_l.value / max(n_l.value, 1)
+        r_alg = blr * M * K * 4
+        out["per_rank_6144"] = {
+            "what": "one rank's share of the 8-GPU recipe (6144 x 768, M=48) solved stand-alone on this GPU: no "
+                    "collective in it, so 8 x value is the ceiling of the 8-GPU run before any all-gather latency",
+            "value": round(blr / rdt, 1), "unit": "vectors/s", "ms_per_step": round(rdt * 1e3, 3),
+            "roofline": {"kernel": "sk_sweep2_kernel<2, true>", "bound": "hbm", "achieved": round(r_alg / (rs_ms * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(r_alg / (rs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch": r_alg, "avg_launch_ms": round(rs_ms, 4),
+                         "launches_timed": n_l.value}}
+
     # ------------------------------------------------------------------ ADC search leg
     if not args.no_adc:
         del pool
@@ -258,9 +298,15 @@ def main():
         per_rank = nq_batch // world
         k = args.adc_k
 
+        from repconc_amd.index import PQIndex
+        index = PQIndex(D, M, device=dev)                      # keeps the permuted code image next to the codes
+        index.set_centroids(C)
+        index.add_codes(index_codes)
+        index_codes = index.codes
+
         def search(bi):
             q = q_all[bi * nq_batch + rank * per_rank: bi * nq_batch + (rank + 1) * per_rank]
-            return ops.adc_search(index_codes, C, q, k)
+            return index.search(q, k)
 
         search(0)
         barrier()
@@ -276,19 +322,56 @@ def main():
         scan_ms = ms_l.value / max(n_l.value, 1)
         adc_alg = per_rank * N_CORPUS * M          # N*M code bytes per query
         adc_ach = adc_alg / (scan_ms * 1e-3) / 1e9 if n_l.value else 0.0
+        # LDS gather roof ("then the bound is LDS gather rate"): one 8-byte table entry per (row,
+        # sub-quantiser, group of 8 queries), 256 CUs x 256 B/clk x 2.4 GHz for conflict-free ds_read_b64
+        lds_peak = 256 * 256 * 2.4                                           # GB/s
+        lds_bytes = ((per_rank + 7) // 8) * N_CORPUS * M * 8
+        lds_ach = lds_bytes / (scan_ms * 1e-3) / 1e9 if n_l.value else 0.0
         out["adc"] = {
             "metric": "adc_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "k": k,
             "index": f"{N_CORPUS} x {M} B uint8 uniform codes, resident", "query_batch": nq_batch,
             "batches": args.adc_batches, "ms_per_batch": round(adt / args.adc_batches * 1e3, 2),
             "parallelism": f"index replicated, queries split x{world}",
-            "roofline": {"kernel": "adc_screen_mfma_kernel<48,8> (8-bit screening scan, i8 MFMA accumulation)", "bound": "hbm", "achieved": round(adc_ach, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(adc_ach / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("adc_screen_mfma_kernel"), "algorithmic_bytes_per_launch": adc_alg,
+            "parity": "ids and score bits equal the repo's C restatement of Faiss IndexPQ search (tests); Faiss itself is "
+                      "not available offline: Faiss-side tie order / last-ulp LUT rounding unpinned",
+            "roofline": {"kernel": "adc_screen_cf_kernel<48,1,4> (8-bit screening scan: conflict-free LDS gathers of "
+                                   "8-query byte tables, 16x16x64 i8 MFMA accumulation)",
+                         "bound": "lds-gather", "achieved": round(lds_ach, 1), "peak": round(lds_peak, 1), "unit": "GB/s",
+                         "frac": round(lds_ach / lds_peak, 4), "lds_bytes_per_launch": lds_bytes,
                          "avg_launch_ms": round(scan_ms, 3), "launches_timed": n_l.value,
-                         "note": "algorithmic bytes = N*M code bytes per query (SURVEY 8d); 8 queries share every code "
-                                 "read and tiles are re-read from L2, so frac > 1 — the physical limit is the LDS "
-                                 "gather rate (random 8-byte reads, 67 % bank-conflict cycles; DESIGN.md §4)"},
+                         "hbm_equivalent": {"algorithmic_bytes_per_launch": adc_alg, "achieved_GBs": round(adc_ach, 1),
+                                            "note": "N*M code bytes per query (SURVEY 8d) / kernel time: 8 queries share every "
+                                                    "code read and tiles are re-read from L2, so this exceeds the HBM peak and is "
+                                                    "not a roofline"},
+                         "traffic": pmc_traffic("adc_screen_cf_kernel")},
         }
+
+    if not args.no_adc:
+        # k in {10, 200} at M = 48 and the M = 96 index (BASELINE configs[3] flat leg), one batch each
+        sweep = {}
+        for kk in (10, 200):
+            search(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            index.search(q_all[:nq_batch], kk)
+            torch.cuda.synchronize()
+            sweep[f"M48_k{kk}"] = round(nq_batch / (time.perf_counter() - t0), 1)
+        del index
+        torch.cuda.empty_cache()
+        M2 = 96
+        C96 = torch.randn((M2, K, D // M2), device=dev, generator=torch.Generator(device=dev).manual_seed(20226))
+        idx96 = PQIndex(D, M2, device=dev)
+        idx96.set_centroids(C96)
+        idx96.add_codes(torch.randint(0, 256, (N_CORPUS, M2), dtype=torch.uint8, device=dev, generator=gen))
+        idx96.search(q_all[:nq_batch], k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx96.search(q_all[:nq_batch], k)
+        torch.cuda.synchronize()
+        sweep[f"M96_k{k}"] = round(nq_batch / (time.perf_counter() - t0), 1)
+        del idx96
+        torch.cuda.empty_cache()
+        out["adc"]["other_shapes_queries_per_sec"] = sweep
 
     # ------------------------------------------------------------------ index-build leg (nearest codes, a-1/a-5)
     if not args.no_adc:
@@ -344,6 +427,46 @@ def main():
             "cpu": _cpu_model(),
         }
         out["speedup_vs_cpu_baseline"] = round(value / (Bs / cdt), 1)
+        # the same port on ONE thread (1024-row batch: ~10 s)
+        c_oracle.set_num_threads(1)
+        t0 = time.perf_counter()
+        c_oracle.quantize(xs[:1024], cent, True, EPS, ITERS)
+        c1 = time.perf_counter() - t0
+        out["cpu_baseline_single_thread"] = {"value": round(1024 / c1, 1), "unit": "vectors/s", "cores": 1, "kind": "port",
+                                             "sample": f"one 1024x768 batch, same port, {c1:.1f} s"}
+        # nearest-code assignment (index build) and k-means sufficient statistics on the host
+        t0 = time.perf_counter()
+        near1, _ = c_oracle.quantize(xs[:512], cent, False)
+        n1 = time.perf_counter() - t0
+        c_oracle.set_num_threads(cores)
+        t0 = time.perf_counter()
+        near_c, _ = c_oracle.quantize(xs, cent, False)
+        nall = time.perf_counter() - t0
+        from oracle import pq_oracle
+        t0 = time.perf_counter()
+        pq_oracle.kmeans_stats(xs, near_c, M)
+        ks = time.perf_counter() - t0
+        if "index_build" in out:
+            out["index_build"]["cpu_baseline"] = {
+                "value": round(Bs / nall, 1), "unit": "vectors/s", "cores": cores, "kind": "port",
+                "sample": f"{Bs} rows, exact fp32 nearest codes, oracle/pq_oracle.c ({nall:.2f} s); one thread: "
+                          f"{512 / n1:.0f} vectors/s (512 rows, {n1:.2f} s)"}
+            out["index_build"]["speedup_vs_cpu_baseline"] = round(out["index_build"]["value"] / (Bs / nall), 1)
+        xg, cg = torch.from_numpy(xs).to(dev), torch.from_numpy(near_c).to(dev)
+        ops.kmeans_stats(xg, cg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ops.kmeans_stats(xg, cg)
+        torch.cuda.synchronize()
+        kg = (time.perf_counter() - t0) / 10
+        out["kmeans_stats"] = {"metric": "kmeans_sufficient_statistics_vectors_per_sec", "value": round(Bs / kg, 1),
+                               "unit": "vectors/s", "rows": Bs, "ms": round(kg * 1e3, 3),
+                               "roofline": {"bound": "hbm", "achieved": round(Bs * (D * 4 + M) / kg / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                            "unit": "GB/s", "frac": round(Bs * (D * 4 + M) / kg / 1e9 / HBM_PEAK_GBS, 4),
+                                            "note": "4 D + M bytes per vector (SURVEY 8d); small batch, launch-bound"},
+                               "cpu_baseline": {"value": round(Bs / ks, 1), "unit": "vectors/s", "cores": 1, "kind": "port",
+                                                "sample": f"{Bs} rows, numpy restatement oracle/pq_oracle.py ({ks:.2f} s)"}}
         if not args.no_adc:
             # ~8 queries per thread over the WHOLE index: about 10 s of host time whatever the core count
             nq_c = min(8 * cores, int(q_all.shape[0]))

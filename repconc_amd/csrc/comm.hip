@@ -98,6 +98,12 @@ extern "C" int rc_comm_destroy(rc_handle_t h) {
     nccl_api* n = nccl();
     for (int i = 0; i < 2; ++i)
         if (h->comm[i] && n) { (void)n->CommDestroy((ncclComm_t)h->comm[i]); h->comm[i] = nullptr; }
+    // cached iteration graphs hold the communicators and the side stream
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        g.exec = nullptr; g.graph = nullptr; g.ws = nullptr; g.stamp = 0;
+    }
     if (h->side_stream) { (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
     if (h->ev_fork) { (void)hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
     if (h->ev_join) { (void)hipEventDestroy(h->ev_join); h->ev_join = nullptr; }
@@ -161,78 +167,191 @@ bool want_split(int world) {
 }
 }  // namespace
 
-size_t rc_solve_ws_bytes(int64_t B, int M, int world) { return dist_layout(B, M, world, true).total; }
+size_t rc_solve_ws_bytes(int64_t B, int M, int world) {
+    return dist_layout(B > 0 ? B : 1, M, world, true).total + 256;   // + the solve's own flag word
+}
+
+namespace {
+__global__ void solve_fill_range_kernel(float* __restrict__ minmax, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) { minmax[i] = -INFINITY; minmax[M + i] = INFINITY; }   // neutral elements of the MAX / MIN all-reduce
+}
+__global__ void solve_merge_flags_kernel(const int* __restrict__ own, int* __restrict__ out) {
+    if (*own) atomicOr(out, *own);
+}
+
+// One iteration (sweep t of every chain + its all-gather).  Shared by the eager loop and the capture.
+struct solve_ctx {
+    rc_handle_t h; nccl_api* n; const dist_ws* L; char* w; float* d; float* minmax; int64_t B; int M, G; double eps;
+    int* flags; hipStream_t st[2]; bool fuse_centre, coll;
+};
+int solve_iteration(const solve_ctx& c, int t) {
+    const dist_ws& L = *c.L;
+    for (int ch = 0; ch < L.nch; ++ch) {
+        const chain_ws& cw = L.ch[ch];
+        const int mc = L.mc[ch];
+        float* dc = c.d + (size_t)L.m0[ch] * c.B * RC_K;
+        double* gath = (double*)(c.w + cw.gathered);
+        const size_t gsz = (size_t)c.G * mc * RC_K;
+        const double* prev = gath + (size_t)((t + 1) & 1) * gsz;   // gathered row sums of sweep t-1
+        double* out = gath + (size_t)(t & 1) * gsz;
+        // one rank: the sweep writes its row sums straight into the "gathered" slot
+        double* rows = c.coll ? (double*)(c.w + cw.rows) : out;
+        int rc = RC_OK;
+        if (c.B == 0) {
+            // a rank without rows contributes zero row sums (already zeroed) and only takes part in the exchange
+        } else if (t == 0 && c.fuse_centre) {
+            rc = rc_sk_sweep0_centre(c.h, dc, c.minmax + L.m0[ch], c.minmax + c.M + L.m0[ch], (double*)(c.w + cw.g),
+                                     (double*)(c.w + cw.colsum), rows, c.B, mc, c.eps, c.flags, c.w + cw.sweep,
+                                     rc_sk_ws_bytes(c.B, mc, RC_K), c.st[ch]);
+        } else {
+            rc = rc_sk_sweep(c.h, dc, prev, c.G, (double*)(c.w + cw.f2), (double*)(c.w + cw.g), (double*)(c.w + cw.colsum),
+                             rows, c.B, mc, RC_K, c.eps, t, c.flags, c.w + cw.sweep, rc_sk_ws_bytes(c.B, mc, RC_K),
+                             (rc_stream_t)c.st[ch]);
+        }
+        if (rc != RC_OK) return rc;
+        if (c.coll)
+            RC_NCCL_CHECK(c.h, c.n->AllGather(rows, out, (size_t)mc * RC_K, ncclDouble, (ncclComm_t)c.h->comm[ch], c.st[ch]));
+    }
+    return RC_OK;
+}
+}  // namespace
 
 // The whole constrained assignment of this rank's rows on `world` ranks (world == 1: no RCCL involved).
+//
+// Ordering invariant (multi-rank): every rank enqueues exactly the same sequence of collectives — per iteration chain 0's
+// all-gather on communicator 0 / stream 0, then chain 1's on communicator 1 / stream 1 — from ONE host thread (or from
+// one captured graph, whose node order is that same sequence).  Two communicators are only ever driven concurrently in
+// that fixed order; a rank with no rows (B == 0) still issues every collective.  RC_DIST_SPLIT=0 falls back to one chain.
+//
+// hipGraph: sweeps t = 2 .. T-1 with their all-gathers (198 kernel launches + 198 collectives per step at T = 100, two
+// chains) are captured once per (workspace, shape, eps, T, world) and replayed with one hipGraphLaunch; t = 0 and 1 stay
+// eager (RCCL finishes its lazy set-up outside the capture).  RC_GRAPH=0, an active rc_profile_enable (per-launch event
+// marks) or a failed capture select the eager loop.
 int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D, int M, double eps,
                     int iters, int world, uint8_t* codes_u8, int64_t* codes_i64, int* flags, void* ws, size_t ws_bytes,
                     hipStream_t s0) {
     const int G = world;
-    nccl_api* n = (G > 1) ? nccl() : nullptr;
-    if (G > 1 && (!n || !h->comm[0])) return RC_ECOMM;
-    if ((int64_t)G * B == 1) {   // a global batch of one row: exact K-way tie, the reference returns code 0
+    // RC_DIST_FORCE_COLL=1 (tests on a one-GPU box): a one-rank communicator still issues every RCCL call of the loop
+    const bool coll = G > 1 || (h->comm[0] && rc_env_int("RC_DIST_FORCE_COLL", 0) != 0);
+    nccl_api* n = coll ? nccl() : nullptr;
+    if (coll && (!n || !h->comm[0])) return RC_ECOMM;
+    if (G == 1 && B == 1) {      // a global batch of one row: exact K-way tie, the reference returns code 0
         if (codes_u8) RC_HIP_CHECK(h, hipMemsetAsync(codes_u8, 0, (size_t)M, s0));
         if (codes_i64) RC_HIP_CHECK(h, hipMemsetAsync(codes_i64, 0, (size_t)M * sizeof(int64_t), s0));
         return RC_OK;
     }
-    const dist_ws L = dist_layout(B, M, G, want_split(G));
-    if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
+    const int64_t Bw = B > 0 ? B : 1;                        // workspace geometry of an empty rank
+    const dist_ws L = dist_layout(Bw, M, G, want_split(G));
+    if (!ws || ws_bytes < L.total + 256) return RC_EWORKSPACE;
     char* w = (char*)ws;
     float* d = (float*)(w + L.d);
     float* minmax = (float*)(w + L.minmax);
+    int* own_flags = (int*)(w + L.total);                     // captured kernels flag here, merged into `flags` at the end
+    RC_HIP_CHECK(h, hipMemsetAsync(own_flags, 0, sizeof(int), s0));
     int rc;
-    if ((rc = rc_pq_dist_table(h, x, ldx, C, B, D, M, RC_K, d, minmax, w + L.dist_ws, rc_pq_dist_table_ws_bytes(B, M),
-                               (rc_stream_t)s0)) != RC_OK) return rc;
-    if (G > 1) {   // modeling_repconc.py:79-80
+    if (B > 0) {
+        if ((rc = rc_pq_dist_table(h, x, ldx, C, B, D, M, RC_K, d, minmax, w + L.dist_ws, rc_pq_dist_table_ws_bytes(B, M),
+                                   (rc_stream_t)s0)) != RC_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(solve_fill_range_kernel, dim3((M + 63) / 64), dim3(64), 0, s0, minmax, M);
+        RC_LAUNCH_CHECK(h);
+        for (int c = 0; c < L.nch; ++c)
+            RC_HIP_CHECK(h, hipMemsetAsync(w + L.ch[c].rows, 0, (size_t)L.mc[c] * RC_K * sizeof(double), s0));
+    }
+    if (coll) {   // modeling_repconc.py:79-80
         RC_NCCL_CHECK(h, n->AllReduce(minmax, minmax, (size_t)M, ncclFloat, ncclMax, (ncclComm_t)h->comm[0], s0));
         RC_NCCL_CHECK(h, n->AllReduce(minmax + M, minmax + M, (size_t)M, ncclFloat, ncclMin, (ncclComm_t)h->comm[0], s0));
     }
     // centring: fused into the first sweep (one pass over the table less); RC_FUSE_CENTRE=0 keeps the separate kernel
     const bool fuse_centre = rc_env_int("RC_FUSE_CENTRE", 1) != 0;
-    if (!fuse_centre && (rc = rc_pq_centre(h, d, minmax, B, M, RC_K, (rc_stream_t)s0)) != RC_OK) return rc;
+    if (B > 0 && !fuse_centre && (rc = rc_pq_centre(h, d, minmax, B, M, RC_K, (rc_stream_t)s0)) != RC_OK) return rc;
 
-    hipStream_t st[2] = {s0, s0};
+    solve_ctx cx = {h, n, &L, w, d, minmax, B, M, G, eps, own_flags, {s0, s0}, fuse_centre, coll};
     if (L.nch == 2) {
         if ((rc = ensure_side_stream(h)) != RC_OK) return rc;
-        st[1] = h->side_stream;
+        cx.st[1] = h->side_stream;
         RC_HIP_CHECK(h, hipEventRecord(h->ev_fork, s0));
-        RC_HIP_CHECK(h, hipStreamWaitEvent(st[1], h->ev_fork, 0));
+        RC_HIP_CHECK(h, hipStreamWaitEvent(cx.st[1], h->ev_fork, 0));
     }
+    auto join = [&]() -> int {
+        if (L.nch == 2) {
+            RC_HIP_CHECK(h, hipEventRecord(h->ev_join, cx.st[1]));
+            RC_HIP_CHECK(h, hipStreamWaitEvent(s0, h->ev_join, 0));
+        }
+        return RC_OK;
+    };
+    auto fork = [&]() -> int {
+        if (L.nch == 2) {
+            RC_HIP_CHECK(h, hipEventRecord(h->ev_fork, s0));
+            RC_HIP_CHECK(h, hipStreamWaitEvent(cx.st[1], h->ev_fork, 0));
+        }
+        return RC_OK;
+    };
     // sweeps t = 0 .. iters-1, the two chains enqueued alternately so both streams stay fed
-    for (int t = 0; t < iters; ++t) {
+    const int variant = rc_env_int("RC_SK_V1", 0) | (rc_env_int("RC_SK_FKLDS", 1) << 1) | (rc_env_int("RC_SK_NB", 0) << 2) |
+                        (rc_env_int("RC_SK_CPB", 0) << 14) | ((int)coll << 24);
+    const bool want_graph = rc_env_int("RC_GRAPH", 1) != 0 && !h->profile_on && !h->graph_broken && iters > 4;
+    int t = 0;
+    const int t_eager = want_graph ? 2 : iters;
+    for (; t < t_eager && t < iters; ++t)
+        if ((rc = solve_iteration(cx, t)) != RC_OK) return rc;
+    if (t < iters) {
+        // ---- sweeps t = 2 .. iters-1 from a cached graph
+        rc_handle_s::solve_graph* hit = nullptr;
+        rc_handle_s::solve_graph* victim = &h->graphs[0];
+        for (auto& g : h->graphs) {
+            if (g.exec && g.ws == ws && g.B == B && g.M == M && g.iters == iters && g.world == G && g.nch == L.nch &&
+                g.variant == variant && g.eps == eps) hit = &g;
+            if (g.stamp < victim->stamp) victim = &g;
+        }
+        if ((rc = join()) != RC_OK) return rc;               // the graph is launched on s0 and forks inside
+        if (!hit) {
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                h->capturing = 1;
+                int crc = fork();
+                for (int tt = t; crc == RC_OK && tt < iters; ++tt) crc = solve_iteration(cx, tt);
+                if (crc == RC_OK) crc = join();
+                h->capturing = 0;
+                const hipError_t e = hipStreamEndCapture(s0, &graph);
+                ok = (crc == RC_OK) && e == hipSuccess && graph != nullptr;
+            }
+            hipGraphExec_t exec = nullptr;
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                if (graph) (void)hipGraphDestroy(graph);
+                h->graph_broken = 1;                         // stay eager on this handle
+            } else {
+                if (victim->exec) (void)hipGraphExecDestroy(victim->exec);
+                if (victim->graph) (void)hipGraphDestroy(victim->graph);
+                *victim = {ws, B, M, iters, G, L.nch, variant, eps, graph, exec, 0};
+                hit = victim;
+            }
+        }
+        if (hit) {
+            hit->stamp = ++h->graph_stamp;
+            RC_HIP_CHECK(h, hipGraphLaunch(hit->exec, s0));
+            if ((rc = fork()) != RC_OK) return rc;           // the argmax launches below use both streams again
+        } else {
+            if ((rc = fork()) != RC_OK) return rc;
+            for (; t < iters; ++t)
+                if ((rc = solve_iteration(cx, t)) != RC_OK) return rc;
+        }
+    }
+    if (B > 0)
         for (int c = 0; c < L.nch; ++c) {
             const chain_ws& cw = L.ch[c];
             const int mc = L.mc[c];
-            const float* dc = d + (size_t)L.m0[c] * B * RC_K;
-            double* gath = (double*)(w + cw.gathered);
-            const size_t gsz = (size_t)G * mc * RC_K;
-            const double* prev = gath + (size_t)((t + 1) & 1) * gsz;   // gathered row sums of sweep t-1
-            double* out = gath + (size_t)(t & 1) * gsz;
-            // one rank: the sweep writes its row sums straight into the "gathered" slot
-            double* rows = (G > 1) ? (double*)(w + cw.rows) : out;
-            if (t == 0 && fuse_centre)
-                rc = rc_sk_sweep0_centre(h, d + (size_t)L.m0[c] * B * RC_K, minmax + L.m0[c], minmax + M + L.m0[c],
-                                         (double*)(w + cw.g), (double*)(w + cw.colsum), rows, B, mc, eps, flags,
-                                         w + cw.sweep, rc_sk_ws_bytes(B, mc, RC_K), st[c]);
-            else
-                rc = rc_sk_sweep(h, dc, prev, G, (double*)(w + cw.f2), (double*)(w + cw.g), (double*)(w + cw.colsum), rows,
-                                 B, mc, RC_K, eps, t, flags, w + cw.sweep, rc_sk_ws_bytes(B, mc, RC_K), (rc_stream_t)st[c]);
-            if (rc != RC_OK) return rc;
-            if (G > 1)
-                RC_NCCL_CHECK(h, n->AllGather(rows, out, (size_t)mc * RC_K, ncclDouble, (ncclComm_t)h->comm[c], st[c]));
+            const double* gath = (const double*)(w + cw.gathered) + (size_t)((iters - 1) & 1) * G * mc * RC_K;
+            if ((rc = rc_sk_argmax_strided(h, d + (size_t)L.m0[c] * B * RC_K, gath, G, (const double*)(w + cw.f2), B, mc, eps,
+                                           iters, M, L.m0[c], codes_u8, codes_i64, own_flags, cx.st[c])) != RC_OK) return rc;
         }
-    }
-    for (int c = 0; c < L.nch; ++c) {
-        const chain_ws& cw = L.ch[c];
-        const int mc = L.mc[c];
-        const double* gath = (const double*)(w + cw.gathered) + (size_t)((iters - 1) & 1) * G * mc * RC_K;
-        if ((rc = rc_sk_argmax_strided(h, d + (size_t)L.m0[c] * B * RC_K, gath, G, (const double*)(w + cw.f2), B, mc, eps,
-                                       iters, M, L.m0[c], codes_u8, codes_i64, flags, st[c])) != RC_OK) return rc;
-    }
-    if (L.nch == 2) {
-        RC_HIP_CHECK(h, hipEventRecord(h->ev_join, st[1]));
-        RC_HIP_CHECK(h, hipStreamWaitEvent(s0, h->ev_join, 0));
-    }
+    if ((rc = join()) != RC_OK) return rc;
+    hipLaunchKernelGGL(solve_merge_flags_kernel, dim3(1), dim3(1), 0, s0, (const int*)own_flags, flags);
+    RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
 
@@ -240,15 +359,15 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
 extern "C" int rc_solve_num_chains(int world, int M) { return (want_split(world) && M >= 2) ? 2 : 1; }
 
 extern "C" size_t rc_pq_assign_sinkhorn_dist_ws_bytes(int64_t B_local, int M, int K, int world) {
-    if (B_local <= 0 || M <= 0 || K != RC_K || world < 1) return 0;
+    if (B_local < 0 || M <= 0 || K != RC_K || world < 1) return 0;
     return rc_solve_ws_bytes(B_local, M, world);
 }
 
 extern "C" int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
                                           int M, int K, double eps, int iters, uint8_t* codes_u8, int64_t* codes_i64,
                                           int* flags, void* ws, size_t ws_bytes, rc_stream_t stream) {
-    if (!h || !h->comm[0] || !x || !C || !flags || B <= 0 || M <= 0 || iters < 1 || !(eps > 0.0) ||
-        (!codes_u8 && !codes_i64))
+    if (!h || !h->comm[0] || !C || !flags || B < 0 || (B > 0 && !x) || M <= 0 || iters < 1 || !(eps > 0.0) ||
+        (B > 0 && !codes_u8 && !codes_i64))
         return RC_EINVAL;
     if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
     return rc_solve_chains(h, x, ldx, C, B, D, M, eps, iters, h->comm_world, codes_u8, codes_i64, flags, ws, ws_bytes,

@@ -40,6 +40,10 @@ extern "C" int rc_create(rc_handle_t* out, int device) {
     h->comm_world = 0;
     h->side_stream = nullptr;
     h->ev_fork = h->ev_join = nullptr;
+    for (auto& g : h->graphs) { g.ws = nullptr; g.graph = nullptr; g.exec = nullptr; g.stamp = 0; }
+    h->graph_stamp = 0;
+    h->graph_broken = 0;
+    h->capturing = 0;
     *out = h;
     return RC_OK;
 }
@@ -53,6 +57,10 @@ extern "C" int rc_destroy(rc_handle_t h) {
             for (hipEvent_t e : v) (void)hipEventDestroy(e);
         for (double* t : h->exp2_tab)
             if (t) (void)hipFree(t);
+        for (auto& g : h->graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
     }
     delete h;
     return RC_OK;
@@ -84,7 +92,7 @@ extern "C" int rc_profile_enable(rc_handle_t h, int on) {
 }
 
 void rc_prof_mark(rc_handle_t h, int slot, hipStream_t s) {
-    if (!h || !h->profile_on) return;
+    if (!h || !h->profile_on || h->capturing) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, s);

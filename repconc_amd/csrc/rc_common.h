@@ -24,6 +24,16 @@ struct rc_handle_s {
     int comm_rank, comm_world;
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
+    // hipGraph cache of the iteration chain of rc_solve_chains (comm.hip): sweeps t = 2 .. T-1 (+ all-gathers) are
+    // captured once per (workspace, shape, eps, T, world, variant) and replayed
+    struct solve_graph {
+        void* ws; int64_t B; int M, iters, world, nch, variant; double eps;
+        hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp;
+    };
+    solve_graph graphs[4];
+    unsigned long long graph_stamp;
+    int graph_broken;                                 // capture failed once on this handle: stay eager
+    int capturing;                                    // inside stream capture: no event marks
 };
 
 // comm.hip: the full constrained assignment as one or two chains of sub-quantisers (world == 1: no RCCL)

@@ -239,9 +239,13 @@ def comm_init(group=None):
     and broadcast through torch.distributed (any backend); everything after that is RCCL called from C."""
     import torch.distributed as dist
     dev = torch.cuda.current_device()
-    if _comm_ready.get(dev):
+    key = id(group) if group is not None else 0
+    if _comm_ready.get(dev) == key:
         return
     lib, h = _lib.load(), _lib.handle(dev)
+    if dev in _comm_ready:                                  # another process group: new communicators
+        _lib.check(lib.rc_comm_destroy(h), "rc_comm_destroy", h)
+        del _comm_ready[dev]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     ids = torch.zeros(256, dtype=torch.uint8)
     if rank == 0:
@@ -255,7 +259,7 @@ def comm_init(group=None):
         ids = t.cpu()
     raw = (C.c_char * 256).from_buffer_copy(bytes(ids.numpy().tobytes()))
     _lib.check(lib.rc_comm_init(h, C.cast(raw, C.c_void_p), rank, world), "rc_comm_init", h)
-    _comm_ready[dev] = True
+    _comm_ready[dev] = key
 
 
 def assign_sinkhorn_dist(x: torch.Tensor, centroids: torch.Tensor, eps: float, iters: int, dtype=torch.int64):
@@ -270,8 +274,7 @@ def assign_sinkhorn_dist(x: torch.Tensor, centroids: torch.Tensor, eps: float, i
         raise _lib.RepconcHipError("assign_sinkhorn_dist: call ops.comm_init() first")
     codes = torch.empty((B, M), dtype=dtype, device=x.device)
     flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
-    if B == 0:
-        return codes, flags
+    # a rank without rows (ragged last batch) still takes part in every collective of the solve
     wsb = lib.rc_pq_assign_sinkhorn_dist_ws_bytes(B, M, K, world)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
     u8 = codes if dtype == torch.uint8 else None
