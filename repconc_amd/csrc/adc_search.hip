@@ -1179,6 +1179,7 @@ extern "C" int rc_adc_cf_describe(int M, int lane, int step, int* slot, int* m, 
 // (Re)build rows [n0, n0 + n) of the image from the canonical codes [N, M] (both pointers = row 0 of the index).
 extern "C" int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
                                  rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !codes || !image || n0 < 0 || n < 0) return RC_EINVAL;
     if (!adc_cf_supported(M)) return RC_ESHAPE;
     if (n == 0) return RC_OK;
@@ -1297,6 +1298,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
 
 extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K, float* lut,
                           rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !C || !q || !lut || nq < 0 || M <= 0 || D <= 0) return RC_EINVAL;
     if (K != RC_K || D % M != 0) return RC_ESHAPE;
     if (nq == 0) return RC_OK;
@@ -1332,6 +1334,7 @@ int rc_adc_launch_select(rc_handle_t h, unsigned long long* cand, const unsigned
 extern "C" int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, const float* C, int D,
                              const float* q, int nq, int k, int64_t id_offset, double sel_slack, float* scores,
                              int64_t* ids, int* status, void* ws, size_t ws_bytes, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     return rc_adc_search_img(h, codes, nullptr, N, M, K, C, D, q, nq, k, id_offset, sel_slack, scores, ids, status, ws,
                              ws_bytes, stream);
 }
@@ -1342,6 +1345,7 @@ extern "C" int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint
                                  const float* C, int D, const float* q, int nq, int k, int64_t id_offset,
                                  double sel_slack, float* scores, int64_t* ids, int* status, void* ws, size_t ws_bytes,
                                  rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !codes || !C || !q || !scores || !ids || !status || N <= 0 || nq < 0 || k <= 0 || M <= 0 || D <= 0)
         return RC_EINVAL;
     if (K != RC_K || D % M != 0 || N > 0xFFFFFFFFll || k > ADC_CAND_CAP / 2) return RC_ESHAPE;

@@ -76,6 +76,7 @@ extern "C" int rc_comm_unique_ids(void* ids_host) {
 }
 
 extern "C" int rc_comm_init(rc_handle_t h, const void* ids_host, int rank, int world) {
+    rc_device_guard device_guard_(h);
     nccl_api* n = nccl();
     if (!n) return RC_ECOMM;
     if (!h || !ids_host || world < 1 || rank < 0 || rank >= world) return RC_EINVAL;
@@ -95,6 +96,7 @@ extern "C" int rc_comm_init(rc_handle_t h, const void* ids_host, int rank, int w
 
 extern "C" int rc_comm_destroy(rc_handle_t h) {
     if (!h) return RC_EINVAL;
+    rc_device_guard device_guard_(h);
     nccl_api* n = nccl();
     for (int i = 0; i < 2; ++i)
         if (h->comm[i] && n) { (void)n->CommDestroy((ncclComm_t)h->comm[i]); h->comm[i] = nullptr; }
@@ -366,6 +368,7 @@ extern "C" size_t rc_pq_assign_sinkhorn_dist_ws_bytes(int64_t B_local, int M, in
 extern "C" int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
                                           int M, int K, double eps, int iters, uint8_t* codes_u8, int64_t* codes_i64,
                                           int* flags, void* ws, size_t ws_bytes, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !h->comm[0] || !C || !flags || B < 0 || (B > 0 && !x) || M <= 0 || iters < 1 || !(eps > 0.0) ||
         (B > 0 && !codes_u8 && !codes_i64))
         return RC_EINVAL;

@@ -31,6 +31,7 @@ struct rc_index_s {
     } while (0)
 
 extern "C" int rc_index_create(rc_handle_t h, int D, int M, int K, rc_index_t* out) {
+    rc_device_guard device_guard_(h);
     if (!h || !out || D <= 0 || M <= 0) return RC_EINVAL;
     if (K != RC_K || D % M != 0) return RC_ESHAPE;
     rc_index_s* idx = new (std::nothrow) rc_index_s();
@@ -51,6 +52,7 @@ extern "C" int rc_index_create(rc_handle_t h, int D, int M, int K, rc_index_t* o
 }
 
 extern "C" int rc_index_destroy(rc_index_t idx) {
+    rc_device_guard device_guard_(idx ? idx->h : nullptr);
     if (!idx) return RC_EINVAL;
     if (idx->C) (void)hipFree(idx->C);
     if (idx->codes) (void)hipFree(idx->codes);
@@ -66,6 +68,7 @@ extern "C" const uint8_t* rc_index_codes(rc_index_t idx) { return idx ? idx->cod
 extern "C" const float* rc_index_centroids(rc_index_t idx) { return (idx && idx->have_centroids) ? idx->C : nullptr; }
 
 extern "C" int rc_index_set_centroids(rc_index_t idx, const float* C, rc_stream_t stream) {
+    rc_device_guard device_guard_(idx ? idx->h : nullptr);
     if (!idx || !C) return RC_EINVAL;
     RC_IDX_HIP(idx, hipMemcpyAsync(idx->C, C, (size_t)idx->M * idx->K * (idx->D / idx->M) * sizeof(float),
                                    hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -74,6 +77,7 @@ extern "C" int rc_index_set_centroids(rc_index_t idx, const float* C, rc_stream_
 }
 
 extern "C" int rc_index_reserve(rc_index_t idx, int64_t rows, rc_stream_t stream) {
+    rc_device_guard device_guard_(idx ? idx->h : nullptr);
     if (!idx || rows < 0) return RC_EINVAL;
     if (rows <= idx->cap) return RC_OK;
     if (rows > 0xFFFFFFFFll) return RC_ESHAPE;
@@ -107,6 +111,7 @@ extern "C" int rc_index_reserve(rc_index_t idx, int64_t rows, rc_stream_t stream
 }
 
 extern "C" int rc_index_add_codes(rc_index_t idx, const uint8_t* codes, int64_t n, rc_stream_t stream) {
+    rc_device_guard device_guard_(idx ? idx->h : nullptr);
     if (!idx || n < 0 || (n > 0 && !codes)) return RC_EINVAL;
     if (n == 0) return RC_OK;
     if (idx->n + n > idx->cap) {
@@ -128,6 +133,7 @@ extern "C" int rc_index_add_codes(rc_index_t idx, const uint8_t* codes, int64_t 
 }
 
 extern "C" int rc_index_reset(rc_index_t idx) {
+    rc_device_guard device_guard_(idx ? idx->h : nullptr);
     if (!idx) return RC_EINVAL;
     idx->n = 0;
     return RC_OK;
@@ -136,6 +142,7 @@ extern "C" int rc_index_reset(rc_index_t idx) {
 // Synchronous (reads the status word between attempts).  scores [nq,k], ids [nq,k] on the device.
 extern "C" int rc_index_search(rc_index_t idx, const float* q, int nq, int k, float* scores, int64_t* ids,
                                rc_stream_t stream) {
+    rc_device_guard device_guard_(idx ? idx->h : nullptr);
     if (!idx || nq < 0 || k <= 0 || (nq > 0 && (!q || !scores || !ids))) return RC_EINVAL;
     if (!idx->have_centroids) return RC_EINVAL;
     if (nq == 0) return RC_OK;

@@ -166,6 +166,7 @@ extern "C" int rc_ivf_search(rc_handle_t h, const uint8_t* codes, const int64_t*
                              int M, int K, const float* lut, const int* probes, const int* base, const int* count, int nq,
                              int nprobe, int64_t stride, int k, float* scores, int64_t* out_ids, int* status, void* ws,
                              size_t ws_bytes, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !codes || !list_off || !ids || !lut || !probes || !base || !count || !scores || !out_ids || !status ||
         N <= 0 || nq < 0 || nprobe <= 0 || stride <= 0 || k <= 0)
         return RC_EINVAL;

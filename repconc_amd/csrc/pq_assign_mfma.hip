@@ -462,6 +462,7 @@ extern "C" size_t rc_pq_assign_nearest_fast_ws_bytes(int64_t B, int M) {
 extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
                                          int M, int K, uint8_t* codes_u8, int64_t* codes_i64, void* ws, size_t ws_bytes,
                                          rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !x || !C || B < 0 || M <= 0 || D <= 0 || ldx < D || (!codes_u8 && !codes_i64)) return RC_EINVAL;
     if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M) || B * (int64_t)M > 0xFFFFFFFFll) return RC_ESHAPE;
     if (((uintptr_t)x & 15) || (ldx % 4) != 0) return RC_EINVAL;
@@ -501,6 +502,7 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
 
 // After the stream has drained: did the doubt list overflow?  (1 = yes: rerun with rc_pq_assign_nearest.)
 extern "C" int rc_pq_assign_nearest_fast_overflow(rc_handle_t h, const void* ws, int64_t B, int M, int* doubtful_host) {
+    rc_device_guard device_guard_(h);
     if (!h || !ws) return RC_EINVAL;
     unsigned n = 0;
     RC_HIP_CHECK(h, hipMemcpy(&n, ws, sizeof(unsigned), hipMemcpyDeviceToHost));

@@ -257,6 +257,7 @@ extern "C" size_t rc_pq_dist_table_ws_bytes(int64_t B, int M) {
 extern "C" int rc_pq_dist_table(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B,
                                 int D, int M, int K, float* d, float* minmax, void* ws, size_t ws_bytes,
                                 rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !x || !C || !d || B < 0 || M <= 0 || D <= 0 || ldx < D) return RC_EINVAL;
     if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
     if (((uintptr_t)x & 15) || (ldx % 4) != 0) return RC_EINVAL;  // float4 row loads
@@ -280,6 +281,7 @@ extern "C" int rc_pq_dist_table(rc_handle_t h, const float* x, int64_t ldx, cons
 
 extern "C" int rc_pq_centre(rc_handle_t h, float* d, const float* minmax, int64_t B, int M, int K,
                             rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !d || !minmax || B < 0 || M <= 0) return RC_EINVAL;
     if (K != RC_K) return RC_ESHAPE;
     if (B == 0) return RC_OK;
@@ -297,6 +299,7 @@ extern "C" int rc_pq_centre(rc_handle_t h, float* d, const float* minmax, int64_
 extern "C" int rc_pq_assign_nearest(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B,
                                     int D, int M, int K, uint8_t* codes_u8, int64_t* codes_i64,
                                     rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !x || !C || B < 0 || M <= 0 || D <= 0 || ldx < D || (!codes_u8 && !codes_i64)) return RC_EINVAL;
     if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
     if (((uintptr_t)x & 15) || (ldx % 4) != 0) return RC_EINVAL;  // float4 row loads

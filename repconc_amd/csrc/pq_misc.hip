@@ -86,6 +86,7 @@ const double* rc_exp2_table(rc_handle_t h, int tb) {
 
 // ------------------------------------------------------------------------------------------ profiling
 extern "C" int rc_profile_enable(rc_handle_t h, int on) {
+    rc_device_guard device_guard_(h);
     if (!h) return RC_EINVAL;
     h->profile_on = on ? 1 : 0;
     return RC_OK;
@@ -100,6 +101,7 @@ void rc_prof_mark(rc_handle_t h, int slot, hipStream_t s) {
 }
 
 extern "C" int rc_profile_collect(rc_handle_t h, int kernel_class, int* launches, double* total_ms) {
+    rc_device_guard device_guard_(h);
     if (!h || !launches || !total_ms || kernel_class < 0 || kernel_class >= RC_PROF_NSLOT) return RC_EINVAL;
     auto& v = h->prof_ev[kernel_class];
     int n = 0;
@@ -175,6 +177,7 @@ static unsigned grid_for(rc_handle_t h, int64_t work_items) {
 
 extern "C" int rc_pq_decode(rc_handle_t h, const void* codes, int code_dtype, const float* C, int64_t n, int M,
                             int K, int dsub, float* out, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !codes || !C || !out || n < 0 || M <= 0 || dsub <= 0) return RC_EINVAL;
     if (K != RC_K || dsub % 4 != 0) return RC_ESHAPE;
     if (n == 0) return RC_OK;
@@ -192,6 +195,7 @@ extern "C" int rc_pq_decode(rc_handle_t h, const void* codes, int code_dtype, co
 
 extern "C" int rc_pq_decode_bwd(rc_handle_t h, const void* codes, int code_dtype, const float* grad_out,
                                 int64_t n, int M, int K, int dsub, float* grad_C, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !codes || !grad_out || !grad_C || n < 0 || M <= 0 || dsub <= 0) return RC_EINVAL;
     if (K != RC_K) return RC_ESHAPE;
     if (n == 0) return RC_OK;
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ C, i
 }
 
 extern "C" int rc_normalize_centroids(rc_handle_t h, float* C, int M, int K, int dsub, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !C || M <= 0 || K <= 0 || dsub <= 0) return RC_EINVAL;
     const int64_t rows = (int64_t)M * K;
     hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C,
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(256) void hist_kernel(const void* __restrict__ code
 
 extern "C" int rc_code_hist(rc_handle_t h, const void* codes, int code_dtype, int64_t n, int M, int K,
                             int32_t* hist, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !codes || !hist || n < 0 || M <= 0) return RC_EINVAL;
     if (K != RC_K) return RC_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -320,6 +326,7 @@ __global__ __launch_bounds__(256) void kmeans_stats_kernel(const float* __restri
 
 extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const uint8_t* codes, int64_t n, int D,
                                int M, int K, double* sums, int64_t* counts, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !x || !codes || !sums || !counts || n < 0 || M <= 0 || D <= 0 || ldx < D) return RC_EINVAL;
     if (K != RC_K || D % M != 0) return RC_ESHAPE;
     const int dsub = D / M;
@@ -349,6 +356,7 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const double* __rest
 
 extern "C" int rc_kmeans_update(rc_handle_t h, const double* sums, const int64_t* counts, float* C, int M, int K,
                                 int dsub, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !sums || !counts || !C || M <= 0 || dsub <= 0) return RC_EINVAL;
     if (K != RC_K) return RC_ESHAPE;
     const int64_t total = (int64_t)M * K * dsub;

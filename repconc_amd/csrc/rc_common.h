@@ -101,6 +101,21 @@ static inline bool rc_env_set(const char* name) {
         default: return RC_ESHAPE;                \
     }
 
+// Every entry point runs on its handle's device whatever the calling thread's current device is (in-process multi-GPU
+// indexes drive several handles from several host threads) and restores the caller's device on return.
+struct rc_device_guard {
+    int prev;
+    bool switched;
+    explicit rc_device_guard(rc_handle_t h) : prev(-1), switched(false) {
+        if (h && hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+    }
+    ~rc_device_guard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    rc_device_guard(const rc_device_guard&) = delete;
+    rc_device_guard& operator=(const rc_device_guard&) = delete;
+};
+
 // ---- wave64 DPP helpers -------------------------------------------------------------------
 // rotate right by N lanes inside each row of 16 lanes (DPP row_ror:N, ctrl 0x120+N)
 template <int N>

@@ -697,6 +697,7 @@ extern "C" size_t rc_sk_ws_bytes(int64_t B, int M, int K) {
 extern "C" int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_prev, int G, double* f2, double* g,
                            double* colsum, double* rows_out, int64_t B, int M, int K, double eps, int t,
                            int* flags, void* ws, size_t ws_bytes, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !d || !rows_out || !flags || B <= 0 || M <= 0 || t < 0 || !(eps > 0.0)) return RC_EINVAL;
     if (t > 0 && (!rows_prev || G <= 0 || !f2 || !g || !colsum)) return RC_EINVAL;
     if (K != RC_K) return RC_ESHAPE;
@@ -782,6 +783,7 @@ int rc_sk_argmax_strided(rc_handle_t h, const float* d, const double* rows_prev,
 extern "C" int rc_sk_argmax(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2,
                             int64_t B, int M, int K, double eps, int t, uint8_t* codes_u8, int64_t* codes_i64,
                             int* flags, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !d || !rows_prev || !f2 || !flags || G <= 0 || B <= 0 || M <= 0 || t < 1 || !(eps > 0.0) ||
         (!codes_u8 && !codes_i64))
         return RC_EINVAL;
@@ -799,6 +801,7 @@ extern "C" size_t rc_pq_assign_sinkhorn_ws_bytes(int64_t B, int M, int K) {
 extern "C" int rc_pq_assign_sinkhorn(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
                                      int M, int K, double eps, int iters, uint8_t* codes_u8, int64_t* codes_i64,
                                      int* flags, void* ws, size_t ws_bytes, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
     if (!h || !x || !C || !flags || B < 0 || M <= 0 || iters < 1 || !(eps > 0.0) || (!codes_u8 && !codes_i64))
         return RC_EINVAL;
     if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;

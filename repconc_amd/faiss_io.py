@@ -62,3 +62,32 @@ def read_index(path: str, device=None) -> PQIndex:
     if ntotal:
         index.add_codes(torch.from_numpy(codes.reshape(ntotal, M).copy()))
     return index
+
+
+# ---- the directory convention of the pipeline steps --------------------------------------------------------------
+# evaluate/run_repconc_eval.py:39-43,57-58 and train/run_train_jpq.py:102-103: <dir>/index (the IndexPQ file) next to
+# <dir>/corpus_ids.npy (index row -> corpus id, the order encode_corpus produced); train/run_warmup.py:187-189 writes both.
+INDEX_FILE, CORPUS_IDS_FILE = "index", "corpus_ids.npy"
+
+
+def save_index_dir(index: PQIndex, corpus_ids, out_dir: str):
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    ids = np.asarray(corpus_ids)
+    if len(ids) != index.ntotal:
+        raise ValueError(f"{len(ids)} corpus ids for an index of {index.ntotal} rows")
+    write_index(index, os.path.join(out_dir, INDEX_FILE))
+    np.save(os.path.join(out_dir, CORPUS_IDS_FILE), ids)
+
+
+def load_index_dir(in_dir: str, device=None):
+    """-> (index, corpus_ids); raises FileNotFoundError when either file is missing (callers then encode the corpus)."""
+    import os
+    ip, cp = os.path.join(in_dir, INDEX_FILE), os.path.join(in_dir, CORPUS_IDS_FILE)
+    if not (os.path.exists(ip) and os.path.exists(cp)):
+        raise FileNotFoundError(f"{ip} / {cp}")
+    index = read_index(ip, device=device)
+    ids = np.load(cp)
+    if len(ids) != index.ntotal:
+        raise ValueError(f"{cp} holds {len(ids)} ids, the index {index.ntotal} rows")
+    return index, ids

@@ -1,0 +1,129 @@
+"""The `repconc.*` import surface (compat/repconc) and the Faiss-idiom helpers — CPU-side checks (no kernels run)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def test_repconc_namespace_aliases_repconc_amd_modules():
+    """A caller-shaped import block (evaluate/run_repconc_eval.py:16-24, train/run_warmup.py, finetune_jpq.py) in a fresh
+    interpreter with compat/ on the path: every name resolves, and to the very objects repconc_amd defines."""
+    code = r'''
+import sys
+from repconc.models.repconc import RepCONC, QuantizeOutput, sinkhorn_algorithm, decode
+from repconc.models.repconc.evaluate_repconc import (ModelArguments, EvalArguments, RepCONCEvaluater, initialize_index,
+    add_docs, from_pq_to_ivfpq, load_index_to_gpu, encode_corpus, encode_query, search, batch_search)
+from repconc.models.dense import AutoDense, BertDense, RobertaDense, DistilBertDense
+from repconc.train.run_warmup import warmup_from_embeds
+from repconc.models.jpq.finetune_jpq import JPQ
+from repconc.utils.eval_utils import load_corpus, load_queries, TextDataset, get_collator_func
+import repconc_amd.models.repconc.modeling_repconc as real
+import repconc.models.repconc.modeling_repconc as alias
+assert alias is real and RepCONC is real.RepCONC
+assert sys.modules["repconc.models.repconc.evaluate_repconc"] is sys.modules["repconc_amd.models.repconc.evaluate_repconc"]
+m = ModelArguments(model_name_or_path="x")
+assert m.doc_encoder_path == m.query_encoder_path == "x"
+assert "faiss" not in sys.modules
+print("ok")
+'''
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "compat"), ROOT]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+
+
+def test_eval_utils_collator_dataset_and_metrics(tmp_path):
+    from repconc_amd.utils.eval_utils import (TextDataset, get_collator_func, load_corpus, load_queries, mrr_at_k,
+                                              recall_at_k)
+
+    class Tok:
+        def __call__(self, texts, padding, truncation, max_length):
+            ids = [[1] + [3] * min(len(t.split()), max_length - 2) + [2] for t in texts]
+            L = max(map(len, ids))
+            return {"input_ids": [i + [0] * (L - len(i)) for i in ids],
+                    "attention_mask": [[1] * len(i) + [0] * (L - len(i)) for i in ids]}
+
+    ds = TextDataset(["a b c", "d"], text_ids=[7, 9])
+    batch = get_collator_func(Tok(), 8, "doc")([ds[0], ds[1]])
+    assert batch["input_ids"].shape == (2, 5) and batch["text_ids"].tolist() == [7, 9]
+    assert batch["attention_mask"].sum().item() == 8
+    assert "text_ids" not in get_collator_func(Tok(), 8, "query")(["x y"])
+    p = tmp_path / "c.tsv"
+    p.write_text("d1\ttitle\tbody text\nd2\tonly body\n")
+    assert load_corpus(str(p), " [SEP] ") == {"d1": "title [SEP] body text", "d2": "only body"}
+    q = tmp_path / "q.tsv"
+    q.write_text("5\twhat is x\n")
+    assert load_queries(str(q)) == {"5": "what is x\n"}
+    qrels = {"q1": {"a": 1}, "q2": {"b": 1, "c": 0}, "q3": {}}
+    run = [["x", "a", "y"], ["c", "z", "w"], ["a"]]
+    assert mrr_at_k(run, qrels, ["q1", "q2", "q3"], 10) == 0.25            # (1/2 + 0) / 2 scored queries
+    assert recall_at_k(run, qrels, ["q1", "q2", "q3"], 2) == 0.5
+
+
+def test_faiss_idiom_helpers_on_cpu_tensors():
+    import torch
+    from repconc_amd import faiss_compat as faiss
+    vec = torch.zeros(4, 256, 2)
+    arr = np.arange(4 * 256 * 2, dtype=np.float32)
+    faiss.copy_array_to_vector(arr, vec)
+    assert np.array_equal(faiss.vector_to_array(vec), arr) and vec[1, 0, 1].item() == 513.0
+    codes = torch.arange(12, dtype=torch.uint8).reshape(3, 4)
+    assert faiss.vector_to_array(codes).tolist() == list(range(12))
+    faiss.omp_set_num_threads(32)
+    assert faiss.METRIC_INNER_PRODUCT == 0
+
+
+def test_indexpq_reader_parses_the_hand_assembled_golden_file_header():
+    """tests/golden/ixpq_d8_m2_n5.faissindex is assembled by tests/golden/make_ixpq.py in Faiss 1.7.x writer order,
+    independently of faiss_io.  CPU part: the byte layout agrees field by field (the GPU test reads it into a PQIndex)."""
+    import struct
+    from conftest import GOLDEN
+    raw = open(os.path.join(GOLDEN, "ixpq_d8_m2_n5.faissindex"), "rb").read()
+    exp = np.load(os.path.join(GOLDEN, "ixpq_d8_m2_n5_expected.npz"))
+    assert raw[:4] == b"IxPq" and len(raw) == 4 + 33 + 24 + 8 + 4 * 2 * 256 * 4 + 8 + 10 + 9
+    d, ntotal, d1, d2, trained, metric = struct.unpack_from("<iqqqBi", raw, 4)
+    assert (d, ntotal, d1, d2, trained, metric) == (8, 5, 1 << 20, 1 << 20, 1, 0)
+    assert struct.unpack_from("<QQQQ", raw, 37) == (8, 2, 8, 2 * 256 * 4)
+    assert np.array_equal(np.frombuffer(raw, "<f4", 2048, 69).reshape(2, 256, 4), exp["centroids"])
+
+
+def test_gradcache_two_pass_gradients_equal_direct_backward_cpu():
+    """repconc_amd.gradcache on a small CPU model with dropout: forward_no_grad + build_cache + a second pass under the
+    recorded RNG contexts reproduces the gradients of one big-batch backward (same dropout masks)."""
+    import torch
+    from repconc_amd.gradcache import GradCache
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Dropout(0.3), torch.nn.Tanh(), torch.nn.Linear(16, 4))
+    xq, xd = torch.randn(10, 6), torch.randn(10, 6)
+    loss_fn = lambda q, d, scale: torch.nn.functional.cross_entropy(q @ d.T * scale, torch.arange(q.shape[0]))
+    gc = GradCache([net], 4, loss_fn)
+    chunks = lambda x: [{"input": c} for c in x.split(4)]
+    net.zero_grad()
+    rq, sq = gc.forward_no_grad(net, chunks(xq))
+    rd, sd = gc.forward_no_grad(net, chunks(xd))
+    assert not rq.requires_grad and len(sq) == 3
+    (gq, gd), loss = gc.build_cache(rq, rd, scale=2.0)
+    for x, g, states in ((xq, gq, sq), (xd, gd, sd)):
+        off = 0
+        for c, st in zip(x.split(4), states):
+            with st:
+                out = net(c)
+            torch.dot(g[off:off + len(c)].flatten(), out.flatten()).backward()
+            off += len(c)
+    got = [p.grad.clone() for p in net.parameters()]
+    # direct: the same masks come from replaying the per-chunk RNG states
+    net.zero_grad()
+    outs = []
+    for x, states in ((xq, sq), (xd, sd)):
+        parts = []
+        for c, st in zip(x.split(4), states):
+            with st:
+                parts.append(net(c))
+        outs.append(torch.cat(parts))
+    direct = loss_fn(outs[0], outs[1], scale=2.0)
+    direct.backward()
+    assert abs(float(direct) - float(loss)) < 1e-6
+    for a, p in zip(got, net.parameters()):
+        assert torch.allclose(a, p.grad, atol=1e-6)

@@ -1188,3 +1188,182 @@ def test_native_rccl_solve_on_two_real_ranks(name):
         got = np.concatenate([ret[0][i][0], ret[1][i][0]], 0)
         assert ret[0][i][1] == 0 and ret[1][i][1] == 0
         assert np.array_equal(got, g["codes_constrained"]), (name, i)
+
+
+@pytest.mark.parametrize("mode", ["replicated", "sharded"])
+def test_load_index_to_all_gpus_in_process(mode):
+    """load_index_to_gpu(index, None) (evaluate_repconc.py:131-134): replicas with the query batch split, or row shards
+    with merged top-k lists — on every visible GPU, and as two virtual parts on one device when only one is visible.
+    Results (ids and score bits) equal the single-device search and the oracle."""
+    from repconc_amd.index import PQIndex
+    from repconc_amd.models.repconc.evaluate_repconc import load_index_to_gpu, batch_search
+    C, codes, q = _adc_case(48, 300011, 13, seed=4711)
+    idx = PQIndex(768, 48)
+    idx.set_centroids(C)
+    idx.add_codes(codes)
+    want_s, want_i = idx.search(_t(q), 100)
+    ndev = torch.cuda.device_count()
+    devs = list(range(ndev)) if ndev >= 2 else [0, 0, 0]
+    multi = load_index_to_gpu(idx, None, shard=(mode == "sharded"), devices=devs)
+    assert type(multi).__name__ == ("ShardedPQIndex" if mode == "sharded" else "ReplicatedPQIndex")
+    assert multi.ntotal == idx.ntotal and multi.pq.M == 48
+    s, i = multi.search(_t(q), 100)
+    assert torch.equal(i.to(DEV), want_i) and torch.equal(s.to(DEV), want_s)
+    sn, inn = multi.search(q, 100)                                     # numpy in -> numpy out (evaluate_repconc.py:182)
+    assert np.array_equal(inn, want_i.cpu().numpy())
+    ws, wi = c_oracle.adc_search(codes, C, q, 100)
+    assert np.array_equal(inn, wi) and np.array_equal(sn.view(np.uint32), ws.view(np.uint32))
+    corpus_ids = np.arange(codes.shape[0]) * 3 + 7
+    bs, bi = batch_search(np.arange(13), q, corpus_ids, multi, 100, 5)
+    assert np.array_equal(bi, corpus_ids[wi])
+    assert load_index_to_gpu(idx, None, devices=[0]) is idx
+
+
+class _HashTokenizer:
+    """Whitespace tokenizer over a 500-word vocabulary (ids by hash); pads to the longest text of the batch."""
+    sep_token = "[SEP]"
+
+    def __call__(self, texts, padding=True, truncation=True, max_length=32):
+        rows = [[1] + [3 + (zlib.crc32(w.encode()) % 490) for w in t.split()][: max_length - 2] + [2] for t in texts]
+        L = max(map(len, rows))
+        return {"input_ids": [r + [0] * (L - len(r)) for r in rows],
+                "attention_mask": [[1] * len(r) + [0] * (L - len(r)) for r in rows]}
+
+
+def test_evaluation_pipeline_with_the_reference_call_sequence(tmp_path):
+    """The call sequence of evaluate/run_repconc_eval.py (load_or_encode_corpus :36-60, search :88-110) against this
+    package's names: encode_corpus -> index file + corpus_ids.npy -> read back -> from_pq_to_ivfpq -> load_index_to_gpu
+    -> encode_query -> batch_search.  Checked against per-text model calls and a brute-force score of the decoded index."""
+    from transformers import BertConfig
+    from repconc_amd import faiss_compat as faiss
+    from repconc_amd.faiss_io import load_index_dir, save_index_dir
+    from repconc_amd.models.dense import BertDense
+    from repconc_amd.models.repconc import RepCONC
+    from repconc_amd.models.repconc.evaluate_repconc import (EvalArguments, ModelArguments, batch_search, encode_corpus,
+                                                             encode_query, from_pq_to_ivfpq, load_index_to_gpu)
+    torch.manual_seed(1)
+    cfg = BertConfig(hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=128, vocab_size=500,
+                     max_position_embeddings=40, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg.MCQ_M, cfg.MCQ_K, cfg.similarity_metric, cfg.pooling = 48, 256, "METRIC_IP", "mean"
+    model = RepCONC(cfg, BertDense(cfg), False, None, None).to(DEV)
+    with torch.no_grad():
+        model.centroids.mul_(0.05)
+        model.rotation.copy_(torch.linalg.qr(torch.randn(768, 768, device=DEV))[0])
+    rng = np.random.default_rng(5)
+    words = [f"w{i}" for i in range(300)]
+    corpus = {f"d{i}": " ".join(rng.choice(words, rng.integers(3, 25))) for i in range(257)}
+    queries = {100 + i: " ".join(rng.choice(words, rng.integers(2, 8))) for i in range(11)}
+    tok = _HashTokenizer()
+    margs = ModelArguments(model_name_or_path="unused", max_seq_length=32)
+    eargs = EvalArguments(output_dir=str(tmp_path / "out"), per_device_eval_batch_size=50, report_to=[])
+    assert eargs.topk == 1000 and eargs.search_batch == 1200 and margs.doc_encoder_path == "unused"
+    index, corpus_ids = encode_corpus(corpus, model, tok, margs.max_seq_length, eargs)
+    assert index.ntotal == 257 and len(corpus[corpus_ids[0]]) >= len(corpus[corpus_ids[-1]])     # longest first
+    # codes: what a per-document forward(return_code=True) gives (the reference's prediction_step, :51-75)
+    col = lambda t: {k: torch.tensor(v, device=DEV) for k, v in tok([t]).items()}
+    for row in (0, 100, 256):
+        want = model(return_code=True, **col(corpus[corpus_ids[row]])).discrete_codes.to(torch.uint8)
+        assert torch.equal(index.codes[row:row + 1], want)
+    save_index_dir(index, corpus_ids, str(tmp_path / "corpus"))
+    index2, ids2 = load_index_dir(str(tmp_path / "corpus"))
+    assert np.array_equal(ids2, corpus_ids) and torch.equal(index2.codes, index.codes)
+    faiss.copy_array_to_vector(model.centroids.detach().cpu().numpy().ravel(), index2.pq.centroids)   # run_repconc_eval.py:123-127
+    index2 = load_index_to_gpu(from_pq_to_ivfpq(index2), 0)
+    qemb, qids = encode_query(queries, model, tok, 16, eargs)
+    assert qemb.shape == (11, 768) and qids.tolist() == sorted(queries)
+    scores, ids = batch_search(qids, qemb, corpus_ids, index2, 10, batch_size=4)
+    recon = index2.reconstruct_n(0, 257)
+    brute = torch.from_numpy(qemb).to(DEV) @ recon.T
+    top = torch.topk(brute, 10, dim=1)
+    np.testing.assert_allclose(scores, top.values.cpu().numpy(), rtol=0, atol=2e-4)
+    assert (ids == corpus_ids[top.indices.cpu().numpy()]).mean() > 0.99
+    assert np.array_equal(faiss.vector_to_array(index2.codes).reshape(257, 48), index.codes.cpu().numpy())
+
+
+def test_indexpq_reader_on_the_hand_assembled_golden_file():
+    from repconc_amd.faiss_io import read_index
+    exp = np.load(os.path.join(GOLDEN, "ixpq_d8_m2_n5_expected.npz"))
+    idx = read_index(os.path.join(GOLDEN, "ixpq_d8_m2_n5.faissindex"), device=DEV)
+    assert (idx.pq.d, idx.pq.M, idx.ntotal, idx.metric_type, idx.is_trained) == (8, 2, 5, 0, True)
+    assert np.array_equal(idx.pq.centroids.cpu().numpy(), exp["centroids"])
+    assert np.array_equal(idx.codes.cpu().numpy(), exp["codes"])
+
+
+class _PtHashTokenizer(_HashTokenizer):
+    def __call__(self, texts, padding=True, truncation=True, max_length=32, return_tensors=None, **_unused):
+        enc = super().__call__(texts, padding, truncation, max_length)
+        return {k: torch.tensor(v, dtype=torch.long) for k, v in enc.items()} if return_tensors == "pt" else enc
+
+
+def test_repconc_finetuner_on_transformers5_gradients_and_train_loop(tmp_path):
+    """`RepCONCFinetuner` (models/repconc/finetune_repconc.py of this package) driven like the reference's trainer
+    (finetune_repconc.py:225-344): built from `RepCONCFinetuneArguments` + `FinetuneCollator`, one `training_step` on a
+    batch with explicit hard negatives (GradCache `forward_no_grad` -> constrained quantize -> `build_cache` ->
+    `_forward_backward`) gives the gradients of the one-pass objective; `create_optimizer` makes the three groups; and
+    `train()` runs on the installed transformers."""
+    from transformers import BertConfig
+    from repconc_amd.models.dense import BertDense
+    from repconc_amd.models.repconc import RepCONC
+    from repconc_amd.models.repconc.finetune_repconc import FinetuneCollator, RepCONCFinetuneArguments, RepCONCFinetuner
+    torch.manual_seed(0)
+    random_state = np.random.default_rng(3)
+    cfg = BertConfig(hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=128, vocab_size=500,
+                     max_position_embeddings=40, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.0)
+    cfg.MCQ_M, cfg.MCQ_K, cfg.similarity_metric, cfg.pooling = 48, 256, "METRIC_IP", "mean"
+    model = RepCONC(cfg, BertDense(cfg), True, 0.003, 20).to(DEV)
+    with torch.no_grad():
+        model.centroids.mul_(0.05)
+    words = [f"w{i}" for i in range(200)]
+    text = lambda lo, hi: " ".join(random_state.choice(words, random_state.integers(lo, hi)))
+    nq, npq = 16, 3
+    feats = [{"query": text(2, 6), "pos_doc": text(5, 20), "qid": i, "pos_docid": 1000 + i,
+              "neg_docs": [text(5, 20) for _ in range(npq)], "neg_docids": [2000 + npq * i + j for j in range(npq)]}
+             for i in range(nq)]
+    feats[5]["neg_docids"][0] = feats[3]["pos_docid"]                 # a duplicate ...
+    qrels = {i: [1000 + i] for i in range(nq)}
+    qrels[2].append(feats[7]["neg_docids"][1])                        # ... and a false negative
+    args = RepCONCFinetuneArguments(output_dir=str(tmp_path / "o"), per_device_train_batch_size=nq, cache_chunk_size=6,
+                                    mse_loss_weight=1e-2, dynamic_topk_hard_negative=7, centroid_learning_rate=5e-4,
+                                    learning_rate=2e-5, max_steps=2, logging_steps=1, save_strategy="no", report_to=[],
+                                    dataloader_drop_last=True, seed=2022)
+    trainer = RepCONCFinetuner(qrels=qrels, model=model, args=args, train_dataset=feats,
+                               data_collator=FinetuneCollator(_PtHashTokenizer(), 8, 24))
+    batch = trainer.data_collator(feats)
+    model.zero_grad()
+    loss = trainer.training_step(model, batch)
+    got = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert torch.isfinite(loss) and float(got["centroids"].abs().sum()) > 0
+    # one-pass objective on the same codes; dropout masks differ, so compare in eval-mode-free terms: dropout 0.1 on
+    # a 1-layer encoder would make the passes differ — replay is what RandContext is for, so re-run with it disabled
+    cfg.hidden_dropout_prob = 0.0
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.zero_grad()
+    loss = trainer.training_step(model, batch)
+    got = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    dev_batch = {k: {kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV) for k, v in batch.items()}
+    q = model(**dev_batch["query_input"]).continuous_embeds
+    p = model(**dev_batch["pos_doc_input"]).continuous_embeds
+    n = model(**dev_batch["neg_doc_input"]).continuous_embeds
+    docs = torch.cat([p, n], 0)
+    with torch.no_grad():
+        codes = model.quantize(docs)
+    quant = model.decode(codes)
+    ste = quant.detach() + (docs - docs.detach()) + (quant - quant.detach())
+    direct = trainer.compute_contrastive_loss(q, ste, dev_batch["qids"], torch.cat([dev_batch["pos_docids"], dev_batch["neg_docids"]]))
+    mse = 0
+    for rep, qt in ((p, quant[:nq]), (n, quant[nq:])):
+        for a in range(0, rep.shape[0], 6):
+            mse = mse + ((qt[a:a + 6] - rep[a:a + 6]) ** 2).sum(-1).mean() * args.mse_loss_weight
+    (direct + mse).backward()
+    assert abs(float(direct.detach()) - float(loss)) < 1e-4
+    for name, grad in got.items():
+        assert torch.allclose(grad, dict(model.named_parameters())[name].grad, rtol=2e-3, atol=2e-5), name
+    opt = trainer.create_optimizer()
+    assert len(opt.param_groups) == 3 and opt.param_groups[2]["lr"] == 5e-4 and len(opt.param_groups[2]["params"]) == 1
+    before = model.centroids.detach().clone()
+    out = trainer.train()
+    assert out.global_step == 2 and np.isfinite(out.training_loss)
+    assert not torch.equal(before, model.centroids.detach())
