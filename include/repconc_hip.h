@@ -270,6 +270,13 @@ int rc_index_search(rc_index_t idx, const float* q, int nq, int k, float* scores
  * lut: [nq,M,256] from rc_adc_lut; base[qi,p] = rows scanned before probe p; count[qi] = rows scanned in total;
  * stride >= max count.  ids -1 / score -inf pad queries whose probed lists hold fewer than k rows.
  * ws: rc_ivf_search_ws_bytes(nq, stride).  status bit1: more than 16384 rows tie at the k-th score. */
+/* Build side: cell[b] = argmin_l ||x_b - cent_l||^2 (first minimum) for nlist coarse centroids of the full dimension D,
+ * evaluated as ||c||^2 - 2<x,c> on the fp32 matrix cores with the argmin fused in (the [B, nlist] score matrix is never
+ * written).  x: [B, ldx >= D] fp32, 16-byte aligned rows, ldx % 4 == 0, D % 16 == 0; cent: [nlist, D]; cell: [B] int32;
+ * ws: rc_ivf_coarse_assign_ws_bytes(nlist). */
+size_t rc_ivf_coarse_assign_ws_bytes(int nlist);
+int rc_ivf_coarse_assign(rc_handle_t h, const float* x, int64_t ldx, const float* cent, int64_t B, int D, int nlist,
+                         int* cell, void* ws, size_t ws_bytes, rc_stream_t stream);
 size_t rc_ivf_search_ws_bytes(int nq, int64_t stride);
 int rc_ivf_search(rc_handle_t h, const uint8_t* codes, const int64_t* list_off, const int64_t* ids, int64_t N,
                   int M, int K, const float* lut, const int* probes, const int* base, const int* count, int nq,

@@ -206,3 +206,155 @@ extern "C" int rc_ivf_search(rc_handle_t h, const uint8_t* codes, const int64_t*
     // N = 0: finding fewer than k rows is legitimate here (the probed lists may hold fewer), only overflow is an error
     return rc_adc_launch_select(h, cand, cnt, nq, 0, k, 0, scores, out_ids, status, s);
 }
+
+// ------------------------------------------------------------------------------------------------ coarse quantiser
+// Cell of every document: argmin_l ||x - c_l||^2 = argmin_l (||c_l||^2 - 2 <x, c_l>), first minimum, for nlist coarse
+// centroids of the FULL dimension D (the reference has no coarse quantiser, evaluate_repconc.py:101-118 builds one list;
+// this is the build side of BASELINE.json's nlist = 5000 configuration).  GEMM-shaped ([B, D] x [D, nlist], 2 B nlist D
+// flop = 68 Tflop for the 8.84 M-passage corpus at nlist = 5000), so it runs on the matrix cores:
+// v_mfma_f32_32x32x2_f32 — fp32 inputs, exact fp32 products, fp32 accumulation in k order (bit-identical to an fmaf
+// chain), 157 TFLOP/s peak — with the argmin fused into the epilogue so the [B, nlist] score matrix never exists.
+//
+// Block = 4 waves = 128 documents x (all list tiles of 128 centroids, one after the other); wave (wr, wc) owns the
+// 64 x 64 corner (centroids wr*64.., documents wc*64..) as 2 x 2 MFMA tiles (rows of D = centroids, columns = documents:
+// a lane holds 16 centroids of ONE document per tile, so the running argmin needs no cross-lane traffic).  K is walked in
+// chunks of 16 staged in LDS (rows padded to 17 floats: conflict-free column reads).
+typedef float ivf_f32x16 __attribute__((ext_vector_type(16)));
+#define IVFC_TILE 128
+#define IVFC_KC 16
+#define IVFC_LD (IVFC_KC + 1)
+
+__global__ __launch_bounds__(256) void ivf_coarse_assign_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                const float* __restrict__ cent,
+                                                                const float* __restrict__ cnorm, int64_t B, int D,
+                                                                int nlist, int* __restrict__ cell) {
+    __shared__ float sa[2][IVFC_TILE * IVFC_LD];     // centroid chunk  [128][16 (+1)]
+    __shared__ float sb[2][IVFC_TILE * IVFC_LD];     // document chunk  [128][16 (+1)]
+    __shared__ float s_best[2][IVFC_TILE];
+    __shared__ int s_idx[2][IVFC_TILE];
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int col = l & 31, half = l >> 5;
+    const int64_t d0 = (int64_t)blockIdx.x * IVFC_TILE;
+    // loader mapping: thread -> (row = tid / 2, 8 consecutive k = (tid & 1) * 8)
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;
+    const int64_t drow = (d0 + lrow < B) ? d0 + lrow : B - 1;
+    float best[2] = {INFINITY, INFINITY};
+    int bidx[2] = {0, 0};
+    const int nkc = D / IVFC_KC;
+    for (int lt = 0; lt < nlist; lt += IVFC_TILE) {
+        const int crow = (lt + lrow < nlist) ? lt + lrow : nlist - 1;
+        ivf_f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        float4 ra[2], rb[2];
+        auto gload = [&](int kc) {
+            const float4* pa = reinterpret_cast<const float4*>(cent + (size_t)crow * D + kc * IVFC_KC + lk);
+            const float4* pb = reinterpret_cast<const float4*>(x + drow * ldx + kc * IVFC_KC + lk);
+            ra[0] = pa[0]; ra[1] = pa[1];
+            rb[0] = pb[0]; rb[1] = pb[1];
+        };
+        auto sstore = [&](int buf) {
+            float* da = &sa[buf][lrow * IVFC_LD + lk];
+            float* db = &sb[buf][lrow * IVFC_LD + lk];
+            da[0] = ra[0].x; da[1] = ra[0].y; da[2] = ra[0].z; da[3] = ra[0].w;
+            da[4] = ra[1].x; da[5] = ra[1].y; da[6] = ra[1].z; da[7] = ra[1].w;
+            db[0] = rb[0].x; db[1] = rb[0].y; db[2] = rb[0].z; db[3] = rb[0].w;
+            db[4] = rb[1].x; db[5] = rb[1].y; db[6] = rb[1].z; db[7] = rb[1].w;
+        };
+        gload(0);
+        sstore(0);
+        __syncthreads();
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < nkc) gload(kc + 1);
+#pragma unroll
+            for (int ks = 0; ks < IVFC_KC / 2; ++ks) {
+                float fa[2], fb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[t] = sa[buf][(wr * 64 + t * 32 + col) * IVFC_LD + 2 * ks + half];   // A[i = col][k = half]
+                    fb[t] = sb[buf][(wc * 64 + t * 32 + col) * IVFC_LD + 2 * ks + half];   // B[k = half][j = col]
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+            if (kc + 1 < nkc) sstore(buf ^ 1);
+            __syncthreads();
+        }
+        // epilogue: this lane's document of column tile b is wc*64 + b*32 + col; its 16 centroids of row tile a are
+        // lt + wr*64 + a*32 + (r & 3) + 8 (r >> 2) + 4 half, ascending in r — strict < keeps the first minimum
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = lt + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (c < nlist) {
+                        const float s = cnorm[c] - 2.0f * acc[a][b][r];
+                        if (s < best[b] || (s == best[b] && c < bidx[b])) { best[b] = s; bidx[b] = c; }
+                    }
+                }
+        __syncthreads();                                           // the next list tile overwrites buffer 0
+    }
+    // merge: the two half-waves of a lane pair, then the two waves (wr = 0, 1) that share the documents
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const float ob = __shfl_xor(best[b], 32);
+        const int oi = __shfl_xor(bidx[b], 32);
+        if (ob < best[b] || (ob == best[b] && oi < bidx[b])) { best[b] = ob; bidx[b] = oi; }
+    }
+    if (half == 0) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            s_best[wr][wc * 64 + b * 32 + col] = best[b];
+            s_idx[wr][wc * 64 + b * 32 + col] = bidx[b];
+        }
+    }
+    __syncthreads();
+    if (tid < IVFC_TILE && d0 + tid < B) {
+        float v = s_best[0][tid];
+        int i = s_idx[0][tid];
+        if (s_best[1][tid] < v || (s_best[1][tid] == v && s_idx[1][tid] < i)) i = s_idx[1][tid];
+        cell[d0 + tid] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void ivf_cnorm_kernel(const float* __restrict__ cent, int D, int nlist, float* __restrict__ cnorm) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (c >= nlist) return;
+    float s = 0.f;
+    for (int j = l; j < D; j += 64) s = __builtin_fmaf(cent[(size_t)c * D + j], cent[(size_t)c * D + j], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (l == 0) cnorm[c] = s;
+}
+
+// x: [B, ldx >= D] fp32 (16-byte aligned rows, ldx % 4 == 0), cent: [nlist, D] fp32, cell: [B] int32.
+// ws: nlist floats (centroid norms).  D % 16 == 0.
+extern "C" size_t rc_ivf_coarse_assign_ws_bytes(int nlist) { return nlist > 0 ? rc_align_up((size_t)nlist * sizeof(float), 256) : 0; }
+
+extern "C" int rc_ivf_coarse_assign(rc_handle_t h, const float* x, int64_t ldx, const float* cent, int64_t B, int D,
+                                    int nlist, int* cell, void* ws, size_t ws_bytes, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !x || !cent || !cell || B < 0 || D <= 0 || nlist <= 0 || ldx < D) return RC_EINVAL;
+    if (D % IVFC_KC != 0 || ldx % 4 != 0) return RC_ESHAPE;
+    if (!ws || ws_bytes < rc_ivf_coarse_assign_ws_bytes(nlist)) return RC_EWORKSPACE;
+    if (B == 0) return RC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    float* cnorm = (float*)ws;
+    hipLaunchKernelGGL(ivf_cnorm_kernel, dim3((unsigned)((nlist + 3) / 4)), dim3(256), 0, s, cent, D, nlist, cnorm);
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(ivf_coarse_assign_kernel, dim3((unsigned)((B + IVFC_TILE - 1) / IVFC_TILE)), dim3(256), 0, s, x, ldx,
+                       cent, (const float*)cnorm, B, D, nlist, cell);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}

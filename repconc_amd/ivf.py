@@ -42,13 +42,23 @@ def coarse_kmeans(x: torch.Tensor, nlist: int, iters: int = 10, seed: int = 1234
     return cent
 
 
-def coarse_assign(x: torch.Tensor, cent: torch.Tensor, chunk: int = 1 << 16) -> torch.Tensor:
-    """L2-nearest centroid of every row: argmin ||c||^2 - 2 x.c  (GEMM)."""
-    c2 = (cent * cent).sum(1)
-    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
-    for i in range(0, x.shape[0], chunk):
-        out[i:i + chunk] = torch.argmin(c2[None, :] - 2.0 * (x[i:i + chunk].float() @ cent.T), dim=1)
-    return out
+def coarse_assign(x: torch.Tensor, cent: torch.Tensor, chunk: int = 1 << 20) -> torch.Tensor:
+    """L2-nearest coarse centroid of every row, argmin_l (||c_l||^2 - 2 <x, c_l>), first minimum: the fp32-MFMA
+    GEMM + fused argmin of csrc/ivf_search.hip (rc_ivf_coarse_assign); the [n, nlist] scores are never materialised."""
+    xt = ops._rows_f32(x)
+    cent = cent.float().contiguous()
+    n, D = xt.shape
+    nlist = cent.shape[0]
+    lib, h, s, _ = ops._ctx(xt)
+    wsb = lib.rc_ivf_coarse_assign_ws_bytes(nlist)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=xt.device)
+    out = torch.empty((n,), dtype=torch.int32, device=xt.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for i in range(0, n, chunk):                        # chunks only bound the grid size, not the memory
+        part = xt[i:i + chunk]
+        _lib.check(lib.rc_ivf_coarse_assign(h, p(part), xt.stride(0), p(cent), part.shape[0], D, nlist,
+                                            C.c_void_p(out.data_ptr() + 4 * i), p(ws), wsb, s), "rc_ivf_coarse_assign", h)
+    return out.to(torch.int64)
 
 
 class IVFPQIndex:

@@ -1367,3 +1367,63 @@ def test_repconc_finetuner_on_transformers5_gradients_and_train_loop(tmp_path):
     out = trainer.train()
     assert out.global_step == 2 and np.isfinite(out.training_loss)
     assert not torch.equal(before, model.centroids.detach())
+
+
+def test_ivf_coarse_assignment_kernel_is_the_nearest_cell():
+    """rc_ivf_coarse_assign (fp32 matrix cores, fused argmin): every document goes to a cell whose fp64 distance equals
+    the fp64 minimum up to fp32 rounding of the GEMM form; exact ties (duplicated centroids) take the lower cell;
+    ragged sizes (B, nlist not multiples of the 128-tile)."""
+    from repconc_amd.ivf import coarse_assign
+    rng = np.random.default_rng(9)
+    for B, nlist in ((1000, 300), (4097, 5000), (77, 129)):
+        x = rng.standard_normal((B, 768)).astype(np.float32)
+        cent = rng.standard_normal((nlist, 768)).astype(np.float32)
+        cent[nlist // 2] = cent[3]                                  # an exact duplicate: cell 3 must win over nlist/2
+        x[:5] = cent[3] + 1e-3 * rng.standard_normal((5, 768)).astype(np.float32)
+        got = coarse_assign(_t(x), _t(cent)).cpu().numpy()
+        d = ((x.astype(np.float64)[:, None, :] - cent.astype(np.float64)[None, :, :]) ** 2).sum(-1) if B * nlist < 2e6 else None
+        if d is None:
+            xx, cc = torch.from_numpy(x).double().to(DEV), torch.from_numpy(cent).double().to(DEV)
+            d = (torch.cdist(xx, cc) ** 2).cpu().numpy()
+        best = d.min(1)
+        mine = d[np.arange(B), got]
+        assert np.all(mine <= best + 2e-4 * (1.0 + best)), (B, nlist)
+        assert np.all(got[:5] == 3)
+        assert (got == d.argmin(1)).mean() > 0.999
+
+
+def test_ivf_m96_nlist5000_against_the_oracle():
+    """BASELINE configs[3] shape: M = 96 (dsub 8), IVF with nlist = 5000 cells (HIP coarse assignment), 300 k rows.
+    (a) every nprobe: ids and score bits equal the brute-force oracle on the same cells; (b) nprobe = nlist equals the
+    flat M = 96 search; (c) the cells are the nearest coarse centroids."""
+    from repconc_amd import ops
+    from repconc_amd.index import PQIndex
+    from repconc_amd.ivf import IVFPQIndex
+    N, M, nlist, nq = 300000, 96, 5000, 7
+    x = synth.clustered_embeddings(51, N, n_clusters=256)
+    C = synth.sample_centroids(52, x[:8192], M)
+    q = x[np.random.default_rng(53).integers(0, N, nq)] + 0.2 * synth.gaussian(54, (nq, 768))
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(C)
+    ivf.train(x[:60000], iters=3)
+    ivf.add(x)
+    codes = ops.assign_nearest(_t(x), _t(C), torch.uint8)
+    lens = (ivf.list_off[1:] - ivf.list_off[:-1])
+    list_ids = torch.empty(N, dtype=torch.int64, device=DEV)
+    list_ids[ivf.ids] = torch.repeat_interleave(torch.arange(nlist, device=DEV), lens)
+    assert torch.equal(ivf.codes, codes[ivf.ids]) and int(lens.sum()) == N
+    xs, cs = torch.from_numpy(x[:2000]).double().to(DEV), ivf.coarse.double()
+    d = torch.cdist(xs, cs) ** 2
+    assert float((d.gather(1, list_ids[:2000, None])[:, 0] <= d.min(1).values * (1 + 1e-5) + 1e-4).float().mean()) == 1.0   # (c)
+    cn, ln, co = codes.cpu().numpy(), list_ids.cpu().numpy(), ivf.coarse.cpu().numpy()
+    for nprobe, k in ((1, 10), (16, 100), (128, 1000)):
+        s, i = ivf.search(q, k, nprobe)
+        ws, wi = pq_oracle.ivf_search(q, C, cn, ln, co, k, nprobe)
+        assert np.array_equal(i, wi), nprobe                                       # (a)
+        assert np.array_equal(s.view(np.uint32), ws.view(np.uint32))
+    flat = PQIndex(768, M, device=DEV)
+    flat.set_centroids(C)
+    flat.add_codes(codes)
+    fs, fi = flat.search(_t(q), 200)
+    s, i = ivf.search(_t(q), 200, nprobe=nlist)
+    assert torch.equal(i, fi) and torch.equal(s, fs)                              # (b)
