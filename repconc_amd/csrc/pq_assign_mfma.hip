@@ -450,15 +450,17 @@ __global__ __launch_bounds__(256) void assign_redo_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------ host
-static unsigned mf_redo_cap(int64_t B, int M) { return (unsigned)(B * M / 32 + 65536); }
+// one slot per (row, sub-quantiser) pair: the doubt list cannot overflow, whatever the codebook (4 B M bytes: 201 MB for a
+// 2^20-row chunk at M = 48), so no caller has to synchronise and re-run
+static unsigned mf_redo_cap(int64_t B, int M) { return (unsigned)(B * M); }
 
 extern "C" size_t rc_pq_assign_nearest_fast_ws_bytes(int64_t B, int M) {
     if (B <= 0 || M <= 0) return 0;
     return rc_align_up(256 + (size_t)mf_redo_cap(B, M) * sizeof(unsigned), 256);
 }
 
-// Asynchronous.  If more than B*M/32 + 65536 pairs are doubtful (degenerate codebooks: duplicated centroids) the list
-// overflows and the codes of the dropped pairs are provisional: query rc_pq_assign_nearest_fast_overflow afterwards.
+// Asynchronous and complete: every doubtful pair (at most B*M of them) is re-judged exactly by assign_redo_kernel.
+// rc_pq_assign_nearest_fast_overflow remains for statistics (number of doubtful pairs) and always reports 0.
 extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D,
                                          int M, int K, uint8_t* codes_u8, int64_t* codes_i64, void* ws, size_t ws_bytes,
                                          rc_stream_t stream) {

@@ -42,6 +42,8 @@ extern "C" int rc_create(rc_handle_t* out, int device) {
     h->ev_fork = h->ev_join = nullptr;
     for (auto& g : h->graphs) { g.ws = nullptr; g.graph = nullptr; g.exec = nullptr; g.stamp = 0; }
     h->graph_stamp = 0;
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
     h->graph_broken = 0;
     h->capturing = 0;
     *out = h;
@@ -57,6 +59,7 @@ extern "C" int rc_destroy(rc_handle_t h) {
             for (hipEvent_t e : v) (void)hipEventDestroy(e);
         for (double* t : h->exp2_tab)
             if (t) (void)hipFree(t);
+        if (h->scratch) (void)hipFree(h->scratch);
         for (auto& g : h->graphs) {
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
             if (g.graph) (void)hipGraphDestroy(g.graph);
@@ -64,6 +67,22 @@ extern "C" int rc_destroy(rc_handle_t h) {
     }
     delete h;
     return RC_OK;
+}
+
+void* rc_scratch(rc_handle_t h, size_t bytes) {
+    if (!h) return nullptr;
+    if (bytes <= h->scratch_bytes) return h->scratch;
+    if (h->scratch) {
+        (void)hipDeviceSynchronize();                    // work queued on the old block finishes before it is freed
+        (void)hipFree(h->scratch);
+        h->scratch = nullptr;
+        h->scratch_bytes = 0;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    h->scratch = p;
+    h->scratch_bytes = bytes;
+    return p;
 }
 
 // 2^(j/N) correctly rounded to double via long-double exp2l (64-bit significand), uploaded once.
@@ -284,44 +303,78 @@ extern "C" int rc_code_hist(rc_handle_t h, const void* codes, int code_dtype, in
 }
 
 // ------------------------------------------------------------------------------------------ k-means
-// Lloyd sufficient statistics for one sub-quantiser per block column: sums[m][k][:] (fp64) and
-// counts[m][k].  A block owns (row strip, m); the K x dsub fp64 accumulator is privatised in LDS
-// (K*dsub*8 = 32 KiB at dsub 16, 128 KiB at dsub 64; dsub 96 is processed in two halves) and
-// merged with fp64 global atomics.  fp64 makes the merge order irrelevant to ~1e-16, so per-rank
-// statistics can be summed in any order (train/run_warmup.py:113 runs this inside Faiss).
-__global__ __launch_bounds__(256) void kmeans_stats_kernel(const float* __restrict__ x, int64_t ldx,
-                                                           const uint8_t* __restrict__ codes, int64_t n, int M,
-                                                           int dsub, int j0, int jn, int rows_per_block,
-                                                           double* __restrict__ sums,
-                                                           unsigned long long* __restrict__ counts) {
-    extern __shared__ __attribute__((aligned(16))) double acc[];  // [K][jn] then counts [K] (as u32)
-    unsigned* cnt = reinterpret_cast<unsigned*>(acc + (size_t)RC_K * jn);
-    const int tid = threadIdx.x;
-    const int m = blockIdx.y;
-    for (int i = tid; i < RC_K * jn; i += 256) acc[i] = 0.0;
-    for (int i = tid; i < RC_K; i += 256) cnt[i] = 0u;
-    __syncthreads();
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
-    // jn consecutive lanes cooperate on one row: lane j adds x[row, m*dsub + j0 + j]
-    const int rows_in_flight = 256 / jn;
-    const int jr = tid % jn, rr = tid / jn;
-    if (rr < rows_in_flight) {
-        for (int64_t r = r0 + rr; r < r1; r += rows_in_flight) {
-            const int k = codes[r * M + m];
-            atomicAdd(&acc[(size_t)k * jn + jr], (double)x[r * ldx + m * dsub + j0 + jr]);
-            if (jr == 0 && j0 == 0) atomicAdd(&cnt[k], 1u);
+// Lloyd sufficient statistics sums[m][k][:] (fp64) and counts[m][k], DETERMINISTIC: every sum has a fixed order, so the
+// warm-up is reproducible run to run and rank to rank (round 1 merged LDS partials with fp64 atomics).
+//
+//  stage 1  grid (strips, M), block = 256 threads = the 256 centroids.  A block walks its strip of rows in order; the
+//           row's code is block-uniform (staged through LDS in chunks of 1024), the ONE thread k == code adds the row's
+//           sub-vector to its private fp64 registers — per (strip, m, k) the rows are added in ascending order, no two
+//           threads ever touch the same accumulator, every x element is read exactly once.  Partials go to scratch
+//           [strip][m][k][dsub].  The wave-uniform test (code >> 6 == wave) skips the three waves that do not own k.
+//  stage 2  sums[m][k][j] += partials in strip order; counts likewise.
+// At most 64 strips (100 MB of scratch at M = 48): 3072 blocks of ~138 k rows for the 8.84 M-row corpus.
+#define KM_CHUNK 1024
+#define KM_MAX_STRIPS 64
+
+template <int JN>
+__global__ __launch_bounds__(256) void kmeans_stats_det_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const uint8_t* __restrict__ codes, int64_t n, int M, int dsub,
+                                                               int j0, int64_t rows_per_strip, double* __restrict__ part,
+                                                               unsigned* __restrict__ pcnt) {
+    __shared__ uint8_t cs[KM_CHUNK];
+    const int tid = threadIdx.x, m = blockIdx.y, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_strip;
+    const int64_t r1 = (r0 + rows_per_strip < n) ? r0 + rows_per_strip : n;
+    double acc[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) acc[j] = 0.0;
+    unsigned cnt = 0;
+    const float* xm = x + m * dsub + j0;
+    for (int64_t c0 = r0; c0 < r1; c0 += KM_CHUNK) {
+        const int nc = (int)((r1 - c0 < KM_CHUNK) ? r1 - c0 : KM_CHUNK);
+        __syncthreads();
+        for (int i = tid; i < nc; i += 256) cs[i] = codes[(c0 + i) * M + m];
+        __syncthreads();
+        for (int i = 0; i < nc; ++i) {
+            const int k = cs[i];                                   // block-uniform
+            if ((k >> 6) == wave) {                                // wave-uniform
+                if (k == tid) {
+                    const float* xr = xm + (c0 + i) * ldx;
+                    if constexpr (JN % 4 == 0) {
+#pragma unroll
+                        for (int j4 = 0; j4 < JN / 4; ++j4) {
+                            const float4 v = reinterpret_cast<const float4*>(xr)[j4];
+                            acc[4 * j4] += (double)v.x; acc[4 * j4 + 1] += (double)v.y;
+                            acc[4 * j4 + 2] += (double)v.z; acc[4 * j4 + 3] += (double)v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < JN; ++j) acc[j] += (double)xr[j];
+                    }
+                    ++cnt;
+                }
+            }
         }
     }
-    __syncthreads();
-    for (int i = tid; i < RC_K * jn; i += 256) {
-        const int k = i / jn, j = i - k * jn;
-        const double v = acc[i];
-        if (v != 0.0) atomicAdd(sums + ((size_t)m * RC_K + k) * dsub + j0 + j, v);
+    double* p = part + (((size_t)blockIdx.x * M + m) * RC_K + tid) * dsub + j0;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) p[j] = acc[j];
+    if (j0 == 0) pcnt[((size_t)blockIdx.x * M + m) * RC_K + tid] = cnt;
+}
+
+__global__ __launch_bounds__(256) void kmeans_stats_reduce_kernel(const double* __restrict__ part, const unsigned* __restrict__ pcnt,
+                                                                  int strips, int64_t per_strip, int dsub,
+                                                                  double* __restrict__ sums, unsigned long long* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_strip) return;
+    double s = 0.0;
+    for (int t = 0; t < strips; ++t) s += part[(size_t)t * per_strip + i];
+    sums[i] += s;
+    if (i % dsub == 0) {
+        unsigned long long c = 0;
+        for (int t = 0; t < strips; ++t) c += pcnt[(size_t)t * (per_strip / dsub) + i / dsub];
+        counts[i / dsub] += c;
     }
-    if (j0 == 0)
-        for (int i = tid; i < RC_K; i += 256)
-            if (cnt[i]) atomicAdd(counts + (size_t)m * RC_K + i, (unsigned long long)cnt[i]);
 }
 
 extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const uint8_t* codes, int64_t n, int D,
@@ -332,16 +385,44 @@ extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const
     const int dsub = D / M;
     if (dsub > 256) return RC_ESHAPE;
     if (n == 0) return RC_OK;
-    const int rpb = 8192;
-    dim3 grid((unsigned)((n + rpb - 1) / rpb), (unsigned)M);
-    const int jmax = 48;  // K*48*8 = 96 KiB of LDS per pass
-    for (int j0 = 0; j0 < dsub; j0 += jmax) {
-        const int jn = (dsub - j0 < jmax) ? dsub - j0 : jmax;
-        const size_t lds = (size_t)RC_K * jn * sizeof(double) + RC_K * sizeof(unsigned);
-        hipLaunchKernelGGL(kmeans_stats_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, ldx, codes, n, M, dsub,
-                           j0, jn, rpb, sums, reinterpret_cast<unsigned long long*>(counts));
+    int64_t rps = 8192;                                            // rows per strip
+    int strips = (int)((n + rps - 1) / rps);
+    if (strips > KM_MAX_STRIPS) {
+        strips = KM_MAX_STRIPS;
+        rps = (n + strips - 1) / strips;
+        rps = (rps + KM_CHUNK - 1) / KM_CHUNK * KM_CHUNK;
+        strips = (int)((n + rps - 1) / rps);
+    }
+    const int64_t per_strip = (int64_t)M * RC_K * dsub;
+    const size_t pbytes = rc_align_up((size_t)strips * per_strip * sizeof(double), 256);
+    const size_t cbytes = rc_align_up((size_t)strips * M * RC_K * sizeof(unsigned), 256);
+    char* ws = (char*)rc_scratch(h, pbytes + cbytes);
+    if (!ws) return RC_EHIP;
+    double* part = (double*)ws;
+    unsigned* pcnt = (unsigned*)(ws + pbytes);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)strips, (unsigned)M);
+    const bool vec = (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0) && (dsub % 4 == 0);
+    for (int j0 = 0; j0 < dsub;) {
+        const int left = dsub - j0;
+        if (vec && left >= 16) {
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<16>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt);
+            j0 += 16;
+        } else if (vec && left >= 8) {
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<8>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt);
+            j0 += 8;
+        } else if (vec && left >= 4) {
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<4>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt);
+            j0 += 4;
+        } else {
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<1>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt);
+            j0 += 1;
+        }
         RC_LAUNCH_CHECK(h);
     }
+    hipLaunchKernelGGL(kmeans_stats_reduce_kernel, dim3((unsigned)((per_strip + 255) / 256)), dim3(256), 0, s, (const double*)part,
+                       (const unsigned*)pcnt, strips, per_strip, dsub, sums, reinterpret_cast<unsigned long long*>(counts));
+    RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
 

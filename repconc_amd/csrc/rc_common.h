@@ -32,6 +32,8 @@ struct rc_handle_s {
     };
     solve_graph graphs[4];
     unsigned long long graph_stamp;
+    void* scratch;                                    // handle-owned device scratch (rc_scratch), grown on demand
+    size_t scratch_bytes;
     int graph_broken;                                 // capture failed once on this handle: stay eager
     int capturing;                                    // inside stream capture: no event marks
 };
@@ -47,6 +49,10 @@ int rc_sk_sweep0_centre(rc_handle_t h, float* d, const float* mx, const float* m
 int rc_sk_argmax_strided(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2, int64_t B,
                          int M, double eps, int t, int code_stride, int m_offset, uint8_t* codes_u8,
                          int64_t* codes_i64, int* flags, hipStream_t s);
+
+// handle-owned device scratch of at least `bytes` bytes (grown with hipMalloc when too small: the old block is freed
+// after a device synchronise); nullptr on allocation failure.  For entry points whose ABI has no workspace argument.
+void* rc_scratch(rc_handle_t h, size_t bytes);
 
 // device pointer to the table 2^(j/2^tb), j < 2^tb (tb = 8, 11 or 12), created on first use
 const double* rc_exp2_table(rc_handle_t h, int tb);

@@ -55,9 +55,13 @@ class JPQ(nn.Module):
         with torch.no_grad():                                                                     # :176
             neg_pids = self.pq_index.search(query_embeds.detach().float().contiguous(), self.neg_top_k)[1]
         nq, k = neg_pids.shape
-        neg_doc_embeds = self._decode_rows(neg_pids).reshape(nq, k, -1)
+        # an index with fewer than neg_top_k rows pads the result with id -1: those slots decode row 0 and are then
+        # pushed out of the softmax (the reference would index with -1, i.e. silently use the LAST row)
+        empty = neg_pids < 0
+        neg_doc_embeds = self._decode_rows(neg_pids.clamp_min(0)).reshape(nq, k, -1)
         neg_masks = self._compute_negative_mask(qids, neg_pids)
         query_negdoc_scores = (query_embeds.unsqueeze(1) * neg_doc_embeds).sum(-1) / self.temperature
+        query_negdoc_scores = query_negdoc_scores.masked_fill(empty, -10000.0)
         pos_pids = torch.tensor([random.choice(self.qrels[int(q)]) for q in qids.tolist()], dtype=torch.int64,
                                 device=neg_pids.device)
         rel_doc_embeds = self._decode_rows(pos_pids)

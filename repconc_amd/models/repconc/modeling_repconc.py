@@ -54,6 +54,12 @@ class RepCONC(nn.Module):
         D = dense_encoder.config.hidden_size
         M, K = config.MCQ_M, config.MCQ_K
         assert config.hidden_size % M == 0
+        # fail at construction, not at the first kernel launch: the exact-order distance kernels exist for these
+        # sub-vector widths (each has its own torch-CPU summation pattern) and K is fixed at 256
+        if K != ops.K or (config.hidden_size // M) not in ops.SUPPORTED_DSUB:
+            raise _lib.RepconcHipError(
+                f"MCQ_K={K}, MCQ_M={M} (sub-vector width {config.hidden_size // M}) unsupported: K must be 256 and "
+                f"hidden_size / MCQ_M one of {ops.SUPPORTED_DSUB}")
         # OPQ rotation (identity until the warm-up fills it) and the M x K sub-centroids
         self.register_buffer("rotation", torch.eye(D))
         self.centroids = nn.Parameter(torch.randn((M, K, config.hidden_size // M)))

@@ -104,15 +104,13 @@ def assign_nearest(x: torch.Tensor, centroids: torch.Tensor, dtype=torch.int64, 
         ws = torch.empty(n, dtype=torch.uint8, device=x.device)
         _lib.check(lib.rc_pq_assign_nearest_fast(h, _p(x), x.stride(0), _p(c), B, D, M, K, _p(u8), _p(i64), _p(ws), n, s),
                    "rc_pq_assign_nearest_fast", h)
-        torch.cuda.current_stream(x.device).synchronize()
-        doubtful = C.c_int(0)
-        over = lib.rc_pq_assign_nearest_fast_overflow(h, _p(ws), B, M, C.byref(doubtful))
-        if over < 0:
-            _lib.check(over, "rc_pq_assign_nearest_fast_overflow", h)
-        if stats is not None:
+        if stats is not None:                               # statistics only: this (and nothing else) synchronises
+            doubtful = C.c_int(0)
+            over = lib.rc_pq_assign_nearest_fast_overflow(h, _p(ws), B, M, C.byref(doubtful))
+            if over < 0:
+                _lib.check(over, "rc_pq_assign_nearest_fast_overflow", h)
             stats.update(method="mfma", doubtful=int(doubtful.value), overflow=bool(over))
-        if not over:
-            return codes
+        return codes
     _lib.check(lib.rc_pq_assign_nearest(h, _p(x), x.stride(0), _p(c), B, D, M, K, _p(u8), _p(i64), s),
                "rc_pq_assign_nearest", h)
     if stats is not None:

@@ -14,8 +14,11 @@ training loop below restates Faiss 1.7.x's published procedure (SURVEY.md Append
 
 Arithmetic: assignment (`rc_pq_assign_nearest`), sufficient statistics (`rc_kmeans_stats`) and centroid update
 (`rc_kmeans_update`) are the HIP kernels; the 768x768 rotation GEMM and SVD are library calls on PyTorch-ROCm
-(SURVEY.md §2.3 K8).  With several ranks each rank passes its corpus shard and the statistics are combined with one
-all-gather + rank-ordered sum per Lloyd iteration (`gather_stats_`).
+(SURVEY.md §2.3 K8).  With several ranks each rank passes its corpus shard; everything that feeds the shared model is
+combined in rank order so that all ranks hold bit-identical rotations and centroids: the Lloyd statistics
+(`gather_stats_`: one all-gather + rank-ordered sum per iteration), the Procrustes matrix x^T x_rec
+(`rank_ordered_sum_`), and the random-sample initial centroids (drawn on rank 0, broadcast).  The returned index holds
+the local shard's codes with `id_offset` = its global position.
 """
 from __future__ import annotations
 
@@ -73,6 +76,32 @@ def gather_stats_(sums: torch.Tensor, counts: torch.Tensor, group=None):
     return sums, counts
 
 
+def _multi(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def rank_ordered_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over the ranks with a FIXED order (rank 0 first): all-gather + local adds, so every rank ends with
+    the same bits (an all-reduce's ring order is not fixed)."""
+    if not _multi(group):
+        return t
+    G = dist.get_world_size(group)
+    flat = torch.empty((G * t.numel(),), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(flat, t.contiguous().view(-1), group=group)
+    parts = flat.view(G, -1)
+    total = parts[0].clone()
+    for r in range(1, G):
+        total += parts[r]
+    t.copy_(total.view_as(t))
+    return t
+
+
+def broadcast_from_rank0_(t: torch.Tensor, group=None) -> torch.Tensor:
+    if _multi(group):
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return t
+
+
 def _reseed_empty(C: torch.Tensor, counts: torch.Tensor):
     """Faiss's empty-cluster rule: give an empty centroid a copy of the biggest cluster's centroid, perturbed by
     +-1/1024 (and the donor by the opposite sign)."""
@@ -100,6 +129,7 @@ def train_pq(x: torch.Tensor, M: int, n_iter: int, centroids: Optional[torch.Ten
     if centroids is None:                                   # random-sample initialisation
         perm = torch.from_numpy(np.random.default_rng(seed).permutation(n)[:256].copy()).to(x.device)
         centroids = x[perm].reshape(256, M, dsub).transpose(0, 1).contiguous()
+        broadcast_from_rank0_(centroids)                    # several ranks: everyone starts from rank 0's sample
     C = centroids.clone().float().contiguous()
     for it in range(n_iter):
         codes = ops.assign_nearest(x, C, torch.uint8)
@@ -108,22 +138,26 @@ def train_pq(x: torch.Tensor, M: int, n_iter: int, centroids: Optional[torch.Ten
         ops.kmeans_update_(sums, counts, C)
         _reseed_empty(C, counts)
     codes = ops.assign_nearest(x, C, torch.uint8)
-    mse = float(((ops.decode_raw(codes, C) - x) ** 2).sum(-1).mean())
-    return C, mse
+    err = torch.stack([((ops.decode_raw(codes, C) - x) ** 2).sum().double(),
+                       torch.tensor(float(n), dtype=torch.float64, device=x.device)])
+    rank_ordered_sum_(err)                                  # MSE over the rows of every rank
+    return C, float(err[0] / err[1])
 
 
 def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, n_pq: int = 4, seed: int = SEED):
     """OPQ rotation R [D,D] (x_rot = x @ R) by alternating PQ training and orthogonal Procrustes."""
     n, D = x.shape
     g = torch.Generator(device="cpu").manual_seed(seed)
-    R = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0].float().to(x.device)
+    R = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0].float().to(x.device)   # same seed on every rank
     C = None
     for it in range(n_outer):
         xr = (x @ R).contiguous()
         C, mse = train_pq(xr, M, n_pq_first if it == 0 else n_pq, centroids=C, seed=seed)
         codes = ops.assign_nearest(xr, C, torch.uint8)
         xrec = ops.decode_raw(codes, C)
-        U, _, Vh = torch.linalg.svd((x.T @ xrec).double())       # fp64: keeps R orthogonal to ~1e-7 after the cast
+        P = (x.T @ xrec).double()
+        rank_ordered_sum_(P)                                    # Procrustes matrix over the rows of every rank
+        U, _, Vh = torch.linalg.svd(P)                          # fp64: keeps R orthogonal to ~1e-7 after the cast
         R = (U @ Vh).float().contiguous()
         if it % 10 == 0 or it == n_outer - 1:
             logger.info("OPQ iteration %d: reconstruction mse %.5f", it, mse)
@@ -151,7 +185,67 @@ def warmup_from_embeds(corpus_embeds: np.ndarray, repconc, opq_iters: int = 50, 
         C = repconc.centroids.data.to(dev)
     index = PQIndex(D, M, 8, METRIC_INNER_PRODUCT, device=dev)
     index.set_centroids(C)
+    if _multi():                                                        # this rank's shard starts after the lower ranks' rows
+        sizes = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=dev)
+        sizes[dist.get_rank()] = N
+        rank_ordered_sum_(sizes)
+        index.id_offset = int(sizes[: dist.get_rank()].sum())
     for i0 in range(0, N, add_chunk):                                   # index.add(corpus_embeds), :114
         chunk = torch.from_numpy(np.ascontiguousarray(corpus_embeds[i0:i0 + add_chunk], dtype=np.float32)).to(dev)
         index.add((chunk @ R).contiguous())
     return repconc, PreTransformIndex(R.T.contiguous(), index)
+
+
+# ---------------------------------------------------------------------------------------------------------------- CLI
+def main(argv=None):
+    """`python -m repconc_amd.train.run_warmup --model_name_or_path ... --MCQ_M 48 --input_corpus_embed_path ...`
+    with the arguments of the reference's script (train/run_warmup.py:22-83,135-189): builds the RepCONC model around
+    the dense encoder, fits rotation + centroids on the corpus embeddings, saves the model, the tokenizer, the IndexPQ
+    file over the rotated vectors and the corpus ids."""
+    import os
+    from dataclasses import dataclass, field
+    from transformers import AutoConfig, AutoTokenizer, HfArgumentParser, set_seed
+    from ..faiss_io import write_index
+    from ..models.dense import AutoDense
+    from ..models.repconc import RepCONC
+
+    @dataclass
+    class DataArguments:
+        input_corpus_embed_path: str = field(metadata={"help": "corpus embeddings (.npy)"})
+        input_corpus_ids_path: str = field(metadata={"help": "corpus ids (.npy), copied next to the index"})
+        output_model_dir: str = field(metadata={"help": "where to save the RepCONC model"})
+        output_index_path: str = field(metadata={"help": "where to save the index"})
+        output_corpus_ids_path: str = field(metadata={"help": "where to save the corpus ids"})
+
+    @dataclass
+    class ModelArguments:
+        model_name_or_path: str = field(metadata={"help": "path of the dense encoder"})
+        MCQ_M: int = field(metadata={"help": "number of sub-vectors per text"})
+        similarity_metric: str = field(default=None, metadata={"choices": ["METRIC_CENTROID_COS", "METRIC_IP", "METRIC_COS"]})
+        pooling: str = field(default=None, metadata={"choices": ["cls", "mean"]})
+        MCQ_K: int = field(default=256)
+
+    model_args, data_args = HfArgumentParser((ModelArguments, DataArguments)).parse_args_into_dataclasses(argv)
+    logging.basicConfig(format="%(asctime)s-%(levelname)s-%(name)s- %(message)s", level=logging.INFO)
+    set_seed(2022)
+    config = AutoConfig.from_pretrained(model_args.model_name_or_path)
+    config.MCQ_M, config.MCQ_K = model_args.MCQ_M, model_args.MCQ_K
+    if model_args.similarity_metric is not None:
+        config.similarity_metric = model_args.similarity_metric
+    if model_args.pooling is not None:
+        config.pooling = model_args.pooling
+    tokenizer = AutoTokenizer.from_pretrained(model_args.model_name_or_path)
+    encoder = AutoDense.from_pretrained(model_args.model_name_or_path, config=config)
+    repconc = RepCONC(config, encoder, use_constraint=False, sk_epsilon=None, sk_iters=None).to("cuda")
+    repconc, index = warmup_from_embeds(np.load(data_args.input_corpus_embed_path), repconc)
+    os.makedirs(data_args.output_model_dir, exist_ok=True)
+    repconc.save_pretrained(data_args.output_model_dir)
+    tokenizer.save_pretrained(data_args.output_model_dir)
+    for path in (data_args.output_index_path, data_args.output_corpus_ids_path):
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    write_index(index.index, data_args.output_index_path)
+    np.save(data_args.output_corpus_ids_path, np.load(data_args.input_corpus_ids_path))
+
+
+if __name__ == "__main__":
+    main()

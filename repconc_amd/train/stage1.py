@@ -179,6 +179,19 @@ def stage1_training_step(model, query_input, pos_doc_input, qids, pos_docids, qr
     return float(loss.item())
 
 
+def allreduce_gradients_(model, group=None):
+    """Average the parameter gradients over the ranks (what DistributedDataParallel does for the reference's trainer).
+    `stage1_training_step` leaves LOCAL gradients of the global-batch loss in `.grad`: call this before
+    `optimizer.step()` when training on more than one rank without a DDP wrapper."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    for p in model.parameters():
+        if p.grad is not None:
+            dist.all_reduce(p.grad, group=group)
+            p.grad.div_(world)
+
+
 def make_optimizer(model, lr: float = 2e-5, centroid_lr: float = 5e-4, weight_decay: float = 0.0):
     """AdamW with the reference's three groups: decay / no-decay encoder parameters and the centroids at their own
     learning rate, weight decay 0 (finetune_repconc.py:488-502)."""

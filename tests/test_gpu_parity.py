@@ -787,8 +787,9 @@ def test_mfma_screened_assignment_non_finite_rows():
 
 
 def test_mfma_assignment_overflow_falls_back_and_unaligned_rows():
-    """All centroids identical: every pair is doubtful, the list overflows and assign_nearest("auto") must fall back
-    to the exact kernel (codes all 0).  Unaligned rows: ops realigns, the raw C call refuses."""
+    """All centroids identical: EVERY pair is doubtful — the doubt list holds one slot per pair, so nothing overflows,
+    the exact judge re-decides all of them (first minimum: code 0) without any host round trip.  Unaligned rows: ops
+    realigns, the raw C call refuses."""
     from repconc_amd import ops, _lib
     rng = np.random.default_rng(5)
     M, B = 48, 8192
@@ -796,8 +797,9 @@ def test_mfma_assignment_overflow_falls_back_and_unaligned_rows():
     x = rng.standard_normal((B, 768)).astype(np.float32)
     st = {}
     codes = ops.assign_nearest(_t(x), _t(C), torch.uint8, stats=st)
-    assert st["method"] == "exact" and st["overflow"]
+    assert st["method"] == "mfma" and not st["overflow"] and st["doubtful"] == B * M
     assert int(codes.max()) == 0
+    assert int(ops.assign_nearest(_t(x), _t(C), torch.uint8).max()) == 0          # the path without statistics
     wide = torch.zeros((64, 771), device=DEV)
     wide[:, 1:769] = _t(x[:64])
     st = {}
@@ -817,7 +819,7 @@ def test_mfma_assignment_overflow_falls_back_and_unaligned_rows():
 
 
 def test_adc_large_k_uses_exact_scan():
-    """k > 2048 on a large index must bypass the integer screen (candidate-buffer bound) and still be exact."""
+    """k > 2048 on a large index (round 1 bypassed the integer screen there; it is screened now) must still be exact."""
     from repconc_amd import ops
     M, N, nq, k = 48, 300000, 3, 3000
     C, codes, q = _adc_case(M, N, nq, seed=4242)
@@ -1427,3 +1429,55 @@ def test_ivf_m96_nlist5000_against_the_oracle():
     fs, fi = flat.search(_t(q), 200)
     s, i = ivf.search(_t(q), 200, nprobe=nlist)
     assert torch.equal(i, fi) and torch.equal(s, fs)                              # (b)
+
+
+def _warmup_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    from repconc_amd.models.repconc import RepCONC
+    from repconc_amd.train.run_warmup import warmup_from_embeds
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+    try:
+        x = synth.clustered_embeddings(91, 6000)
+        cfg = SimpleNamespace(hidden_size=768, MCQ_M=48, MCQ_K=256, similarity_metric="METRIC_IP")
+        enc = _TableEncoder(torch.zeros(4, 768))
+        model = RepCONC(cfg, enc, False, None, None).to(dev)
+        model, index = warmup_from_embeds(x[rank * 3000:(rank + 1) * 3000], model, opq_iters=3, pq_iters=3)
+        ret[rank] = (model.rotation.cpu().numpy(), model.centroids.detach().cpu().numpy(), index.index.id_offset,
+                     index.index.ntotal)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_multi_rank_warmup_gives_every_rank_the_same_rotation_and_centroids():
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_warmup_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert np.array_equal(ret[0][0], ret[1][0]) and np.array_equal(ret[0][1], ret[1][1])
+    assert (ret[0][2], ret[1][2]) == (0, 3000) and ret[0][3] == ret[1][3] == 3000
+
+
+def test_kmeans_statistics_are_deterministic_and_match_the_oracle():
+    """rc_kmeans_stats: fixed-order two-stage reduction — identical bits run to run, sums equal to the fp64 oracle to
+    rounding, counts exact, accumulation into non-zero buffers, every supported sub-vector width and a ragged size."""
+    from repconc_amd import ops
+    for M, n in ((48, 70001), (8, 5000), (64, 9000), (96, 3001)):
+        x = synth.gaussian(60 + M, (n, 768))
+        codes = synth.uniform_codes(61 + M, n, M)
+        xt, ct = _t(x), _t(codes)
+        s1, c1 = ops.kmeans_stats(xt, ct)
+        s2, c2 = ops.kmeans_stats(xt, ct)
+        assert torch.equal(s1, s2) and torch.equal(c1, c2)
+        ws, wc = pq_oracle.kmeans_stats(x, codes, M)
+        assert np.array_equal(c1.cpu().numpy(), wc)
+        np.testing.assert_allclose(s1.cpu().numpy(), ws, rtol=1e-12, atol=1e-9)
+        s3, c3 = ops.kmeans_stats(xt, ct, s1.clone(), c1.clone())                    # accumulates
+        np.testing.assert_allclose(s3.cpu().numpy(), 2 * ws, rtol=1e-12, atol=1e-9)
+        assert np.array_equal(c3.cpu().numpy(), 2 * wc)

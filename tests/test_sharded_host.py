@@ -176,3 +176,31 @@ def test_merge_topk_order_and_ties_on_cpu():
         items.sort(key=lambda t: (-t[0], t[1]))
         assert [int(v) for v in mi[qi]] == [t[1] for t in items[:k]]
         assert [float(v) for v in ms[qi]] == [t[0] for t in items[:k]]
+
+
+def _rank_sum_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from repconc_amd.train.run_warmup import broadcast_from_rank0_, rank_ordered_sum_
+    g = torch.Generator().manual_seed(100 + rank)
+    t = torch.randn(64, 64, generator=g, dtype=torch.float64) * (10.0 ** (3 * rank))      # wildly different magnitudes
+    init = torch.randn(5, 7, generator=g)
+    rank_ordered_sum_(t)
+    broadcast_from_rank0_(init)
+    ret[rank] = (t.numpy().copy(), init.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_gloo_rank_ordered_sum_and_rank0_broadcast_are_rank_identical():
+    """Multi-rank warm-up (train/run_warmup.py): the Procrustes matrix and the MSE are summed over the ranks in rank
+    order and the initial centroids come from rank 0, so every rank holds the same rotation and centroids bit for bit."""
+    world = 3
+    ret = mp.Manager().dict()
+    mp.spawn(_rank_sum_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    parts = [torch.randn(64, 64, generator=torch.Generator().manual_seed(100 + r), dtype=torch.float64) * (10.0 ** (3 * r))
+             for r in range(world)]
+    want = (parts[0] + parts[1]) + parts[2]
+    for r in range(world):
+        assert np.array_equal(ret[r][0], want.numpy())          # the same bits on every rank, rank order
+        assert np.array_equal(ret[r][1], ret[0][1])
