@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-adc", action="store_true", help="skip the ADC leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-per-rank", action="store_true",
+                    help="skip the per_rank_6144 leg (profiling runs: its launches of the sweep kernel would mix into "
+                         "the per-kernel averages of the timed 49152-row configuration)")
     ap.add_argument("--adc-batches", type=int, default=2)
     ap.add_argument("--adc-k", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=B_GLOBAL, help=argparse.SUPPRESS)
@@ -260,7 +263,7 @@ def main():
         out["multi_gpu_check"] = dist_check
 
     # ------------------------------------------------------------------ the 8-GPU recipe's per-rank shape on this GPU
-    if not use_dist and B == B_GLOBAL:
+    if not use_dist and B == B_GLOBAL and not args.no_per_rank:
         blr = B_GLOBAL // 8
         xr = pool[0][:blr].contiguous()
         for _ in range(2):

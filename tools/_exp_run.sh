@@ -1,3 +1,4 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r02i; mkdir -p $O
-timeout 2400 python -m pytest tests -q -m gpu --timeout 900 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -150 > $O/pytest_gpu.txt; grep -E "^FAILED|^ERROR|passed|failed" $O/pytest_gpu.txt | tail -20
-python tools/warmup_bench.py 2>&1 | tail -5
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r02j; mkdir -p $O; ROOT=$GRAFT_REPO_ROOT
+python tools/adc_quick_bench.py 48 96 > $O/adc.txt 2>&1; grep QPS $O/adc.txt
+export REPCONC_HIP_LIB=$ROOT/repconc_amd/lib/librepconc_hip_dual.so
+python tools/adc_quick_bench.py 48 96 > $O/adc_dual.txt 2>&1; grep QPS $O/adc_dual.txt

@@ -10,12 +10,12 @@ raw = json.load(open(sys.argv[1]))
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 B, M, K, NC, NQ, NB = 49152, 48, 256, 8841823, 1200, 1 << 20
 ALG = {  # SURVEY 8(d) per-unit bytes x units per launch
-    "sk_sweep_kernel": ("sk_sweep_kernel<false, false, true>", B * M * K * 4),
-    "adc_screen_mfma_kernel": ("adc_screen_mfma_kernel<48, 8>", NQ * NC * M),
+    "sk_sweep_kernel": ("sk_sweep2_kernel<2, true>", B * M * K * 4),
+    "adc_screen_cf_kernel": ("adc_screen_cf_kernel<48, 1, 4>", NQ * NC * M),
     "assign_mfma_kernel": ("assign_mfma_kernel<16>", NB * (768 * 4 + M)),
 }
 out = {"_how": "tools/pmc_collect.sh: rocprofv3 --pmc <group> --kernel-trace, one pass per counter group, over "
-               "`python bench.py --steps 1 --warmup 1 --no-cpu --adc-batches 1`; means per launch. FETCH_SIZE/WRITE_SIZE are "
+               "`python bench.py --steps 1 --warmup 1 --no-cpu --no-per-rank --adc-batches 1`; means per launch. FETCH_SIZE/WRITE_SIZE are "
                "KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md. " + note}
 for key, (kname, alg) in ALG.items():
     c = raw.get(kname)
@@ -30,6 +30,10 @@ for key, (kname, alg) in ALG.items():
     if "SQ_INSTS_VALU" in sq and "GRBM_GUI_ACTIVE" in sq:
         # GRBM_GUI_ACTIVE sums the 8 XCDs; a wave64 VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs
         e["valu_busy_frac"] = round(sq["SQ_INSTS_VALU"] * 4 / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
+    if sq.get("SQ_LDS_IDX_ACTIVE") and "GRBM_GUI_ACTIVE" in sq:
+        # SQ_LDS_IDX_ACTIVE: LDS-array cycles summed over the 256 CUs; SQ_LDS_BANK_CONFLICT: the share that are conflict cycles
+        e["lds_busy_frac"] = round(sq["SQ_LDS_IDX_ACTIVE"] / (sq["GRBM_GUI_ACTIVE"] / 8 * 256), 3)
+        e["lds_bank_conflict_frac"] = round(sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"], 3)
     if sq.get("SQ_VALU_MFMA_BUSY_CYCLES") and "GRBM_GUI_ACTIVE" in sq:
         # SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe cycles summed over the SIMDs (32 per 32x32x16 bf16 / 32x32x32 i8 MFMA)
         e["mfma_busy_frac"] = round(sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
