@@ -278,6 +278,22 @@ int rc_index_search(rc_index_t idx, const float* q, int nq, int k, float* scores
 size_t rc_ivf_coarse_assign_ws_bytes(int nlist);
 int rc_ivf_coarse_assign(rc_handle_t h, const float* x, int64_t ldx, const float* cent, int64_t B, int D, int nlist,
                          int* cell, void* ws, size_t ws_bytes, rc_stream_t stream);
+/* List-centric search of the same index (M in {16,32,48,64,96}): all queries probing a cell are split into groups of up
+ * to 8, one block per (cell, group) task runs the conflict-free 8-bit screen of the flat search over the cell's rows,
+ * survivors are re-scored exactly — results identical to rc_ivf_search.  image: rc_adc_scan_image of the cell-major codes.
+ * Per query: probes / sbase [nq,nprobe] (probed cells; position of each probe's first SAMPLED row — a cell of n rows is
+ * sampled in runs of 16 rows every 16 ss rows, 16 floor(n / 16 ss) + min(16, n mod 16 ss) entries — in the query's sample
+ * array of stride sstride), scount (sampled rows), rows (probed rows), rank (rank of the
+ * sample score used as threshold, 0 = keep every probed row).  Tasks: task_list / task_qstart / task_qcnt [ntasks] over
+ * sorted_q (query ids ordered by probed cell).  status bit0: a query kept fewer than min(k, rows) candidates (retry with
+ * larger ranks), bit1: a candidate list overflowed. */
+size_t rc_ivf_search_lists_ws_bytes(int M, int nq, int64_t sstride);
+int rc_ivf_search_lists(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
+                        const int64_t* rowmap, int64_t N, int M, int K, const float* lut, int nq, const int* probes,
+                        const int* sbase, const int* scount, const int* rows, const int* rank, int nprobe,
+                        int64_t sstride, int ss, const int* task_list, const int* task_qstart, const int* task_qcnt,
+                        const int* sorted_q, int ntasks, int k, float* scores, int64_t* out_ids, int* status, void* ws,
+                        size_t ws_bytes, rc_stream_t stream);
 size_t rc_ivf_search_ws_bytes(int nq, int64_t stride);
 int rc_ivf_search(rc_handle_t h, const uint8_t* codes, const int64_t* list_off, const int64_t* ids, int64_t N,
                   int M, int K, const float* lut, const int* probes, const int* base, const int* count, int nq,

@@ -889,12 +889,24 @@ typedef int adc_i32x4v __attribute__((ext_vector_type(4)));
 
 // grid (groups of 8 queries, row tiles of ADC_CF_TILE rows), XCD-remapped like the other screens.
 // A wave owns R chunks of 16 rows per round; lanes (r = l & 15, g = l >> 4).
-template <int M, int NP, int R>
+// IVF mode (list-centric scan of csrc/ivf_search.hip's index): a block is a TASK = (coarse cell, up to 8 of the queries that
+// probe it); its rows are the cell's row range, its byte tables are transposed on the fly from the per-query tables
+// (adc_qbyte_kernel), its thresholds are those of its queries.
+struct adc_ivf_tasks {
+    const int* task_list;        // [tasks] cell of the task
+    const int* task_qstart;      // [tasks] first entry of the task's queries in sorted_q
+    const int* task_qcnt;        // [tasks] 1 .. 8 queries
+    const int* sorted_q;         // query ids ordered by probed cell
+    const int64_t* list_off;     // [nlist + 1] row ranges of the cells
+    const uint8_t* qbyte;        // [nq][NP][256][SLOTS] per-query byte tables in slot layout
+};
+
+template <int M, int NP, int R, bool IVF = false>
 __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_t* __restrict__ image, int64_t N,
                                                                     const uint8_t* __restrict__ qlut,
                                                                     const int* __restrict__ tint, int nq,
                                                                     unsigned* __restrict__ id_count,
-                                                                    unsigned* __restrict__ ids) {
+                                                                    unsigned* __restrict__ ids, adc_ivf_tasks T) {
     constexpr int PM = M / NP;
     using L = adc_cf<PM>;
     constexpr int STEPS = L::STEPS, NW = STEPS * ADC_IMG_ES / 4;   // code dwords per lane per chunk and phase
@@ -903,24 +915,64 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_
     constexpr int ROUND = NWAVES * R * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    unsigned bgroup, btile;
-    adc_xcd_remap(bgroup, btile);
+    unsigned bgroup = 0, btile = 0;
+    if constexpr (!IVF) adc_xcd_remap(bgroup, btile);
     const int q0 = (int)bgroup * 8;
     const uint8_t* qsrc = qlut + (size_t)bgroup * NP * L::TABLE_BYTES;
+    // IVF: the task's queries (block-uniform scalars), -1 = empty slot
+    int tqid[8];
+    if constexpr (IVF) {
+        const int qs = T.task_qstart[blockIdx.x], qc = T.task_qcnt[blockIdx.x];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tqid[j] = (j < qc) ? T.sorted_q[qs + j] : -1;
+    }
     auto fill = [&](int phase) {
-        const uint4* src = reinterpret_cast<const uint4*>(qsrc + (size_t)phase * L::TABLE_BYTES);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int i = tid; i < L::TABLE_BYTES / 16; i += ADC_THREADS) {
-            uint4 v = src[i];
-            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;   // l -> l - 128 (signed)
-            dst[i] = v;
+        if constexpr (!IVF) {
+            const uint4* src = reinterpret_cast<const uint4*>(qsrc + (size_t)phase * L::TABLE_BYTES);
+            uint4* dst = reinterpret_cast<uint4*>(smem);
+            for (int i = tid; i < L::TABLE_BYTES / 16; i += ADC_THREADS) {
+                uint4 v = src[i];
+                v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;   // l -> l - 128 (signed)
+                dst[i] = v;
+            }
+        } else {
+            // byte transpose: dword i of each query's table holds the bytes of four consecutive (code, slot) entries;
+            // the LDS entry of one (code, slot) is the 8 queries' bytes side by side (two 4 x 4 byte transposes by v_perm)
+            constexpr int QB = RC_K * L::SLOTS;                 // bytes of one query's table phase
+            uint4* dst = reinterpret_cast<uint4*>(smem);
+            for (int i = tid; i < QB / 4; i += ADC_THREADS) {
+                unsigned d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    d[j] = tqid[j] >= 0 ? reinterpret_cast<const unsigned*>(T.qbyte + ((size_t)tqid[j] * NP + phase) * QB)[i] : 0u;
+                unsigned o[8];                                   // o[2 t] = queries 0-3 of entry t, o[2 t + 1] = queries 4-7
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    const unsigned a0 = d[4 * hq], a1 = d[4 * hq + 1], a2 = d[4 * hq + 2], a3 = d[4 * hq + 3];
+                    const unsigned t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+                    const unsigned u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+                    o[0 + hq] = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+                    o[2 + hq] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+                    o[4 + hq] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+                    o[6 + hq] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+                }
+                dst[2 * i] = make_uint4(o[0] ^ 0x80808080u, o[1] ^ 0x80808080u, o[2] ^ 0x80808080u, o[3] ^ 0x80808080u);
+                dst[2 * i + 1] = make_uint4(o[4] ^ 0x80808080u, o[5] ^ 0x80808080u, o[6] ^ 0x80808080u, o[7] ^ 0x80808080u);
+            }
         }
     };
     const int l = tid & 63, wv = tid >> 6;
     const int r = l & 15, g = l >> 4;
     int tq = INT_MAX;                                        // this lane's query = D column (l & 15)
-    if (r < 8 && q0 + r < nq) {
-        const int t = tint[q0 + r];
+    int myq = -1;                                            // ... and its id
+    if constexpr (IVF) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) myq = (r == j) ? tqid[j] : myq;
+    } else if (r < 8 && q0 + r < nq) {
+        myq = q0 + r;
+    }
+    if (myq >= 0) {
+        const int t = tint[myq];
         tq = (t == INT_MIN) ? INT_MIN : t - 128 * M;
     }
     adc_i32x4v bsel = {0, 0, 0, 0};                          // B[k][j = r] = [k % 8 == r], same bytes in every lane quarter
@@ -938,8 +990,17 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_
         // 32 bits are the LDS address), so the gather address below needs no further base add
         off[s] = (unsigned)slot * 8u + static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     }
-    const int64_t t0 = (int64_t)btile * ADC_CF_TILE;
-    const int64_t t1 = (t0 + ADC_CF_TILE < N) ? t0 + ADC_CF_TILE : N;
+    int64_t t0 = (int64_t)btile * ADC_CF_TILE;
+    int64_t t1 = (t0 + ADC_CF_TILE < N) ? t0 + ADC_CF_TILE : N;
+    unsigned row_lo = 0;                                      // rows of the tile before this are not the task's
+    if constexpr (IVF) {
+        const int cell = T.task_list[blockIdx.x];
+        const int64_t a = T.list_off[cell];
+        t1 = T.list_off[cell + 1];
+        t0 = a & ~(int64_t)15;                                // chunks start on multiples of 16 rows: the image's permutation
+        row_lo = (unsigned)(a - t0);                          // depends on the ABSOLUTE row index mod 16
+        if (t1 <= a) return;                                  // empty cell (block-uniform)
+    }
     // Flat sequence of steps it = round * NP + i; a round covers ROUND rows and visits the NP table phases, odd rounds in
     // reverse order, so the tables already in LDS are used first (NP - 1 refills per round).  The codes of step it + 1 are
     // loaded while step it is gathered (NP == 1; with two phases the eight chunks' codes are loaded at the start of the
@@ -1034,9 +1095,9 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const unsigned n = r0 + 16u * c + 4u * g + e;   // D[row = 4 g + e][column = r]
-                        if (acc[c][e] >= tq && n < nrows) {
-                            const unsigned slot = atomicAdd(id_count + q0 + r, 1u);
-                            if (slot < ADC_ID_CAP) ids[(size_t)(q0 + r) * ADC_ID_CAP + slot] = (unsigned)(t0 + n);
+                        if (acc[c][e] >= tq && n < nrows && n >= row_lo) {
+                            const unsigned slot = atomicAdd(id_count + myq, 1u);
+                            if (slot < ADC_ID_CAP) ids[(size_t)myq * ADC_ID_CAP + slot] = (unsigned)(t0 + n);
                         }
                     }
                 }
@@ -1067,7 +1128,8 @@ __global__ __launch_bounds__(256) void adc_rescore_kernel(const uint8_t* __restr
                                                           const unsigned* __restrict__ ids,
                                                           unsigned* __restrict__ cand_count,
                                                           unsigned long long* __restrict__ cand,
-                                                          int* __restrict__ status) {
+                                                          int* __restrict__ status,
+                                                          const int64_t* __restrict__ rowmap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tab = reinterpret_cast<float*>(smem);  // [M][256]
     const int qi = blockIdx.x, tid = threadIdx.x;
@@ -1098,9 +1160,12 @@ __global__ __launch_bounds__(256) void adc_rescore_kernel(const uint8_t* __restr
             if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(cand_count + qi, (unsigned)__popcll(mask));
             base = __shfl(base, (int)__builtin_ctzll(mask));
             const unsigned slot = base + rank;
-            if (pass && slot < ADC_CAND_CAP)
+            if (pass && slot < ADC_CAND_CAP) {
+                // IVF: rows are stored cell-major; the key carries the row's corpus position so ties order by corpus id
+                const unsigned id = rowmap ? (unsigned)rowmap[n] : n;
                 cand[(size_t)qi * ADC_CAND_CAP + slot] =
-                    ((unsigned long long)adc_order_key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - n);
+                    ((unsigned long long)adc_order_key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - id);
+            }
         }
     }
 }
@@ -1261,7 +1326,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             const unsigned cf_tiles = (unsigned)((N + ADC_CF_TILE - 1) / ADC_CF_TILE);
             hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 7) / 8), cf_tiles), dim3(ADC_THREADS), sl, s, image, N, b.qlut,
-                               b.tint, nq, b.idcnt, b.ids);
+                               b.tint, nq, b.idcnt, b.ids, adc_ivf_tasks{});
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             RC_LAUNCH_CHECK(h);
         }
@@ -1288,7 +1353,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
     const size_t rl = (size_t)M * RC_K * sizeof(float);
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
     hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(256), rl, s, codes, b.lut, b.thr, b.idcnt, b.ids, b.cnt, b.cand,
-                       status);
+                       status, (const int64_t*)nullptr);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
@@ -1394,4 +1459,291 @@ extern "C" int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint
     if (rc != RC_OK) return rc;
     (void)adc_qt_for;
     return rc_adc_launch_select(h, cand, cnt, nq, N, k, id_offset, scores, ids, status, s);
+}
+
+// =============================================================================================== IVF, list-centric
+// Search of the cell-major IVF index (csrc/ivf_search.hip; a build-side extension, the reference has one list) with the
+// machinery of the flat search.  Round 1 scanned every probed cell once per query (one block per query slice, fp32
+// tables, dense score write-out + radix select over it).  Here the work is organised by CELL: all queries probing a cell
+// are split into groups of up to 8, one block per (cell, group) TASK runs the conflict-free 8-bit screen over the cell's
+// rows — 8 queries share every gather, the cell's codes are read once per group — and the survivors are re-scored
+// exactly and selected like in the flat search:
+//   1. adc_lut                     fp32 tables of every query (caller)
+//   2. ivf_sample_scan_kernel      exact scores of every SS-th row of the query's probed cells -> sample[q][..]
+//   3. ivf_rank_select_kernel      tau_q = rank_q-th largest sample score (rank 0: -inf, every probed row is a candidate)
+//   4. adc_qbyte_kernel            per query: 8-bit tables in slot layout + integer threshold (as adc_qlut_cf_kernel)
+//   5. adc_screen_cf_kernel<IVF>   per task: transpose the 8 queries' byte tables into LDS, screen the cell's rows
+//   6. adc_rescore_kernel          exact fp32 score of the survivors, keys carry the corpus position of the row
+//   7. adc_select_kernel           top-k, (score desc, corpus id asc) — the tie rule of the flat search
+// The host builds the task list (cells sorted, 8 queries per task) and the sample ranks; status bit0 = a query kept
+// fewer than min(k, rows probed) candidates (retry with more slack), bit1 = a list overflowed (less slack).
+
+// grid (nq, slices): the query's sample entries 0 .. scount[qi] are dealt to the threads of its blocks; an entry finds its
+// cell by binary search over the query's sbase row (no per-cell loop: a probed cell contributes only a few dozen sampled
+// rows, and walking the cells one after the other would serialise two dependent loads per cell).
+template <int M>
+__global__ __launch_bounds__(256) void ivf_sample_scan_kernel(const uint8_t* __restrict__ codes,
+                                                              const int64_t* __restrict__ list_off,
+                                                              const float* __restrict__ lut, const int* __restrict__ probes,
+                                                              const int* __restrict__ sbase, const int* __restrict__ scount,
+                                                              int nprobe, int64_t sstride, int ss,
+                                                              float* __restrict__ sample) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tab = reinterpret_cast<float*>(smem);   // [M][256]
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < M * RC_K; i += 256) tab[i] = lut[(size_t)qi * M * RC_K + i];
+    __syncthreads();
+    const int n = scount[qi];
+    const int* sb = sbase + (size_t)qi * nprobe;
+    const int* pr = probes + (size_t)qi * nprobe;
+    for (int i = blockIdx.y * 256 + tid; i < n; i += gridDim.y * 256) {
+        int lo = 0, hi = nprobe - 1;                              // last probe p with sbase[p] <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sb[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const int off = i - sb[lo];
+        // the sample of a cell: runs of 16 consecutive rows (coalesced reads), one run every 16 * ss rows
+        const int64_t row = list_off[pr[lo]] + (int64_t)(off >> 4) * 16 * ss + (off & 15);
+        const unsigned* cp = reinterpret_cast<const unsigned*>(codes + row * M);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < M / 4; ++j) {
+            const unsigned w = cp[j];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s = s + tab[(4 * j + b) * RC_K + ((w >> (8 * b)) & 0xFFu)];
+        }
+        sample[(size_t)qi * sstride + i] = s;
+    }
+}
+
+// thr[qi] = rank[qi]-th largest of sample[qi][0 .. scount[qi]); rank <= 0 or > scount: -inf.  One block per query,
+// 8 bits per pass over global memory (the sample is 1/SS of the probed rows).
+__global__ __launch_bounds__(1024) void ivf_rank_select_kernel(const float* __restrict__ sample, const int* __restrict__ scount,
+                                                               const int* __restrict__ rank, int64_t sstride,
+                                                               float* __restrict__ thr) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_rank;
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    const int n = scount[qi], k = rank[qi];
+    if (k <= 0 || k > n) {
+        if (tid == 0) thr[qi] = -INFINITY;
+        return;
+    }
+    const float* row = sample + (size_t)qi * sstride;
+    if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)k; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = sel_prefix;
+        const unsigned himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned key = adc_order_key(row[i]);
+            if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned need = sel_rank, b = 255;
+            for (;; --b) {
+                if (hist[b] >= need) break;
+                need -= hist[b];
+                if (b == 0) break;
+            }
+            sel_prefix = prefix | (b << shift);
+            sel_rank = need;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) thr[qi] = adc_unorder_key(sel_prefix);
+}
+
+// Per query: the 8-bit tables of adc_qlut_cf_kernel, but one table per QUERY in slot layout [phase][code][slot] (one byte
+// per entry, both copies of a 16-block filled), plus the integer threshold.  The screen transposes 8 of them into LDS.
+__global__ __launch_bounds__(RC_K) void adc_qbyte_kernel(const float* __restrict__ lut, const float* __restrict__ thr, int M,
+                                                         int PM, int slots, uint8_t* __restrict__ qbyte,
+                                                         int* __restrict__ tint) {
+    __shared__ float lo_m[128];
+    __shared__ float red_lo[4], red_hi[4];
+    __shared__ float s_delta;
+    const int qi = blockIdx.x, c = threadIdx.x;
+    const float* lq = lut + (size_t)qi * M * RC_K;
+    float maxrange = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float v = lq[m * RC_K + c];
+        float lo = v, hi = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if ((c & 63) == 0) { red_lo[c >> 6] = lo; red_hi[c >> 6] = hi; }
+        __syncthreads();
+        lo = fminf(fminf(red_lo[0], red_lo[1]), fminf(red_lo[2], red_lo[3]));
+        hi = fmaxf(fmaxf(red_hi[0], red_hi[1]), fmaxf(red_hi[2], red_hi[3]));
+        if (c == 0) lo_m[m] = lo;
+        maxrange = fmaxf(maxrange, hi - lo);
+        __syncthreads();
+    }
+    if (c == 0) {
+        float delta = maxrange / 255.0f;
+        if (!(delta > 0.f)) delta = 1.0f;
+        s_delta = delta;
+        double A = 0.0;
+        for (int m = 0; m < M; ++m) A += (double)lo_m[m];
+        const float t = thr[qi];
+        int T;
+        if (t == -INFINITY) {
+            T = INT_MIN;
+        } else {
+            const double v = ceil(((double)t - A) / (double)delta) - (double)(M + 2);
+            T = v < -2.0e9 ? INT_MIN : (v > 2.0e9 ? INT_MAX : (int)v);
+        }
+        tint[qi] = T;
+    }
+    __syncthreads();
+    const float delta = s_delta;
+    const int NP = M / PM, n32 = PM / 32;
+    uint8_t* dst = qbyte + (size_t)qi * NP * RC_K * slots;
+    for (int m = 0; m < M; ++m) {
+        const float v = (lq[m * RC_K + c] - lo_m[m]) / delta;
+        int l = (int)floorf(v);
+        l = l < 0 ? 0 : (l > 255 ? 255 : l);
+        const int phase = m / PM, mp = m % PM;
+        uint8_t* row = dst + ((size_t)phase * RC_K + c) * slots;
+        row[mp] = (uint8_t)l;
+        if (mp >= 32 * n32) row[mp + 16] = (uint8_t)l;            // second copy of the 16-block
+    }
+}
+
+__global__ void ivf_check_kernel(const unsigned* __restrict__ cand_count, const int* __restrict__ rows, int nq, int k,
+                                 int* __restrict__ status) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    const int want = rows[qi] < k ? rows[qi] : k;
+    if ((int)cand_count[qi] < want) atomicOr(status, 1);
+}
+
+namespace {
+struct ivfl_ws {
+    size_t sample, thr, tint, qbyte, idcnt, ids, cnt, cand, total;
+};
+ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
+    ivfl_ws L;
+    size_t o = 0;
+    L.sample = o; o += rc_align_up((size_t)nq * (size_t)sstride * sizeof(float), 256);
+    L.thr = o;    o += rc_align_up((size_t)nq * sizeof(float), 256);
+    L.tint = o;   o += rc_align_up((size_t)nq * sizeof(int), 256);
+    L.qbyte = o;  o += rc_align_up((size_t)nq * (adc_cf_table_bytes(M) / 8), 256);
+    L.idcnt = o;  o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
+    L.ids = o;    o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
+    L.cnt = o;    o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
+    L.cand = o;   o += rc_align_up((size_t)nq * ADC_CAND_CAP * sizeof(unsigned long long), 256);
+    L.total = o;
+    return L;
+}
+
+template <int M>
+int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off, const int64_t* rowmap,
+                int64_t N, const float* lut, int nq, const int* probes, const int* sbase, const int* scount,
+                const int* rows, const int* rank, int nprobe, int64_t sstride, int ss, const adc_ivf_tasks& T, int ntasks,
+                int k, float* scores, int64_t* out_ids, int* status, char* w, const ivfl_ws& L, hipStream_t s) {
+    constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP;
+    constexpr int R = (NP == 2) ? 8 : (M == 64 ? 2 : 4);
+    float* sample = (float*)(w + L.sample);
+    float* thr = (float*)(w + L.thr);
+    int* tint = (int*)(w + L.tint);
+    uint8_t* qbyte = (uint8_t*)(w + L.qbyte);
+    unsigned* idcnt = (unsigned*)(w + L.idcnt);
+    unsigned* ids = (unsigned*)(w + L.ids);
+    unsigned* cnt = (unsigned*)(w + L.cnt);
+    unsigned long long* cand = (unsigned long long*)(w + L.cand);
+    {
+        auto kern = ivf_sample_scan_kernel<M>;
+        const size_t lds = (size_t)M * RC_K * sizeof(float);
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // every block stages the query's 4 M 256-byte fp32 table: as few slices per query as keep ~2048 sampled rows each
+        int64_t slices = (sstride + 2047) / 2048;
+        if (slices > 16) slices = 16;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nq, (unsigned)(slices < 1 ? 1 : slices)), dim3(256), lds, s, codes, list_off, lut,
+                           probes, sbase, scount, nprobe, sstride, ss, sample);
+        RC_LAUNCH_CHECK(h);
+    }
+    hipLaunchKernelGGL(ivf_rank_select_kernel, dim3((unsigned)nq), dim3(1024), 0, s, (const float*)sample, scount, rank, sstride, thr);
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(adc_qbyte_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)thr, M, PM, adc_cf<PM>::SLOTS,
+                       qbyte, tint);
+    RC_LAUNCH_CHECK(h);
+    RC_HIP_CHECK(h, hipMemsetAsync(idcnt, 0, (size_t)nq * sizeof(unsigned), s));
+    RC_HIP_CHECK(h, hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(unsigned), s));
+    {
+        auto kern = adc_screen_cf_kernel<M, NP, R, true>;
+        constexpr int sl = adc_cf<PM>::TABLE_BYTES;
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+        adc_ivf_tasks TT = T;
+        TT.qbyte = qbyte;
+        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+        hipLaunchKernelGGL(kern, dim3((unsigned)ntasks), dim3(ADC_THREADS), sl, s, image, N, (const uint8_t*)nullptr,
+                           (const int*)tint, nq, idcnt, ids, TT);
+        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+        RC_LAUNCH_CHECK(h);
+    }
+    {
+        auto krescore = adc_rescore_kernel<M>;
+        const size_t rl = (size_t)M * RC_K * sizeof(float);
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+        hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(256), rl, s, codes, lut, (const float*)thr, (const unsigned*)idcnt,
+                           (const unsigned*)ids, cnt, cand, status, rowmap);
+        RC_LAUNCH_CHECK(h);
+    }
+    hipLaunchKernelGGL(ivf_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const unsigned*)cnt, rows, nq, k, status);
+    RC_LAUNCH_CHECK(h);
+    // N = 0: fewer than k rows is legitimate (small cells); too FEW CANDIDATES is what ivf_check_kernel reports
+    return rc_adc_launch_select(h, cand, cnt, nq, 0, k, 0, scores, out_ids, status, s);
+}
+}  // namespace
+
+extern "C" size_t rc_ivf_search_lists_ws_bytes(int M, int nq, int64_t sstride) {
+    if (!adc_cf_supported(M) || nq <= 0 || sstride <= 0) return 0;
+    return ivfl_layout(M, nq, sstride).total;
+}
+
+// codes / image: [N,M] cell-major canonical codes and their permuted image; list_off [nlist+1]; rowmap [N] corpus position
+// of every row; lut [nq,M,256] (rc_adc_lut); probes / sbase [nq,nprobe]: probed cells and the position of each probe's
+// first SAMPLED row in the query's sample array (a cell of n rows is sampled in runs of 16 rows every 16 ss rows:
+// 16 floor(n / (16 ss)) + min(16, n mod (16 ss)) entries);
+// scount [nq] sampled rows, rows [nq] probed rows, rank [nq] rank of the sample score used as threshold (0: keep all);
+// tasks: task_list / task_qstart / task_qcnt [ntasks] and sorted_q (query ids ordered by probed cell).
+extern "C" int rc_ivf_search_lists(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
+                                   const int64_t* rowmap, int64_t N, int M, int K, const float* lut, int nq,
+                                   const int* probes, const int* sbase, const int* scount, const int* rows, const int* rank,
+                                   int nprobe, int64_t sstride, int ss, const int* task_list, const int* task_qstart,
+                                   const int* task_qcnt, const int* sorted_q, int ntasks, int k, float* scores,
+                                   int64_t* out_ids, int* status, void* ws, size_t ws_bytes, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !codes || !image || !list_off || !rowmap || !lut || !probes || !sbase || !scount || !rows || !rank ||
+        !task_list || !task_qstart || !task_qcnt || !sorted_q || !scores || !out_ids || !status || N <= 0 || nq < 0 ||
+        nprobe <= 0 || sstride <= 0 || ss <= 0 || ntasks < 0 || k <= 0)
+        return RC_EINVAL;
+    if (K != RC_K || !adc_cf_supported(M) || k > ADC_CAND_CAP / 2 || N > 0xFFFFFFFFll || RC_ADC_IMG16) return RC_ESHAPE;
+    if (nq == 0) return RC_OK;
+    const ivfl_ws L = ivfl_layout(M, nq, sstride);
+    if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
+    adc_ivf_tasks T = {task_list, task_qstart, task_qcnt, sorted_q, list_off, nullptr};
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)ws;
+    if (ntasks == 0) {                                        // nothing probed: empty results through the select kernel
+        RC_HIP_CHECK(h, hipMemsetAsync(w + L.cnt, 0, (size_t)nq * sizeof(unsigned), s));
+        return rc_adc_launch_select(h, (unsigned long long*)(w + L.cand), (const unsigned*)(w + L.cnt), nq, 0, k, 0, scores,
+                                    out_ids, status, s);
+    }
+    switch (M) {
+#define IVFL_CASE(MM)                                                                                                   \
+        case MM: return ivfl_launch<MM>(h, codes, image, list_off, rowmap, N, lut, nq, probes, sbase, scount, rows, rank, \
+                                        nprobe, sstride, ss, T, ntasks, k, scores, out_ids, status, w, L, s);
+        IVFL_CASE(16) IVFL_CASE(32) IVFL_CASE(48) IVFL_CASE(64) IVFL_CASE(96)
+#undef IVFL_CASE
+        default: return RC_ESHAPE;
+    }
 }

@@ -35,9 +35,10 @@ def main() -> int:
     os.environ["RC_DIST_NATIVE"] = "0"
     staged, _ = assign_sinkhorn_sharded(xl, C, 0.003, 100, comm, dtype=torch.uint8)
     os.environ["RC_DIST_NATIVE"] = "1"
-    native, _ = assign_sinkhorn_sharded(xl, C, 0.003, 100, comm, dtype=torch.uint8)
+    native, _ = assign_sinkhorn_sharded(xl, C, 0.003, 100, comm, dtype=torch.uint8)       # captures the iteration graph
+    replay, _ = assign_sinkhorn_sharded(xl, C, 0.003, 100, comm, dtype=torch.uint8)       # replays it (same workspace block)
     torch.cuda.synchronize()
-    ok = torch.tensor([int(torch.equal(staged, native))], dtype=torch.int32, device=dev)
+    ok = torch.tensor([int(torch.equal(staged, native) and torch.equal(staged, replay))], dtype=torch.int32, device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     return 0 if int(ok.item()) == 1 else 1

@@ -69,6 +69,7 @@ class IVFPQIndex:
         self.pq_centroids = torch.zeros((M, 256, d // M), dtype=torch.float32, device=self.device)
         self.codes = torch.empty((0, M), dtype=torch.uint8, device=self.device)
         self.ids = torch.empty((0,), dtype=torch.int64, device=self.device)
+        self.image = None            # permuted copy of `codes` for the conflict-free screen (list-centric search)
         self.list_off = torch.zeros((nlist + 1,), dtype=torch.int64, device=self.device)
         self.ntotal = 0
 
@@ -91,6 +92,10 @@ class IVFPQIndex:
         cnt = torch.bincount(list_ids, minlength=self.nlist)
         self.list_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=self.device), torch.cumsum(cnt, 0)]).contiguous()
         self.ntotal = codes.shape[0]
+        self.image = None
+        if ops.adc_image_supported(self.M) and self.ntotal:
+            self.image = torch.empty((self.ntotal, ops.adc_image_row_bytes(self.M)), dtype=torch.uint8, device=self.device)
+            ops.adc_scan_image_(self.codes, self.image)
 
     def add(self, x, codes: Optional[torch.Tensor] = None):
         """Index (rotated) embeddings x [N,d]: nearest PQ codes (unless the model's `codes` are given) + coarse cell."""
@@ -120,16 +125,37 @@ class IVFPQIndex:
     def probe(self, q: torch.Tensor, nprobe: int) -> torch.Tensor:
         """[nq, nprobe] cells by decreasing <q, centroid> (ties: lower cell id), int32."""
         s = q.float() @ self.coarse.T
-        order = torch.argsort(s, dim=1, descending=True, stable=True)[:, :nprobe]
+        if nprobe * 4 <= self.nlist:
+            # select first, then order the selected cells by (score desc, cell asc): a full stable sort of nlist scores
+            # per query costs more than the search itself at small nprobe
+            top = torch.topk(s, nprobe, dim=1, sorted=False).indices
+            top = torch.sort(top, dim=1).values
+            sel = torch.gather(s, 1, top)
+            order = torch.gather(top, 1, torch.argsort(sel, dim=1, descending=True, stable=True))
+        else:
+            order = torch.argsort(s, dim=1, descending=True, stable=True)[:, :nprobe]
         return order.to(torch.int32).contiguous()
 
-    def search(self, x, k: int, nprobe: int):
+    def search(self, x, k: int, nprobe: int, method: str = "auto"):
+        """method: "lists" = list-centric 8-bit screen (rc_ivf_search_lists: the queries probing a cell share its read,
+        M in {16,32,48,64,96}); "scan" = the per-query exact scan (rc_ivf_search); "auto" = lists where available.
+        Both return the same (scores, ids)."""
         as_numpy = not isinstance(x, torch.Tensor)
         q = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if as_numpy else x).to(self.device, torch.float32)
         q = q.contiguous()
         nq = q.shape[0]
         nprobe = min(int(nprobe), self.nlist)
         probes = self.probe(q, nprobe)
+        if method not in ("auto", "lists", "scan"):
+            raise ValueError("method must be auto|lists|scan")
+        if method == "lists" and self.image is None:
+            raise _lib.RepconcHipError(f"the list-centric search needs M in (16, 32, 48, 64, 96), not {self.M}")
+        if method == "auto" and self.image is not None:
+            # few probed rows per query: the per-query scan has less fixed work (task list, per-query byte tables)
+            method = "lists" if self.ntotal * nprobe / max(self.nlist, 1) >= self.LISTS_MIN_ROWS else "scan"
+        if method == "lists" and nq > 0:
+            scores, ids = self._search_lists(q, probes, int(k), nprobe)
+            return (scores.cpu().numpy(), ids.cpu().numpy()) if as_numpy else (scores, ids)
         sizes = (self.list_off[1:] - self.list_off[:-1])[probes.long()]                      # [nq, nprobe]
         csum = torch.cumsum(sizes, 1)
         base = (csum - sizes).to(torch.int32).contiguous()
@@ -153,3 +179,71 @@ class IVFPQIndex:
         if as_numpy:
             return scores.cpu().numpy(), ids.cpu().numpy()
         return scores, ids
+
+    # ---- list-centric search
+    SAMPLE_STEP = 8                 # every 8th (up to every 64th) row of a probed cell is scored exactly ...
+    SAMPLE_ROWS = 6144              # ... so that about this many sampled rows per query place the candidate threshold
+    CAND_CAP = 16384                # candidate keys per query (ADC_CAND_CAP)
+    KEEP_ALL_ROWS = 4096            # queries probing no more rows than this re-score every row (no threshold)
+    LISTS_MIN_ROWS = 32768          # "auto": average probed rows per query from which the list-centric search pays
+
+    def _search_lists(self, q: torch.Tensor, probes: torch.Tensor, k: int, nprobe: int, sel_slack: float = 6.0,
+                      max_retries: int = 3):
+        dev, nq = self.device, q.shape[0]
+        pl = probes.long()
+        sizes = (self.list_off[1:] - self.list_off[:-1])[pl]                                   # [nq, nprobe]
+        rows = sizes.sum(1)
+        # sample step: about SAMPLE_ROWS exactly scored rows per query place the candidate threshold
+        ss = self.SAMPLE_STEP
+        while ss < 64 and self.ntotal * nprobe / max(self.nlist, 1) / (2 * ss) >= self.SAMPLE_ROWS:
+            ss *= 2
+        ssz = 16 * (sizes // (16 * ss)) + torch.clamp(sizes % (16 * ss), max=16)               # sampled rows per probe (runs of 16)
+        scs = torch.cumsum(ssz, 1)
+        sbase = (scs - ssz).to(torch.int32).contiguous()
+        scount = scs[:, -1]
+        # tasks: (cell, <= 8 of the queries probing it); bookkeeping on [nq * nprobe] pairs
+        flat_cell = pl.reshape(-1)
+        order = torch.argsort(flat_cell, stable=True)
+        sorted_q = (order // nprobe).to(torch.int32).contiguous()
+        per_cell = torch.bincount(flat_cell, minlength=self.nlist)
+        cell_start = torch.cumsum(per_cell, 0) - per_cell
+        tasks_per_cell = (per_cell + 7) // 8
+        ntasks = int(tasks_per_cell.sum().item())
+        task_cell = torch.repeat_interleave(torch.arange(self.nlist, device=dev), tasks_per_cell)
+        first_task = torch.cumsum(tasks_per_cell, 0) - tasks_per_cell
+        within = torch.arange(ntasks, device=dev) - first_task[task_cell]
+        task_qstart = (cell_start[task_cell] + 8 * within).to(torch.int32).contiguous()
+        task_qcnt = torch.clamp(per_cell[task_cell] - 8 * within, max=8).to(torch.int32).contiguous()
+        task_list = task_cell.to(torch.int32).contiguous()
+        sstride = max(4, int(scount.max().item()))
+        lut = ops.adc_lut(self.pq_centroids, q)
+        lib, h = _lib.load(), _lib.handle(dev.index)
+        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        wsb = lib.rc_ivf_search_lists_ws_bytes(self.M, nq, sstride)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        rows32, scount32 = rows.to(torch.int32).contiguous(), scount.to(torch.int32).contiguous()
+        p = lambda t: C.c_void_p(t.data_ptr())
+        slack = float(sel_slack)
+        for _ in range(max_retries + 1):
+            # rank of the sample score used as threshold: mu = expected number of the k best among the sampled rows;
+            # queries whose probed rows fit the candidate list keep every row (rank 0 -> threshold -inf)
+            mu = k * scount.double() / rows.clamp_min(1).double()
+            rank = (mu + slack * torch.sqrt(mu + 1.0) + 4.0).floor() + 1
+            cap = (0.8 * self.CAND_CAP * scount.double() / rows.clamp_min(1).double()).floor()
+            rank = torch.where((rank > cap) & (cap >= mu + 2.5 * torch.sqrt(mu + 1.0) + 2.0), cap, rank)
+            rank = torch.where(rows <= self.KEEP_ALL_ROWS, torch.zeros_like(rank), torch.minimum(rank, scount.double()))
+            rank32 = rank.to(torch.int32).contiguous()
+            status.zero_()
+            _lib.check(lib.rc_ivf_search_lists(h, p(self.codes), p(self.image), p(self.list_off), p(self.ids), self.ntotal,
+                                               self.M, 256, p(lut), nq, p(probes), p(sbase), p(scount32), p(rows32), p(rank32),
+                                               nprobe, sstride, ss, p(task_list), p(task_qstart), p(task_qcnt), p(sorted_q),
+                                               ntasks, k, p(scores), p(ids), p(status), p(ws), wsb, s),
+                       "rc_ivf_search_lists", h)
+            st = int(status.item())
+            if st == 0:
+                return scores, ids
+            slack = slack * 3.0 + 2.0 if (st & 1) else max(slack / 3.0, 0.0)
+        raise _lib.RepconcHipError(f"IVF candidate selection did not converge (status {st})")

@@ -621,14 +621,17 @@ def test_ivf_extension_exact_and_equals_flat_when_all_lists_probed():
     flat.add_codes(codes)
     for k in (10, 200):
         fs, fi = flat.search(_t(q), k)
-        s, i = ivf.search(_t(q), k, nprobe=nlist)
-        assert torch.equal(i, fi) and torch.equal(s, fs)                         # (a)
+        for method in ("lists", "scan"):
+            s, i = ivf.search(_t(q), k, nprobe=nlist, method=method)
+            assert torch.equal(i, fi) and torch.equal(s, fs), method             # (a)
     recalls = []
     for nprobe in (1, 4, 16):
         s, i = ivf.search(q, 10, nprobe)
         ws, wi = pq_oracle.ivf_search(q, C, codes.cpu().numpy(), list_ids.cpu().numpy(), ivf.coarse.cpu().numpy(), 10, nprobe)
         assert np.array_equal(i, wi)                                             # (b)
         assert np.array_equal(s.view(np.uint32), ws.view(np.uint32))
+        s_, i_ = ivf.search(q, 10, nprobe, method="scan")
+        assert np.array_equal(i_, wi) and np.array_equal(s_.view(np.uint32), ws.view(np.uint32))
         fi10 = flat.search(q, 10)[1]
         recalls.append(np.mean([len(set(i[r]) & set(fi10[r])) / 10 for r in range(nq)]))
     assert recalls[0] <= recalls[1] <= recalls[2] and recalls[2] > 0.8          # (c)
@@ -1418,11 +1421,12 @@ def test_ivf_m96_nlist5000_against_the_oracle():
     d = torch.cdist(xs, cs) ** 2
     assert float((d.gather(1, list_ids[:2000, None])[:, 0] <= d.min(1).values * (1 + 1e-5) + 1e-4).float().mean()) == 1.0   # (c)
     cn, ln, co = codes.cpu().numpy(), list_ids.cpu().numpy(), ivf.coarse.cpu().numpy()
-    for nprobe, k in ((1, 10), (16, 100), (128, 1000)):
-        s, i = ivf.search(q, k, nprobe)
+    for nprobe, k in ((1, 10), (16, 100), (128, 1000), (700, 1000)):
         ws, wi = pq_oracle.ivf_search(q, C, cn, ln, co, k, nprobe)
-        assert np.array_equal(i, wi), nprobe                                       # (a)
-        assert np.array_equal(s.view(np.uint32), ws.view(np.uint32))
+        for method in ("lists", "scan"):                                           # list-centric screen / per-query scan
+            s, i = ivf.search(q, k, nprobe, method=method)
+            assert np.array_equal(i, wi), (nprobe, method)                         # (a)
+            assert np.array_equal(s.view(np.uint32), ws.view(np.uint32)), (nprobe, method)
     flat = PQIndex(768, M, device=DEV)
     flat.set_centroids(C)
     flat.add_codes(codes)
@@ -1481,3 +1485,25 @@ def test_kmeans_statistics_are_deterministic_and_match_the_oracle():
         s3, c3 = ops.kmeans_stats(xt, ct, s1.clone(), c1.clone())                    # accumulates
         np.testing.assert_allclose(s3.cpu().numpy(), 2 * ws, rtol=1e-12, atol=1e-9)
         assert np.array_equal(c3.cpu().numpy(), 2 * wc)
+
+
+@pytest.mark.parametrize("M", [16, 32, 48, 64])
+def test_ivf_list_centric_search_equals_per_query_scan(M):
+    """rc_ivf_search_lists (cells scanned once per group of up to 8 probing queries, 8-bit screen + exact rescoring) against
+    rc_ivf_search (per-query exact scan) on skewed cells (a few very large ones: thresholds from the sample; many tiny or
+    empty ones: every row a candidate), for every M the screen supports in one table phase."""
+    from repconc_amd.ivf import IVFPQIndex
+    N, nlist, nq = 400000, 300, 37
+    rng = np.random.default_rng(700 + M)
+    codes = synth.uniform_codes(701 + M, N, M)
+    cells = np.minimum((rng.pareto(1.2, N) * 3).astype(np.int64), nlist - 1)      # cell 0..: heavy head, empty tail cells
+    C = synth.gaussian(702 + M, (M, 256, 768 // M))
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(C)
+    ivf.coarse = _t(synth.gaussian(703 + M, (nlist, 768)))
+    ivf.set_lists(_t(codes), _t(cells))
+    q = _t(synth.gaussian(704 + M, (nq, 768)))
+    for nprobe, k in ((3, 10), (40, 1000), (nlist, 200)):
+        s1, i1 = ivf.search(q, k, nprobe, method="lists")
+        s2, i2 = ivf.search(q, k, nprobe, method="scan")
+        assert torch.equal(i1, i2) and torch.equal(s1, s2), (M, nprobe)
