@@ -198,12 +198,14 @@ def main():
         codes, flags = step(i)
     barrier()
     import ctypes
-    # N = 1: every sweep launch of the timed region is bracketed by HIP events (rc_profile_*; the event marks select
-    # the eager launch loop).  N > 1: the timed region runs the product default — sweeps t >= 2 and their all-gathers
-    # replayed from the captured hipGraph — and the per-launch kernel time comes from ONE extra, untimed, profiled step.
+    # The timed region runs the product default: sweeps t >= 2 (and, N > 1, their all-gathers) replayed from the captured
+    # hipGraph.  N = 1: each step's run of T - 2 = 98 sweep launches is bracketed by ONE pair of HIP events on the launch
+    # stream (rc_profile_enable(h, 2)): avg_launch_ms = bracket time / 98, the ~1.5 us gaps between launches included.
+    # N > 1 (two chains on two streams overlap): the per-launch time comes from ONE extra, untimed step with an event
+    # pair around every launch (eager loop).
     profile_timed = not use_dist
     if profile_timed:
-        lib.rc_profile_enable(h, 1)
+        lib.rc_profile_enable(h, 2)
     t0 = time.perf_counter()
     for i in range(args.steps):
         codes, flags = step(args.warmup + i)
@@ -229,7 +231,8 @@ def main():
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if n_l.value else 0.0
     roofline = {"kernel": "sk_sweep2_kernel<2, true> (Sinkhorn sweep t >= 1 incl. fused row-potential update and integer "
                           "column exponents; potentials from LDS, 4 blocks per CU, one equal column range per block)",
-                "measured_in": "timed region, HIP events around every launch" if profile_timed else
+                "measured_in": "timed region: one HIP-event pair around each step's 98 back-to-back sweep launches (t >= 2, "
+                               "replayed from the hipGraph), divided by 98 - inter-launch gaps included" if profile_timed else
                                "one extra profiled step after the timed region (the timed region replays the hipGraph)",
                 "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -269,7 +272,7 @@ def main():
         for _ in range(2):
             ops.assign_sinkhorn(xr, C, EPS, ITERS, torch.uint8)
         torch.cuda.synchronize()
-        lib.rc_profile_enable(h, 1)
+        lib.rc_profile_enable(h, 2)
         t0 = time.perf_counter()
         nrep = 10
         for _ in range(nrep):

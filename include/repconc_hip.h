@@ -67,7 +67,10 @@ int rc_num_cus(rc_handle_t h);
  * on the launch stream.  rc_profile_collect() waits for the recorded events of one kernel class,
  * returns the number of launches and the summed device time in milliseconds, and clears them.
  * Classes: 0 = Sinkhorn sweep (sk_sweep_kernel, t >= 1), 1 = ADC filter scan, 2 = nearest assignment,
- * 3 = distance table.  bench.py's `roofline.achieved` comes from this. */
+ * 3 = distance table.  bench.py's `roofline.achieved` comes from this.
+ * on = 1: one event pair per launch (the Sinkhorn solve then runs its eager launch loop).  on = 2 ("bracket"): ONE pair
+ * around the whole run of sweeps t >= 2 of a solve — eager or replayed from the captured hipGraph — counted as that
+ * many launches: two event records per solve, the inter-launch gaps (~1.5 us each) are inside the measured time. */
 int rc_profile_enable(rc_handle_t h, int on);
 int rc_profile_collect(rc_handle_t h, int kernel_class, int* launches, double* total_ms);
 

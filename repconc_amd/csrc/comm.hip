@@ -293,22 +293,25 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
     // sweeps t = 0 .. iters-1, the two chains enqueued alternately so both streams stay fed
     const int variant = rc_env_int("RC_SK_V1", 0) | (rc_env_int("RC_SK_FKLDS", 1) << 1) | (rc_env_int("RC_SK_NB", 0) << 2) |
                         (rc_env_int("RC_SK_CPB", 0) << 14) | ((int)coll << 24);
-    const bool want_graph = rc_env_int("RC_GRAPH", 1) != 0 && !h->profile_on && !h->graph_broken && iters > 4;
+    // per-launch event marks (profile mode 1) need the eager loop; the bracket mode (2) times the whole run of sweeps
+    const bool want_graph = rc_env_int("RC_GRAPH", 1) != 0 && h->profile_on != 1 && !h->graph_broken && iters > 4;
+    const bool bracket = h->profile_on == 2 && L.nch == 1 && B > 0;     // one chain: launches are back to back on s0
     int t = 0;
-    const int t_eager = want_graph ? 2 : iters;
+    const int t_eager = (want_graph || bracket) ? 2 : iters;
     for (; t < t_eager && t < iters; ++t)
         if ((rc = solve_iteration(cx, t)) != RC_OK) return rc;
     if (t < iters) {
         // ---- sweeps t = 2 .. iters-1 from a cached graph
         rc_handle_s::solve_graph* hit = nullptr;
         rc_handle_s::solve_graph* victim = &h->graphs[0];
+        if (want_graph)
         for (auto& g : h->graphs) {
             if (g.exec && g.ws == ws && g.B == B && g.M == M && g.iters == iters && g.world == G && g.nch == L.nch &&
                 g.variant == variant && g.eps == eps) hit = &g;
             if (g.stamp < victim->stamp) victim = &g;
         }
         if ((rc = join()) != RC_OK) return rc;               // the graph is launched on s0 and forks inside
-        if (!hit) {
+        if (!hit && want_graph) {
             hipGraph_t graph = nullptr;
             bool ok = hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
@@ -333,14 +336,18 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
                 hit = victim;
             }
         }
+        const int nsweeps = iters - t;
+        if (bracket) rc_prof_bracket(h, RC_PROF_SK_PASS, s0, true, nsweeps);
         if (hit) {
             hit->stamp = ++h->graph_stamp;
             RC_HIP_CHECK(h, hipGraphLaunch(hit->exec, s0));
+            if (bracket) rc_prof_bracket(h, RC_PROF_SK_PASS, s0, false, nsweeps);
             if ((rc = fork()) != RC_OK) return rc;           // the argmax launches below use both streams again
         } else {
             if ((rc = fork()) != RC_OK) return rc;
             for (; t < iters; ++t)
                 if ((rc = solve_iteration(cx, t)) != RC_OK) return rc;
+            if (bracket) rc_prof_bracket(h, RC_PROF_SK_PASS, s0, false, nsweeps);
         }
     }
     if (B > 0)

@@ -107,16 +107,26 @@ const double* rc_exp2_table(rc_handle_t h, int tb) {
 extern "C" int rc_profile_enable(rc_handle_t h, int on) {
     rc_device_guard device_guard_(h);
     if (!h) return RC_EINVAL;
-    h->profile_on = on ? 1 : 0;
+    h->profile_on = on == 2 ? 2 : (on ? 1 : 0);
     return RC_OK;
 }
 
 void rc_prof_mark(rc_handle_t h, int slot, hipStream_t s) {
-    if (!h || !h->profile_on || h->capturing) return;
+    if (!h || h->profile_on != 1 || h->capturing) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, s);
     h->prof_ev[slot].push_back(e);
+    if (h->prof_ev[slot].size() % 2 == 0) h->prof_n[slot].push_back(1);
+}
+
+void rc_prof_bracket(rc_handle_t h, int slot, hipStream_t s, bool open, int launches) {
+    if (!h || h->profile_on != 2 || h->capturing) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    h->prof_ev[slot].push_back(e);
+    if (!open) h->prof_n[slot].push_back(launches);
 }
 
 extern "C" int rc_profile_collect(rc_handle_t h, int kernel_class, int* launches, double* total_ms) {
@@ -130,10 +140,11 @@ extern "C" int rc_profile_collect(rc_handle_t h, int kernel_class, int* launches
         RC_HIP_CHECK(h, hipEventSynchronize(v[i + 1]));
         RC_HIP_CHECK(h, hipEventElapsedTime(&ms, v[i], v[i + 1]));
         tot += ms;
-        ++n;
+        n += (i / 2 < h->prof_n[kernel_class].size()) ? h->prof_n[kernel_class][i / 2] : 1;
     }
     for (hipEvent_t e : v) (void)hipEventDestroy(e);
     v.clear();
+    h->prof_n[kernel_class].clear();
     *launches = n;
     *total_ms = tot;
     return RC_OK;

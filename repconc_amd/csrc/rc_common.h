@@ -17,6 +17,7 @@ struct rc_handle_s {
     int last_hip_error;
     int profile_on;
     std::vector<hipEvent_t> prof_ev[RC_PROF_NSLOT];  // start, stop, start, stop, ...
+    std::vector<int> prof_n[RC_PROF_NSLOT];          // launches covered by each (start, stop) pair
     double* exp2_tab[3];                             // device tables 2^(j/N): [0] N=256, [1] N=2048, [2] N=4096
     // RCCL state of rc_comm_init (comm.hip): two communicators so two independent chains of collectives can be
     // in flight on two streams
@@ -60,6 +61,10 @@ const double* rc_exp2_table(rc_handle_t h, int tb);
 // Record a start / stop event around one launch of a profiled kernel class (no-ops unless
 // rc_profile_enable(h, 1)).  Events are recorded on the stream the kernel is launched on.
 void rc_prof_mark(rc_handle_t h, int slot, hipStream_t s);
+// Profile mode 2 ("bracket"): ONE (start, stop) pair around a whole run of `launches` back-to-back launches of a kernel
+// class (the sweeps of a solve, eager or replayed from the hipGraph): two event records per solve instead of two per
+// launch.  Call with open = true before the run and open = false after it.  No-op unless rc_profile_enable(h, 2).
+void rc_prof_bracket(rc_handle_t h, int slot, hipStream_t s, bool open, int launches);
 
 #define RC_K 256  // centroids per sub-quantiser (reference asserts MCQ_K == 256)
 

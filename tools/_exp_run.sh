@@ -1,9 +1,9 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r02k; mkdir -p $O
-timeout 1500 python -m pytest tests -q -m gpu --timeout 900 -k "ivf" 2>&1 | tail -40 > $O/pytest_ivf.txt; grep -E "^FAILED|^ERROR|passed|failed|Error|assert " $O/pytest_ivf.txt | tail -12
-python tools/ivf_bench.py 96 2>&1 | tail -6
-cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- python $GRAFT_REPO_ROOT/tools/ivf_bench.py 96 > /dev/null 2>&1; python - <<PY
-import csv,glob
-f=glob.glob("/tmp/ks/**/*kernel_stats.csv", recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:22]:
-    print(r["Name"][:64].ljust(64), r["Calls"].rjust(5), f'{float(r["AverageNs"])/1e3:10.1f} us', r["Percentage"])
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r02l; mkdir -p $O
+timeout 600 python -m pytest tests -q -m gpu --timeout 600 -k "graph or golden_codes or native_rccl" 2>&1 | tail -3
+python bench.py --no-cpu > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; python - <<PY
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+print({k:d[k] for k in ("value","ms_per_step")}, d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], d["roofline"]["launches_timed"])
+print(d["per_rank_6144"]["value"], d["per_rank_6144"]["ms_per_step"], d["per_rank_6144"]["roofline"]["frac"], d["per_rank_6144"]["roofline"]["avg_launch_ms"])
+print(d["adc"]["value"], d["ivf"]["queries_per_sec"])
 PY
