@@ -345,6 +345,13 @@ def main():
                          "bound": "lds-gather", "achieved": round(lds_ach, 1), "peak": round(lds_peak, 1), "unit": "GB/s",
                          "frac": round(lds_ach / lds_peak, 4), "lds_bytes_per_launch": lds_bytes,
                          "avg_launch_ms": round(scan_ms, 3), "launches_timed": n_l.value,
+                         "measured_gather_roof": {"ns_per_gather_instruction_per_cu": 2.2, "GBs": round(512 / 2.2 * 256, 1),
+                                                  "frac": round(lds_ach / (512 / 2.2 * 256), 4),
+                                                  "note": "tools/ubench_lds_gather.hip (profiles/r02c_ubench_lds_gather.txt): a "
+                                                          "random-code ds_read_b64 gather with the screen's two-instruction address, "
+                                                          "zero bank conflicts, 16 waves per CU, sustains 2.2-2.4 ns per "
+                                                          "wave-instruction per CU with or without the MFMAs - the nominal 256 B/clk is "
+                                                          "for sequential reads"},
                          "hbm_equivalent": {"algorithmic_bytes_per_launch": adc_alg, "achieved_GBs": round(adc_ach, 1),
                                             "note": "N*M code bytes per query (SURVEY 8d) / kernel time: 8 queries share every "
                                                     "code read and tiles are re-read from L2, so this exceeds the HBM peak and is "

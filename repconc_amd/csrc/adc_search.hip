@@ -46,7 +46,9 @@
 #define RC_ADC_IMG16 0         // 1: the permuted code image holds 16-bit codes (one v_mad_u32_u16 per gather address instead of bfe + lshl_add)
 #endif
 #define ADC_IMG_ES (RC_ADC_IMG16 ? 2 : 1)   // bytes per code in the image
+#ifndef ADC_CF_TILE
 #define ADC_CF_TILE 65536     // rows per block of the conflict-free screen: a 65536 x 48 B tile (3 MiB) still fits the XCD's 4 MiB L2; half the table fills
+#endif
 
 __device__ __forceinline__ unsigned adc_order_key(float s) {
     const unsigned u = __float_as_uint(s);
