@@ -480,6 +480,55 @@ def main():
         }
         del xb
 
+    # ------------------------------------------------------------------ warm-up leg (OPQ + PQ training, a-12)
+    if world == 1 and not args.no_adc:
+        from repconc_amd.train.run_warmup import MAX_TRAIN_POINTS, train_opq, train_pq
+        gw = torch.Generator(device=dev).manual_seed(20226)
+        xt = torch.randn((MAX_TRAIN_POINTS, D), device=dev, generator=gw)
+        xt = (xt @ (torch.randn((D, D), device=dev, generator=gw) / D ** 0.5)).contiguous()    # correlated dimensions
+        train_pq(xt, M, 1)                                        # library / kernel warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        Cw, mse_pq = train_pq(xt, M, 25)
+        torch.cuda.synchronize()
+        t_pq = time.perf_counter() - t0
+        hist = []
+        t0 = time.perf_counter()
+        Rw = train_opq(xt, M, n_outer=50, n_pq_first=40, n_pq=4, history=hist)
+        torch.cuda.synchronize()
+        t_opq = time.perf_counter() - t0
+        xr = (xt @ Rw).contiguous()
+        t0 = time.perf_counter()
+        Cw, mse_opq = train_pq(xr, M, 25)
+        torch.cuda.synchronize()
+        t_pq2 = time.perf_counter() - t0
+        Pm = (xt.T @ xt).double()
+        t0 = time.perf_counter()
+        torch.linalg.svd(Pm)
+        torch.cuda.synchronize()
+        t_svd = time.perf_counter() - t0
+        from repconc_amd.train.run_warmup import procrustes_rotation
+        t0 = time.perf_counter()
+        procrustes_rotation(Pm)
+        torch.cuda.synchronize()
+        t_polar = time.perf_counter() - t0
+        out["warmup"] = {
+            "metric": "opq_pq_training_seconds", "value": round(t_opq + t_pq2, 3), "unit": "s", "higher_is_better": False,
+            "train_rows": MAX_TRAIN_POINTS, "M": M,
+            "opq_50_rounds_s": round(t_opq, 3), "final_pq_25_lloyd_iterations_s": round(t_pq2, 3),
+            "lloyd_iteration_ms": round(t_pq / 26 * 1e3, 3),
+            "procrustes_newton_schulz_s": round(t_polar, 4), "procrustes_library_svd_fp64_s": round(t_svd, 3),
+            "mse_pq_without_rotation": round(mse_pq, 5), "mse_after_opq": round(mse_opq, 5),
+            "mse_opq_rounds_first_last": [round(hist[0], 5), round(hist[-1], 5)],
+            "rotation_orthogonality_error": float((Rw @ Rw.T - torch.eye(D, device=dev)).abs().max()),
+            "note": "the whole training of run_warmup.py:92-113 at Faiss-default sizes (65 536 training rows; 50 OPQ rounds "
+                    "with 40 + 49 x 4 Lloyd iterations, then 25 Lloyd iterations on the rotated rows), nothing projected: "
+                    "assignment / statistics / update are the HIP kernels, the 768-wide GEMMs are library calls, the "
+                    "Procrustes step is a GEMM-only Newton-Schulz polar iteration in fp64 (the library SVD beside it)",
+        }
+        del xr, Pm
+        del xt, Cw, Rw
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     if world == 1 and not args.no_cpu:
         from oracle import c_oracle

@@ -306,6 +306,70 @@ def lloyd(x, centroids, n_iter: int):
     return C
 
 
+def reseed_empty(C, cnt):
+    """Faiss 1.7.x `split_clusters` as SURVEY.md Appendix B restates it: an empty cluster takes a copy of the most
+    populated cluster's centroid, the copy scaled by (1 +- 1/1024) with alternating sign over the components and the
+    donor by the opposite factor; the donor's count is split in two.  (Simplification kept on both sides of the parity
+    test: the donor is the argmax, not Faiss's size-proportional random draw.)"""
+    eps = 1.0 / 1024
+    M, K, dsub = C.shape
+    cnt = cnt.copy()
+    sign = np.where(np.arange(dsub) % 2 == 0, 1.0, -1.0).astype(F32) * F32(eps)
+    n = 0
+    for m, k in zip(*np.nonzero(cnt == 0)):
+        j = int(np.argmax(cnt[m]))
+        C[m, k] = C[m, j] * (F32(1) + sign)
+        C[m, j] = C[m, j] * (F32(1) - sign)
+        half = cnt[m, j] // 2
+        cnt[m, k] = half
+        cnt[m, j] -= half
+        n += 1
+    return n
+
+
+def train_pq(x, M, n_iter, centroids=None, seed=1234, quantize_fn=None):
+    """The PQ half of `index.train` (train/run_warmup.py:113): Lloyd iterations of the M sub-quantisers on x [n, D]
+    from a random sample of 256 training rows (numpy default_rng(seed) permutation — the build's choice; Faiss draws
+    with its own generator, which cannot be reproduced here) or from `centroids`; returns (C, mse) with
+    mse = mean_b ||decode(code_b) - x_b||^2 after a final assignment.  `quantize_fn` (default: this file's exact-order
+    `quantize`) lets a test substitute the compiled C restatement of the same arithmetic for speed."""
+    q = quantize_fn or (lambda xx, cc: quantize(xx, cc, False))
+    n, D = x.shape
+    dsub = D // M
+    if centroids is None:
+        perm = np.random.default_rng(seed).permutation(n)[:256]
+        centroids = np.ascontiguousarray(x[perm].reshape(256, M, dsub).transpose(1, 0, 2))
+    C = centroids.astype(F32).copy()
+    for _ in range(n_iter):
+        codes = q(x, C)
+        s, c = kmeans_stats(x, codes, M)
+        C = kmeans_update(s, c, C)
+        reseed_empty(C, c)
+    codes = q(x, C)
+    rec = decode(codes, C)
+    mse = float(((rec.astype(F64) - x.astype(F64)) ** 2).sum() / n)
+    return C, mse
+
+
+def train_opq(x, M, R0, n_outer, n_pq_first, n_pq, seed=1234, quantize_fn=None):
+    """The OPQ half of `index.train` (the `OPQ{M}` pre-transform of run_warmup.py:92-96), non-parametric OPQ as Faiss's
+    OPQMatrix::train runs it (Ge et al. 2013): from the orthogonal R0, n_outer rounds of { x_r = x R ; PQ k-means on x_r
+    (n_pq_first Lloyd iterations the first round, n_pq warm-started ones afterwards) ; x_rec = decode(encode(x_r)) ;
+    R = U V^T with x^T x_rec = U S V^T }.  Returns (R, [mse per round])."""
+    q = quantize_fn or (lambda xx, cc: quantize(xx, cc, False))
+    R = R0.astype(F32).copy()
+    C, hist = None, []
+    for it in range(n_outer):
+        xr = np.ascontiguousarray((x.astype(F32) @ R).astype(F32))
+        C, mse = train_pq(xr, M, n_pq_first if it == 0 else n_pq, centroids=C, seed=seed, quantize_fn=quantize_fn)
+        hist.append(mse)
+        xrec = decode(q(xr, C), C)
+        P = x.astype(F64).T @ xrec.astype(F64)
+        U, _, Vh = np.linalg.svd(P)
+        R = (U @ Vh).astype(F32)
+    return R, hist
+
+
 # --------------------------------------------------------------------------- metric
 def mrr_at_k(ranked_ids: np.ndarray, positives, k: int = 10) -> float:
     """MRR@k as utils/eval_utils.py:136-190 computes it through pytrec_eval: truncate each

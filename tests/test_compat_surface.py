@@ -127,3 +127,22 @@ def test_gradcache_two_pass_gradients_equal_direct_backward_cpu():
     assert abs(float(direct) - float(loss)) < 1e-6
     for a, p in zip(got, net.parameters()):
         assert torch.allclose(a, p.grad, atol=1e-6)
+
+
+def test_procrustes_rotation_equals_the_svd_solution():
+    """train/run_warmup.py (OPQ step): the Newton-Schulz polar factor is U V^T of the SVD; singular input falls back."""
+    import torch
+    from repconc_amd.train.run_warmup import procrustes_rotation
+    g = torch.Generator().manual_seed(4)
+    for D, cond in ((96, 1e2), (96, 1e6), (33, 1e3)):
+        U = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
+        V = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
+        S = torch.logspace(0, -float(torch.log10(torch.tensor(cond))), D, dtype=torch.float64) * 12.5
+        R = procrustes_rotation((U * S) @ V.T)
+        assert float((R - U @ V.T).abs().max()) < 1e-9
+        assert float((R.T @ R - torch.eye(D, dtype=torch.float64)).abs().max()) < 1e-12
+    P = torch.zeros(8, 8, dtype=torch.float64)
+    P[0, 0] = 1.0                                                   # rank 1: no unique polar factor -> SVD branch
+    R = procrustes_rotation(P)
+    assert float((R.T @ R - torch.eye(8, dtype=torch.float64)).abs().max()) < 1e-12
+    assert float((R.T @ R - torch.eye(8, dtype=torch.float64)).abs().max()) < 1e-12 and abs(float(R[0, 0])) > 0.999

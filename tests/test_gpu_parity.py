@@ -1507,3 +1507,45 @@ def test_ivf_list_centric_search_equals_per_query_scan(M):
         s1, i1 = ivf.search(q, k, nprobe, method="lists")
         s2, i2 = ivf.search(q, k, nprobe, method="scan")
         assert torch.equal(i1, i2) and torch.equal(s1, s2), (M, nprobe)
+
+
+def test_warmup_procedure_follows_the_oracle_round_by_round():
+    """a-12, procedure level: `train_pq` / `train_opq` on the HIP kernels against oracle/pq_oracle.py's restatement of
+    the same published procedure (same training rows, same initial rotation and centroid sample).  One Lloyd round from a
+    given table is exact up to the fp32 rounding of a mean; over several rounds a rare assignment flip (the rotated
+    inputs come from different GEMMs) may move single centroids, so the trajectory is compared through the
+    reconstruction error of every round and the final rotation."""
+    from repconc_amd.train.run_warmup import train_opq, train_pq
+    D, M, n = 128, 8, 8192
+    rng = np.random.default_rng(21)
+    cent = rng.standard_normal((32, D), dtype=np.float32) * 2.0
+    x = cent[rng.integers(0, 32, n)] + rng.standard_normal((n, D), dtype=np.float32)
+    x = np.ascontiguousarray((x @ (rng.standard_normal((D, D), dtype=np.float32) / np.sqrt(D))).astype(np.float32))
+    cq = lambda xx, cc: c_oracle.quantize(xx, cc, False)[0]
+    # PQ k-means: same sample initialisation (seed rule of train_pq), 6 rounds
+    Cw, mse_w = pq_oracle.train_pq(x, M, 6, quantize_fn=cq)
+    Cg, mse_g = train_pq(_t(x), M, 6)
+    assert abs(mse_g - mse_w) <= 1e-4 * mse_w, (mse_g, mse_w)
+    moved = np.abs(Cg.cpu().numpy() - Cw).max(axis=-1) > 1e-5
+    assert moved.mean() < 0.01, float(moved.mean())
+    # first round alone: bit-identical codes, means equal to the last bit or two
+    C1w, _ = pq_oracle.train_pq(x, M, 1, quantize_fn=cq)
+    C1g, _ = train_pq(_t(x), M, 1)
+    np.testing.assert_allclose(C1g.cpu().numpy(), C1w, rtol=2e-6, atol=1e-7)
+    # OPQ: 4 rounds from the same orthogonal start
+    R0 = np.linalg.qr(np.random.default_rng(3).standard_normal((D, D)))[0].astype(np.float32)
+    Rw, hist_w = pq_oracle.train_opq(x, M, R0, 4, 5, 2, quantize_fn=cq)
+    hist_g = []
+    Rg = train_opq(_t(x), M, n_outer=4, n_pq_first=5, n_pq=2, R0=_t(R0), history=hist_g)
+    assert len(hist_g) == 4
+    np.testing.assert_allclose(hist_g, hist_w, rtol=5e-4)
+    R1w, _ = pq_oracle.train_opq(x, M, R0, 1, 5, 2, quantize_fn=cq)     # one round: the rotations still coincide
+    R1g = train_opq(_t(x), M, n_outer=1, n_pq_first=5, n_pq=2, R0=_t(R0)).cpu().numpy()
+    print("one OPQ round: max |R - R_oracle|", float(np.abs(R1g - R1w).max()))
+    assert np.abs(R1g - R1w).max() < 1e-2
+    assert hist_g[-1] < hist_g[0]
+    Rg = Rg.cpu().numpy()
+    assert np.abs(Rg @ Rg.T - np.eye(D)).max() < 1e-5
+    print("opq parity: mse", hist_g, hist_w, "max |R - R_oracle|", float(np.abs(Rg - Rw).max()),
+          "pq moved", float(moved.mean()), "mse", mse_g, mse_w)
+    assert np.abs(Rg - Rw).max() < 0.05

@@ -111,3 +111,37 @@ def test_mrr_at_k():
     ranked = np.array([[5, 3, 9], [1, 2, 3], [7, 8, 9]])
     assert pq_oracle.mrr_at_k(ranked, [{3}, {1}, {4}], 10) == round((0.5 + 1.0 + 0.0) / 3, 5)
     assert pq_oracle.mrr_at_k(ranked, [{9}, {1}, {4}], 2) == round((0.0 + 1.0 + 0.0) / 3, 5)
+
+
+def _correlated(seed, n, D):
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((32, D), dtype=np.float32) * 2.0
+    x = cent[rng.integers(0, 32, n)] + rng.standard_normal((n, D), dtype=np.float32)
+    mix = rng.standard_normal((D, D), dtype=np.float32) / np.sqrt(D)
+    return np.ascontiguousarray((x @ mix).astype(np.float32))
+
+
+def test_warmup_procedure_oracle_lowers_the_error_and_keeps_the_rotation_orthogonal():
+    """oracle train_pq / train_opq (train/run_warmup.py:92-113 restated): the C restatement of the assignment plugs into
+    the numpy procedure (same codes as the numpy one), Lloyd lowers the reconstruction error, OPQ lowers it further on
+    correlated data and returns an orthogonal matrix."""
+    D, M, n = 64, 8, 4096
+    x = _correlated(11, n, D)
+    cq = lambda xx, cc: c_oracle.quantize(xx, cc, False)[0]
+    C0, mse0 = pq_oracle.train_pq(x, M, 0, quantize_fn=cq)
+    C3, mse3 = pq_oracle.train_pq(x, M, 3, quantize_fn=cq)
+    C3n, mse3n = pq_oracle.train_pq(x[:1024], M, 1)                      # numpy assignment == C assignment
+    C3c, mse3c = pq_oracle.train_pq(x[:1024], M, 1, quantize_fn=cq)
+    assert np.array_equal(C3n, C3c) and mse3n == mse3c
+    assert mse3 < mse0
+    R0 = np.linalg.qr(np.random.default_rng(3).standard_normal((D, D)))[0].astype(np.float32)
+    R, hist = pq_oracle.train_opq(x, M, R0, 4, 3, 2, quantize_fn=cq)
+    assert np.abs(R @ R.T - np.eye(D)).max() < 1e-5
+    assert hist[-1] < hist[0]
+    # empty clusters are re-seeded from the biggest one
+    C = C3.copy()
+    cnt = np.full((M, 256), 16, np.int64)
+    cnt[2, 7] = 0
+    cnt[2, 9] = 100
+    assert pq_oracle.reseed_empty(C, cnt) == 1
+    assert np.allclose(C[2, 7] + C[2, 9], 2 * C3[2, 9], rtol=1e-6) and not np.array_equal(C[2, 7], C[2, 9])
