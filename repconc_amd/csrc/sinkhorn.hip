@@ -69,20 +69,16 @@ __device__ __forceinline__ double sk_exp2n(double u, int gq8, const double* __re
     const double n = __builtin_rint(u);
     const double r = u - n;
     const int ni8 = ((int)n << 3) + gq8;
-    // the table is the first thing in the kernel's (dynamic-only) LDS segment, i.e. at LDS address 0 — checked once per
-    // block by sk_assert_table_at_lds0 — so the masked value IS the ds_read address (no base add)
-    (void)tab;
+    // a generic pointer into LDS is {shared aperture, byte offset}: its low 32 bits are the LDS address.  The table is the
+    // first thing in the kernel's (dynamic-only) LDS segment, so that base is 0 with today's code generation and the add
+    // folds away; if a compiler ever places the segment elsewhere the add stays and the result is still right.
+    const unsigned tbase = static_cast<unsigned>(reinterpret_cast<uintptr_t>(tab));
     typedef const double __attribute__((address_space(3))) sk_lds_cd;
-    const double T = *reinterpret_cast<sk_lds_cd*>(static_cast<unsigned>(ni8 & ((SK_N - 1) << 3)));
+    const double T = *reinterpret_cast<sk_lds_cd*>(tbase + static_cast<unsigned>(ni8 & ((SK_N - 1) << 3)));
     double q = __builtin_fma(Z * Z * Z / 6.0, r, Z * Z / 2.0);
     q = __builtin_fma(q, r, Z);
     q = q * r;
     return __builtin_ldexp(__builtin_fma(T, q, T), ni8 >> (SK_TB + 3));
-}
-
-__device__ __forceinline__ void sk_assert_table_at_lds0(const double* tab) {
-    // a generic pointer into LDS is {shared aperture, byte offset}: the low 32 bits are the LDS address
-    if (static_cast<unsigned>(reinterpret_cast<uintptr_t>(tab)) != 0u) __builtin_trap();
 }
 
 __device__ __forceinline__ int sk_kidx(int lane, int i) { return ((i >> 2) << 6) + (lane << 2) + (i & 3); }
@@ -181,7 +177,6 @@ __global__ __launch_bounds__(SK_THREADS, (FKLDS ? 4 : 3)) void sk_sweep_kernel(
     const int64_t c1 = (c0 + cols_per_block < B) ? c0 + cols_per_block : B;
     const int ncols = (int)(c1 - c0);
 
-    sk_assert_table_at_lds0(tab);
     for (int i = tid; i < SK_N; i += SK_THREADS) tab[i] = exp2_tab[i];
     if constexpr (!FIRST) {
         // ---- updates that follow sweep t-1 (modeling_repconc.py:157-158 and :162) ----

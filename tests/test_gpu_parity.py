@@ -1549,3 +1549,29 @@ def test_warmup_procedure_follows_the_oracle_round_by_round():
     print("opq parity: mse", hist_g, hist_w, "max |R - R_oracle|", float(np.abs(Rg - Rw).max()),
           "pq moved", float(moved.mean()), "mse", mse_g, mse_w)
     assert np.abs(Rg - Rw).max() < 0.05
+
+
+def test_end_to_end_code_flips_from_the_rotation_gemm_are_counted():
+    """forward() = encoder -> `@ rotation.T` -> quantize (modeling_repconc.py:87-110).  Codes are bit-exact GIVEN the
+    rotated embeddings; the rotation itself is a library GEMM whose summation order differs from the reference's
+    (torch-CPU here, cuBLAS on the reference's own box), so a sub-vector sitting within rounding distance of a cell
+    boundary may take the neighbouring code.  Count those flips instead of assuming them away: nearest codes from the
+    device GEMM against nearest codes from an fp64 rotation rounded to fp32, and against the torch-CPU fp32 GEMM."""
+    from repconc_amd import ops
+    B, M = 16384, 48
+    x = synth.clustered_embeddings(31, B)
+    R = np.linalg.qr(np.random.default_rng(32).standard_normal((768, 768)))[0].astype(np.float32)
+    C = synth.sample_centroids(33, (x @ R.T).astype(np.float32), M)
+    xr_dev = (_t(x) @ _t(R).T).contiguous()
+    xr_cpu = (torch.from_numpy(x) @ torch.from_numpy(R).T).contiguous()
+    xr_f64 = (x.astype(np.float64) @ R.T.astype(np.float64)).astype(np.float32)
+    rel = float((xr_dev.cpu() - torch.from_numpy(xr_f64)).abs().max() / np.abs(xr_f64).max())
+    assert rel < 1e-5, rel
+    c_dev = ops.assign_nearest(xr_dev, _t(C), torch.uint8).cpu().numpy()
+    c_cpu = ops.assign_nearest(xr_cpu.to(DEV), _t(C), torch.uint8).cpu().numpy()
+    c_f64 = ops.assign_nearest(_t(xr_f64), _t(C), torch.uint8).cpu().numpy()
+    assert np.array_equal(c_f64[:2048], pq_oracle.quantize(xr_f64[:2048], C, False).astype(np.uint8))
+    flips_f64 = float((c_dev != c_f64).mean())
+    flips_cpu = float((c_dev != c_cpu).mean())
+    print(f"rotation GEMM: max rel error {rel:.2e}; code flips vs fp64 rotation {flips_f64:.2e}, vs torch-CPU GEMM {flips_cpu:.2e}")
+    assert flips_f64 < 2e-4 and flips_cpu < 2e-4
