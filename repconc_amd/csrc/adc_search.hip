@@ -824,17 +824,20 @@ __global__ __launch_bounds__(256) void adc_scan_image_kernel(const uint8_t* __re
     }
 }
 
-// Byte tables of the conflict-free screen: [group of 8 queries][phase][code][slot][8], every copy of a 16-block filled.
-// One block per query, thread = code; quantisation exactly as adc_qlut_kernel.
-__global__ __launch_bounds__(RC_K) void adc_qlut_cf_kernel(const float* __restrict__ lut, const float* __restrict__ thr,
-                                                           int M, int PM, int slots, uint8_t* __restrict__ qlut,
-                                                           int* __restrict__ tint) {
-    __shared__ float lo_m[128];
-    __shared__ float red_lo[4], red_hi[4];
-    __shared__ float s_delta;
+// Quantisation of a query's tables to 8 bits, split in two kernels (round 2; the one-kernel form spent 0.31 ms per
+// 1200 queries in 96 block barriers and 19.6 M single-byte stores):
+//   adc_qstats_kernel        per query: lo[m] = min_k LUT[m][k], delta = max_m range / 255, integer threshold  (3 barriers)
+//   adc_qlut_cf_write_kernel byte tables of the conflict-free screen, [group of 8 queries][phase][code][slot][8], every
+//                            copy of a 16-block filled; thread = code, 16-byte stores (two slots x 8 queries)
+//   adc_qbyte_write_kernel   the IVF form: one table per QUERY, [phase][code][slot] one byte per entry
+// The arithmetic per entry is exactly adc_qlut_kernel's: floor((v - lo_m) / delta) clamped to [0, 255].
+#define ADC_QSTAT_STRIDE 128          // floats per query: lo[0..M), delta at [127]
+__global__ __launch_bounds__(RC_K) void adc_qstats_kernel(const float* __restrict__ lut, const float* __restrict__ thr,
+                                                          int M, float* __restrict__ qstat, int* __restrict__ tint) {
+    __shared__ float s_lo[4][ADC_QSTAT_STRIDE], s_hi[4][ADC_QSTAT_STRIDE];
+    __shared__ float s_rng[ADC_QSTAT_STRIDE];
     const int qi = blockIdx.x, c = threadIdx.x;
     const float* lq = lut + (size_t)qi * M * RC_K;
-    float maxrange = 0.f;
     for (int m = 0; m < M; ++m) {
         const float v = lq[m * RC_K + c];
         float lo = v, hi = v;
@@ -843,20 +846,27 @@ __global__ __launch_bounds__(RC_K) void adc_qlut_cf_kernel(const float* __restri
             lo = fminf(lo, __shfl_xor(lo, o));
             hi = fmaxf(hi, __shfl_xor(hi, o));
         }
-        if ((c & 63) == 0) { red_lo[c >> 6] = lo; red_hi[c >> 6] = hi; }
-        __syncthreads();
-        lo = fminf(fminf(red_lo[0], red_lo[1]), fminf(red_lo[2], red_lo[3]));
-        hi = fmaxf(fmaxf(red_hi[0], red_hi[1]), fmaxf(red_hi[2], red_hi[3]));
-        if (c == 0) lo_m[m] = lo;
-        maxrange = fmaxf(maxrange, hi - lo);
-        __syncthreads();
+        if ((c & 63) == 0) { s_lo[c >> 6][m] = lo; s_hi[c >> 6][m] = hi; }
     }
+    __syncthreads();
+    if (c < M) {
+        const float lo = fminf(fminf(s_lo[0][c], s_lo[1][c]), fminf(s_lo[2][c], s_lo[3][c]));
+        const float hi = fmaxf(fmaxf(s_hi[0][c], s_hi[1][c]), fmaxf(s_hi[2][c], s_hi[3][c]));
+        qstat[(size_t)qi * ADC_QSTAT_STRIDE + c] = lo;
+        s_lo[0][c] = lo;
+        s_rng[c] = hi - lo;
+    }
+    __syncthreads();
     if (c == 0) {
+        float maxrange = 0.f;
+        double A = 0.0;
+        for (int m = 0; m < M; ++m) {
+            maxrange = fmaxf(maxrange, s_rng[m]);
+            A += (double)s_lo[0][m];
+        }
         float delta = maxrange / 255.0f;
         if (!(delta > 0.f)) delta = 1.0f;
-        s_delta = delta;
-        double A = 0.0;
-        for (int m = 0; m < M; ++m) A += (double)lo_m[m];
+        qstat[(size_t)qi * ADC_QSTAT_STRIDE + ADC_QSTAT_STRIDE - 1] = delta;
         const float t = thr[qi];
         int T;
         if (t == -INFINITY) {
@@ -867,22 +877,71 @@ __global__ __launch_bounds__(RC_K) void adc_qlut_cf_kernel(const float* __restri
         }
         tint[qi] = T;
     }
-    __syncthreads();
-    const float delta = s_delta;
+}
+
+__device__ __forceinline__ unsigned adc_quant8(float v, float lo, float delta) {
+    int l = (int)floorf((v - lo) / delta);
+    l = l < 0 ? 0 : (l > 255 ? 255 : l);
+    return (unsigned)l;
+}
+
+template <int PM>
+__global__ __launch_bounds__(64) void adc_qlut_cf_write_kernel(const float* __restrict__ lut, const float* __restrict__ qstat,
+                                                               int M, int nq, uint8_t* __restrict__ qlut) {
+    constexpr int SLOTS = adc_cf<PM>::SLOTS;
+    const int g = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
     const int NP = M / PM;
-    uint8_t* dst = qlut + (size_t)(qi / 8) * NP * RC_K * slots * 8 + (qi % 8);
-    for (int m = 0; m < M; ++m) {
-        const float v = (lq[m * RC_K + c] - lo_m[m]) / delta;
-        int l = (int)floorf(v);
-        l = l < 0 ? 0 : (l > 255 ? 255 : l);
-        const int phase = m / PM, mp = m % PM;
-        const int n32 = PM / 32;
-        uint8_t* row = dst + ((size_t)(phase * RC_K + c) * slots) * 8;
-        if (mp < 32 * n32) {
-            row[mp * 8] = (uint8_t)l;                                  // 32-block: slot = sub-quantiser
-        } else {
-            row[mp * 8] = (uint8_t)l;                                  // 16-block: two copies, 16 slots apart
-            row[(mp + 16) * 8] = (uint8_t)l;
+    const int nv = (nq - 8 * g) < 8 ? (nq - 8 * g) : 8;       // valid queries of the group (block-uniform)
+    float delta[8];
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq)
+        delta[qq] = qq < nv ? qstat[(size_t)(8 * g + qq) * ADC_QSTAT_STRIDE + ADC_QSTAT_STRIDE - 1] : 1.0f;
+    for (int phase = 0; phase < NP; ++phase) {
+        uint4* row = reinterpret_cast<uint4*>(qlut + (((size_t)g * NP + phase) * RC_K + c) * SLOTS * 8);
+        for (int s2 = blockIdx.z; s2 < SLOTS / 2; s2 += gridDim.z) {     // slot pairs are dealt over grid.z
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int sl = 2 * s2 + h2;
+                const int mp = sl < PM ? sl : sl - 16;           // second copy of the 16-block
+                const int m = phase * PM + mp;
+#pragma unroll
+                for (int qq = 0; qq < 8; ++qq) {
+                    if (qq < nv) {
+                        const int q = 8 * g + qq;
+                        const unsigned l = adc_quant8(lut[((size_t)q * M + m) * RC_K + c],
+                                                      qstat[(size_t)q * ADC_QSTAT_STRIDE + m], delta[qq]);
+                        w[2 * h2 + (qq >> 2)] |= l << (8 * (qq & 3));
+                    }
+                }
+            }
+            row[s2] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
+template <int PM>
+__global__ __launch_bounds__(RC_K) void adc_qbyte_write_kernel(const float* __restrict__ lut, const float* __restrict__ qstat,
+                                                               int M, uint8_t* __restrict__ qbyte) {
+    constexpr int SLOTS = adc_cf<PM>::SLOTS;
+    const int qi = blockIdx.x, c = threadIdx.x;
+    const int NP = M / PM;
+    const float* lq = lut + (size_t)qi * M * RC_K;
+    const float* st = qstat + (size_t)qi * ADC_QSTAT_STRIDE;
+    const float delta = st[ADC_QSTAT_STRIDE - 1];
+    for (int phase = 0; phase < NP; ++phase) {
+        uint4* row = reinterpret_cast<uint4*>(qbyte + (((size_t)qi * NP + phase) * RC_K + c) * SLOTS);
+#pragma unroll
+        for (int s16 = 0; s16 < SLOTS / 16; ++s16) {
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int sl = 16 * s16 + j;
+                const int mp = sl < PM ? sl : sl - 16;
+                const int m = phase * PM + mp;
+                w[j >> 2] |= adc_quant8(lq[m * RC_K + c], st[m], delta) << (8 * (j & 3));
+            }
+            row[s16] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
 }
@@ -893,7 +952,7 @@ typedef int adc_i32x4v __attribute__((ext_vector_type(4)));
 // A wave owns R chunks of 16 rows per round; lanes (r = l & 15, g = l >> 4).
 // IVF mode (list-centric scan of csrc/ivf_search.hip's index): a block is a TASK = (coarse cell, up to 8 of the queries that
 // probe it); its rows are the cell's row range, its byte tables are transposed on the fly from the per-query tables
-// (adc_qbyte_kernel), its thresholds are those of its queries.
+// (adc_qstats_kernel + adc_qbyte_write_kernel), its thresholds are those of its queries.
 struct adc_ivf_tasks {
     const int* task_list;        // [tasks] cell of the task
     const int* task_qstart;      // [tasks] first entry of the task's queries in sorted_q
@@ -1174,7 +1233,7 @@ __global__ __launch_bounds__(256) void adc_rescore_kernel(const uint8_t* __restr
 
 // ------------------------------------------------------------------------------------------ host
 struct adc_ws_layout {
-    size_t lut, sample, thr, cnt, cand, qlut, tint, idcnt, ids, image, total;
+    size_t lut, sample, thr, cnt, cand, qlut, tint, qstat, idcnt, ids, image, total;
     int64_t S;
 };
 static int adc_qs_for(int M) { (void)M; return 16; }   // table groups are sized for 16 queries (covers the 8- and 4-query kernels)
@@ -1197,7 +1256,7 @@ static adc_ws_layout adc_layout(int64_t N, int M, int nq, bool own_image = true)
     L.thr = o;    o += rc_align_up((size_t)nq * sizeof(float), 256);
     L.cnt = o;    o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
     L.cand = o;   o += rc_align_up((size_t)nq * ADC_CAND_CAP * sizeof(unsigned long long), 256);
-    L.qlut = L.tint = L.idcnt = L.ids = o;
+    L.qlut = L.tint = L.qstat = L.idcnt = L.ids = o;
     if (N >= ADC_SCREEN_MIN_N) {
         const int QS = adc_qs_for(M);
         size_t qb = (size_t)((nq + QS - 1) / QS) * M * RC_K * QS;
@@ -1207,6 +1266,7 @@ static adc_ws_layout adc_layout(int64_t N, int M, int nq, bool own_image = true)
         }
         L.qlut = o;  o += rc_align_up(qb, 256);
         L.tint = o;  o += rc_align_up((size_t)nq * sizeof(int), 256);
+        L.qstat = o; o += rc_align_up((size_t)nq * ADC_QSTAT_STRIDE * sizeof(float), 256);
         L.idcnt = o; o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
         L.ids = o;   o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
     }
@@ -1266,7 +1326,7 @@ static int adc_qt_for(int M) {
 
 struct adc_bufs {
     float* lut; float* sample; float* thr; unsigned* cnt; unsigned long long* cand;
-    uint8_t* qlut; int* tint; unsigned* idcnt; unsigned* ids;
+    uint8_t* qlut; int* tint; unsigned* idcnt; unsigned* ids; float* qstat;
 };
 
 template <int M, int QT>
@@ -1321,8 +1381,10 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             constexpr int R = (NP == 2) ? 8 : ((M == 64 || (ADC_IMG_ES == 2 && M == 48)) ? 2 : 4);   // register budget
             auto kern = adc_screen_cf_kernel<M, NP, R>;
             constexpr int sl = adc_cf<PM>::TABLE_BYTES;
-            hipLaunchKernelGGL(adc_qlut_cf_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, PM,
-                               adc_cf<PM>::SLOTS, b.qlut, b.tint);
+            hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, b.qstat, b.tint);
+            RC_LAUNCH_CHECK(h);
+            hipLaunchKernelGGL(adc_qlut_cf_write_kernel<PM>, dim3((unsigned)((nq + 7) / 8), RC_K / 64, 4), dim3(64), 0, s, b.lut,
+                               (const float*)b.qstat, M, nq, b.qlut);
             RC_LAUNCH_CHECK(h);
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
@@ -1433,7 +1495,7 @@ extern "C" int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint
     unsigned* cnt = (unsigned*)(w + L.cnt);
     unsigned long long* cand = (unsigned long long*)(w + L.cand);
     const adc_bufs bufs = {lut, (float*)(w + L.sample), (float*)(w + L.thr), cnt, cand, (uint8_t*)(w + L.qlut),
-                           (int*)(w + L.tint), (unsigned*)(w + L.idcnt), (unsigned*)(w + L.ids)};
+                           (int*)(w + L.tint), (unsigned*)(w + L.idcnt), (unsigned*)(w + L.ids), (float*)(w + L.qstat)};
     hipStream_t s = (hipStream_t)stream;
     int rc = rc_adc_lut(h, C, q, nq, D, M, K, lut, stream);
     if (rc != RC_OK) return rc;
@@ -1473,7 +1535,7 @@ extern "C" int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint
 //   1. adc_lut                     fp32 tables of every query (caller)
 //   2. ivf_sample_scan_kernel      exact scores of every SS-th row of the query's probed cells -> sample[q][..]
 //   3. ivf_rank_select_kernel      tau_q = rank_q-th largest sample score (rank 0: -inf, every probed row is a candidate)
-//   4. adc_qbyte_kernel            per query: 8-bit tables in slot layout + integer threshold (as adc_qlut_cf_kernel)
+//   4. adc_qstats_kernel + adc_qbyte_write_kernel   per query: 8-bit tables in slot layout + integer threshold
 //   5. adc_screen_cf_kernel<IVF>   per task: transpose the 8 queries' byte tables into LDS, screen the cell's rows
 //   6. adc_rescore_kernel          exact fp32 score of the survivors, keys carry the corpus position of the row
 //   7. adc_select_kernel           top-k, (score desc, corpus id asc) — the tie rule of the flat search
@@ -1561,64 +1623,6 @@ __global__ __launch_bounds__(1024) void ivf_rank_select_kernel(const float* __re
     if (tid == 0) thr[qi] = adc_unorder_key(sel_prefix);
 }
 
-// Per query: the 8-bit tables of adc_qlut_cf_kernel, but one table per QUERY in slot layout [phase][code][slot] (one byte
-// per entry, both copies of a 16-block filled), plus the integer threshold.  The screen transposes 8 of them into LDS.
-__global__ __launch_bounds__(RC_K) void adc_qbyte_kernel(const float* __restrict__ lut, const float* __restrict__ thr, int M,
-                                                         int PM, int slots, uint8_t* __restrict__ qbyte,
-                                                         int* __restrict__ tint) {
-    __shared__ float lo_m[128];
-    __shared__ float red_lo[4], red_hi[4];
-    __shared__ float s_delta;
-    const int qi = blockIdx.x, c = threadIdx.x;
-    const float* lq = lut + (size_t)qi * M * RC_K;
-    float maxrange = 0.f;
-    for (int m = 0; m < M; ++m) {
-        const float v = lq[m * RC_K + c];
-        float lo = v, hi = v;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = fminf(lo, __shfl_xor(lo, o));
-            hi = fmaxf(hi, __shfl_xor(hi, o));
-        }
-        if ((c & 63) == 0) { red_lo[c >> 6] = lo; red_hi[c >> 6] = hi; }
-        __syncthreads();
-        lo = fminf(fminf(red_lo[0], red_lo[1]), fminf(red_lo[2], red_lo[3]));
-        hi = fmaxf(fmaxf(red_hi[0], red_hi[1]), fmaxf(red_hi[2], red_hi[3]));
-        if (c == 0) lo_m[m] = lo;
-        maxrange = fmaxf(maxrange, hi - lo);
-        __syncthreads();
-    }
-    if (c == 0) {
-        float delta = maxrange / 255.0f;
-        if (!(delta > 0.f)) delta = 1.0f;
-        s_delta = delta;
-        double A = 0.0;
-        for (int m = 0; m < M; ++m) A += (double)lo_m[m];
-        const float t = thr[qi];
-        int T;
-        if (t == -INFINITY) {
-            T = INT_MIN;
-        } else {
-            const double v = ceil(((double)t - A) / (double)delta) - (double)(M + 2);
-            T = v < -2.0e9 ? INT_MIN : (v > 2.0e9 ? INT_MAX : (int)v);
-        }
-        tint[qi] = T;
-    }
-    __syncthreads();
-    const float delta = s_delta;
-    const int NP = M / PM, n32 = PM / 32;
-    uint8_t* dst = qbyte + (size_t)qi * NP * RC_K * slots;
-    for (int m = 0; m < M; ++m) {
-        const float v = (lq[m * RC_K + c] - lo_m[m]) / delta;
-        int l = (int)floorf(v);
-        l = l < 0 ? 0 : (l > 255 ? 255 : l);
-        const int phase = m / PM, mp = m % PM;
-        uint8_t* row = dst + ((size_t)phase * RC_K + c) * slots;
-        row[mp] = (uint8_t)l;
-        if (mp >= 32 * n32) row[mp + 16] = (uint8_t)l;            // second copy of the 16-block
-    }
-}
-
 __global__ void ivf_check_kernel(const unsigned* __restrict__ cand_count, const int* __restrict__ rows, int nq, int k,
                                  int* __restrict__ status) {
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1629,7 +1633,7 @@ __global__ void ivf_check_kernel(const unsigned* __restrict__ cand_count, const 
 
 namespace {
 struct ivfl_ws {
-    size_t sample, thr, tint, qbyte, idcnt, ids, cnt, cand, total;
+    size_t sample, thr, tint, qstat, qbyte, idcnt, ids, cnt, cand, total;
 };
 ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
     ivfl_ws L;
@@ -1637,6 +1641,7 @@ ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
     L.sample = o; o += rc_align_up((size_t)nq * (size_t)sstride * sizeof(float), 256);
     L.thr = o;    o += rc_align_up((size_t)nq * sizeof(float), 256);
     L.tint = o;   o += rc_align_up((size_t)nq * sizeof(int), 256);
+    L.qstat = o;  o += rc_align_up((size_t)nq * ADC_QSTAT_STRIDE * sizeof(float), 256);
     L.qbyte = o;  o += rc_align_up((size_t)nq * (adc_cf_table_bytes(M) / 8), 256);
     L.idcnt = o;  o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
     L.ids = o;    o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
@@ -1656,6 +1661,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     float* sample = (float*)(w + L.sample);
     float* thr = (float*)(w + L.thr);
     int* tint = (int*)(w + L.tint);
+    float* qstat = (float*)(w + L.qstat);
     uint8_t* qbyte = (uint8_t*)(w + L.qbyte);
     unsigned* idcnt = (unsigned*)(w + L.idcnt);
     unsigned* ids = (unsigned*)(w + L.ids);
@@ -1674,8 +1680,9 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     }
     hipLaunchKernelGGL(ivf_rank_select_kernel, dim3((unsigned)nq), dim3(1024), 0, s, (const float*)sample, scount, rank, sstride, thr);
     RC_LAUNCH_CHECK(h);
-    hipLaunchKernelGGL(adc_qbyte_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)thr, M, PM, adc_cf<PM>::SLOTS,
-                       qbyte, tint);
+    hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)thr, M, qstat, tint);
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(adc_qbyte_write_kernel<PM>, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)qstat, M, qbyte);
     RC_LAUNCH_CHECK(h);
     RC_HIP_CHECK(h, hipMemsetAsync(idcnt, 0, (size_t)nq * sizeof(unsigned), s));
     RC_HIP_CHECK(h, hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(unsigned), s));
