@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--no-per-rank", action="store_true",
                     help="skip the per_rank_6144 leg (profiling runs: its launches of the sweep kernel would mix into "
                          "the per-kernel averages of the timed 49152-row configuration)")
-    ap.add_argument("--adc-batches", type=int, default=2)
+    ap.add_argument("--adc-batches", type=int, default=6,
+                    help="1200-query batches in the timed ADC region (6 = the 6980 dev queries of the reference's evaluation)")
     ap.add_argument("--adc-k", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=B_GLOBAL, help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
@@ -312,14 +313,15 @@ def main():
 
         def search(bi):
             q = q_all[bi * nq_batch + rank * per_rank: bi * nq_batch + (rank + 1) * per_rank]
-            return index.search(q, k)
+            return index.search_async(q, k)
 
-        search(0)
+        search(0)()
         barrier()
         lib.rc_profile_enable(h, 1)
         t0 = time.perf_counter()
-        for bi in range(args.adc_batches):
-            sc, ids = search(bi)
+        pending = [search(bi) for bi in range(args.adc_batches)]     # as batch_search: every batch enqueued, then read
+        for fin in pending:
+            sc, ids = fin()
         barrier()
         adt = max_over_ranks(time.perf_counter() - t0)
         lib.rc_profile_enable(h, 0)

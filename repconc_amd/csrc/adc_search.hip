@@ -1514,6 +1514,7 @@ extern "C" int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint
         const double r_cap = 0.8 * (double)ADC_CAND_CAP * (double)L.S / (double)N;
         if ((double)r > r_cap && r_cap >= mu + 2.5 * sqrt(mu + 1.0) + 2.0) r = (int)r_cap;
         if (r > L.S) r = (int)L.S;
+        if (r < 1) r = 1;       // a (hugely) negative slack: the best sample score
     }
     switch (M) {
         ADC_CASE(8, 4) ADC_CASE(12, 4) ADC_CASE(16, 4) ADC_CASE(24, 4) ADC_CASE(32, 4)

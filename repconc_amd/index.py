@@ -92,15 +92,25 @@ class PQIndex:
     def search(self, x, k: int):
         """(scores [nq,k], ids [nq,k]); numpy in -> numpy out (evaluate_repconc.py:182), CUDA tensors
         in -> CUDA tensors out (finetune_jpq.py:176 via faiss.contrib.torch_utils)."""
+        return self.search_async(x, k)()
+
+    def search_async(self, x, k: int):
+        """Enqueue the search and return a callable that yields what `search` returns.  Nothing synchronises with the
+        host until it is called, so a caller with several query batches (`batch_search`) can enqueue them all first: the
+        device then never idles between batches waiting for the host to read a status word and launch the next one."""
         as_numpy = not isinstance(x, torch.Tensor)
         q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if as_numpy else x
-        q = q.to(self.device, torch.float32)
+        q = q.to(self.device, torch.float32, non_blocking=True)
         # prefixes of the row-major buffers are contiguous views: nothing is copied
-        scores, ids = ops.adc_search(self._codes[: self.ntotal], self._centroids, q, int(k), id_offset=self.id_offset,
-                                     scan_image=None if self._image is None else self._image[: self.ntotal])
-        if as_numpy:
-            return scores.cpu().numpy(), ids.cpu().numpy()
-        return scores, ids
+        pending = ops.adc_search(self._codes[: self.ntotal], self._centroids, q, int(k), id_offset=self.id_offset,
+                                 scan_image=None if self._image is None else self._image[: self.ntotal], defer=True)
+
+        def finish():
+            scores, ids = pending.result()
+            if as_numpy:
+                return scores.cpu().numpy(), ids.cpu().numpy()
+            return scores, ids
+        return finish
 
     def reconstruct_n(self, i0: int, n: int) -> torch.Tensor:
         return ops.decode_raw(self.codes[i0:i0 + n].contiguous(), self._centroids)

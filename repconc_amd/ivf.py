@@ -245,5 +245,5 @@ class IVFPQIndex:
             st = int(status.item())
             if st == 0:
                 return scores, ids
-            slack = slack * 3.0 + 2.0 if (st & 1) else max(slack / 3.0, 0.0)
+            slack = max(slack, 0.0) * 3.0 + 2.0 if (st & 1) else max(slack / 3.0, 0.0)
         raise _lib.RepconcHipError(f"IVF candidate selection did not converge (status {st})")

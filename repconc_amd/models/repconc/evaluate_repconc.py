@@ -192,11 +192,22 @@ def search(query_ids: np.ndarray, query_embeds, corpus_ids: np.ndarray, index: P
 
 def batch_search(query_ids: np.ndarray, query_embeds, corpus_ids: np.ndarray, index: PQIndex, topk: int,
                  batch_size: int):
-    """evaluate_repconc.py:188-206 (np.array_split batching)."""
+    """evaluate_repconc.py:188-206 (np.array_split batching).  Every batch is enqueued before the first result is read
+    (`search_async`), so the device runs the batches back to back; indexes without `search_async` (the multi-device
+    wrappers, anything Faiss-shaped) take the reference's batch-by-batch loop."""
     iterations = max(1, math.ceil(len(query_ids) / batch_size))
+    qid_parts, emb_parts = np.array_split(query_ids, iterations), np.array_split(query_embeds, iterations)
+    if not hasattr(index, "search_async"):
+        got = [search(qid_it, emb_it, corpus_ids, index, topk) for qid_it, emb_it in zip(qid_parts, emb_parts)]
+        return np.concatenate([g[0] for g in got], axis=0), np.concatenate([g[1] for g in got], axis=0)
+    pending = [index.search_async(emb_it, topk) for emb_it in emb_parts]
     all_scores, all_ids = [], []
-    for qid_it, emb_it in zip(np.array_split(query_ids, iterations), np.array_split(query_embeds, iterations)):
-        s, i = search(qid_it, emb_it, corpus_ids, index, topk)
-        all_scores.append(s)
-        all_ids.append(i)
+    ids_table = np.asarray(corpus_ids)
+    for qid_it, fin in zip(qid_parts, pending):
+        topk_scores, topk_idx = fin()
+        if isinstance(topk_idx, torch.Tensor):
+            topk_idx, topk_scores = topk_idx.cpu().numpy(), topk_scores.cpu().numpy()
+        assert len(qid_it) == len(topk_scores) == len(topk_idx)
+        all_scores.append(topk_scores)
+        all_ids.append(ids_table[topk_idx])
     return np.concatenate(all_scores, axis=0), np.concatenate(all_ids, axis=0)

@@ -417,12 +417,41 @@ def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Op
     return image
 
 
+class PendingSearch:
+    """A search that has been enqueued but whose status word has not been read yet (`adc_search(..., defer=True)`).
+    `result()` synchronises, reads the status and — in the rare case that the sampled threshold admitted too few or too
+    many candidates — repeats the search with an adjusted slack, exactly as the immediate form does; then returns
+    (scores, ids).  Lets a caller enqueue every query batch before the first host synchronisation."""
+
+    def __init__(self, run, scores, ids, status, slack, max_retries):
+        self._run, self._scores, self._ids, self._status = run, scores, ids, status
+        self._slack, self._left, self._done = slack, max_retries, status is None
+
+    def result(self):
+        while not self._done:
+            st = int(self._status.item())
+            if st == 0:
+                self._done = True
+                break
+            if self._left <= 0:
+                raise _lib.RepconcHipError(f"ADC candidate selection did not converge (status {st}); "
+                                           "the index probably holds thousands of identical codes")
+            # bit0: too few candidates (threshold too high) -> widen; bit1: overflow -> tighten
+            self._slack = max(self._slack, 0.0) * 3.0 + 2.0 if (st & 1) else max(self._slack / 3.0, 0.0)
+            self._left -= 1
+            self._run(self._slack)
+        self._run = None
+        return self._scores, self._ids
+
+
 def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k: int, id_offset: int = 0,
-               sel_slack: float = 6.0, max_retries: int = 3, scan_image: Optional[torch.Tensor] = None):
+               sel_slack: float = 6.0, max_retries: int = 3, scan_image: Optional[torch.Tensor] = None,
+               defer: bool = False):
     """Top-k inner-product ADC search of `q` [nq,D] against uint8 `codes` [N,M].
     Returns (scores [nq,k] fp32, ids [nq,k] int64), sorted (score desc, id asc).
     evaluate_repconc.py:180-185 / finetune_jpq.py:176.
-    scan_image: the index's permuted code image (adc_scan_image_), kept by PQIndex; None = rebuilt per call."""
+    scan_image: the index's permuted code image (adc_scan_image_), kept by PQIndex; None = rebuilt per call.
+    defer: return a `PendingSearch` instead (no host synchronisation here; `.result()` gives the pair)."""
     _need_cuda(codes, centroids, q, scan_image)
     if codes.dtype != torch.uint8 or not codes.is_contiguous():
         raise ValueError("index codes must be contiguous uint8 [N, M]")
@@ -438,23 +467,22 @@ def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k:
     lib, h, s, _ = _ctx(q)
     scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-    if nq == 0:
-        return scores, ids
-    if N == 0:
-        return scores.fill_(float("-inf")), ids.fill_(-1)
+    if nq == 0 or N == 0:
+        if nq and N == 0:
+            scores.fill_(float("-inf"))
+            ids.fill_(-1)
+        return PendingSearch(None, scores, ids, None, 0.0, 0) if defer else (scores, ids)
     wsb = (lib.rc_adc_search_img_ws_bytes if scan_image is not None else lib.rc_adc_search_ws_bytes)(N, M, K, nq, k)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
     status = torch.zeros((1,), dtype=torch.int32, device=q.device)
-    slack = float(sel_slack)
-    for _ in range(max_retries + 1):
+
+    def run(slack):
+        # the workspace is released when this returns: the caching allocator hands it out again in stream order only
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
         status.zero_()
         _lib.check(lib.rc_adc_search_img(h, _p(codes), _p(scan_image), N, M, K, _p(c), D, _p(q), nq, int(k),
-                                         int(id_offset), slack, _p(scores), _p(ids), _p(status), _p(ws), wsb, s),
+                                         int(id_offset), float(slack), _p(scores), _p(ids), _p(status), _p(ws), wsb, s),
                    "rc_adc_search_img", h)
-        st = int(status.item())
-        if st == 0:
-            return scores, ids
-        # bit0: too few candidates (threshold too high) -> widen; bit1: overflow -> tighten
-        slack = slack * 3.0 + 2.0 if (st & 1) else max(slack / 3.0, 0.0)
-    raise _lib.RepconcHipError(f"ADC candidate selection did not converge (status {st}); "
-                               "the index probably holds thousands of identical codes")
+
+    run(float(sel_slack))
+    pending = PendingSearch(run, scores, ids, status, float(sel_slack), max_retries)
+    return pending if defer else pending.result()

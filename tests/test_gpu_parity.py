@@ -1575,3 +1575,40 @@ def test_end_to_end_code_flips_from_the_rotation_gemm_are_counted():
     flips_cpu = float((c_dev != c_cpu).mean())
     print(f"rotation GEMM: max rel error {rel:.2e}; code flips vs fp64 rotation {flips_f64:.2e}, vs torch-CPU GEMM {flips_cpu:.2e}")
     assert flips_f64 < 2e-4 and flips_cpu < 2e-4
+
+
+def test_deferred_search_and_the_retry_path():
+    """`adc_search(defer=True)` / `PQIndex.search_async` give the results of the immediate call, and a sampled threshold
+    that admits too few candidates (forced with a hugely negative slack: rank 1 of the sample) is repaired by the retry
+    inside `result()` — the answer is still the oracle's."""
+    from repconc_amd import ops
+    from repconc_amd.index import PQIndex
+    from repconc_amd.models.repconc.evaluate_repconc import batch_search, search
+    N, M, nq, k = 400000, 48, 24, 100
+    rng = np.random.default_rng(77)
+    codes = rng.integers(0, 256, (N, M), dtype=np.uint8)
+    C = rng.standard_normal((M, 256, 16), dtype=np.float32)
+    q = rng.standard_normal((nq, 768), dtype=np.float32)
+    want_s, want_i = c_oracle.adc_search(codes, C, q, k)
+    now_s, now_i = ops.adc_search(_t(codes), _t(C), _t(q), k)
+    pend = ops.adc_search(_t(codes), _t(C), _t(q), k, defer=True)
+    assert isinstance(pend, ops.PendingSearch)
+    later_s, later_i = pend.result()
+    assert torch.equal(now_i, later_i) and torch.equal(now_s, later_s)
+    assert np.array_equal(now_i.cpu().numpy(), want_i)
+    assert np.array_equal(now_s.cpu().numpy().view(np.uint32), want_s.view(np.uint32))
+    tight = ops.adc_search(_t(codes), _t(C), _t(q), k, sel_slack=-1e6, defer=True)     # threshold = best sample score
+    assert int(tight._status.item()) & 1                                               # too few candidates ...
+    ts, ti = tight.result()                                                            # ... repaired by the retry
+    assert np.array_equal(ti.cpu().numpy(), want_i)
+    with pytest.raises(Exception):
+        ops.adc_search(_t(codes), _t(C), _t(q), k, sel_slack=-1e6, max_retries=0)
+    # batch_search: all batches enqueued, then read == batch by batch
+    idx = PQIndex(768, M)
+    idx.set_centroids(_t(C))
+    idx.add_codes(_t(codes))
+    qid, cid = np.arange(nq), np.arange(N)[::-1].copy()
+    s1, i1 = batch_search(qid, q, cid, idx, k, 7)
+    parts = [search(qid[a:a + 6], q[a:a + 6], cid, idx, k) for a in range(0, nq, 6)]
+    assert np.array_equal(i1, np.concatenate([p[1] for p in parts])) and np.array_equal(i1, cid[want_i])
+    assert np.array_equal(s1, np.concatenate([p[0] for p in parts]))
