@@ -92,13 +92,22 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # RC_BENCH_SHARE_GPU=1 (development only, flagged in the line): every rank on cuda:0 with gloo collectives, to walk
+    # the N > 1 branches of this file on a one-GPU box; RCCL refuses two ranks on one device, so the native solve's probe
+    # fails there and the staged driver runs.  The numbers of such a run mean nothing.
+    share_gpu = os.environ.get("RC_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         comm = TorchDistComm()
     else:
         comm = SingleComm()
@@ -257,14 +266,18 @@ def main():
                                "49152x768 batches (180 = 8.84M corpus), M=48 K=256 eps=0.003 T=100",
                    "global_batch": B, "rows_per_gpu": bl, "D": D, "M": M, "K": K, "sk_iters": ITERS,
                    "parallelism": f"batch-sharded x{world}, all-gather of [M,K] f64 row sums per iteration"
-                                  + (", RCCL driven from C, two chains of M/2 sub-quantisers on two streams "
-                                     "(all-gathers overlap sweeps)" if use_dist else "")},
+                                  + ((", RCCL driven from C, two chains of M/2 sub-quantisers on two streams "
+                                      "(all-gathers overlap sweeps)" if os.environ.get("RC_DIST_NATIVE", "1") != "0" else
+                                      ", python-staged torch.distributed loop (the native driver did not pass the probe)")
+                                     if use_dist else "")},
         "sub_assignments_per_sec": round(value * M, 1),
         "max_code_imbalance": round(imb, 4),
         "roofline": roofline,
     }
     if dist_check is not None:
         out["multi_gpu_check"] = dist_check
+    if share_gpu:
+        out["test_mode"] = "RC_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo - a walk through the N > 1 code, not a measurement"
 
     # ------------------------------------------------------------------ the 8-GPU recipe's per-rank shape on this GPU
     if not use_dist and B == B_GLOBAL and not args.no_per_rank:
