@@ -121,6 +121,23 @@ class IVFPQIndex:
         ivf.set_lists(flat.codes, coarse_assign(xt, ivf.coarse))
         return ivf
 
+    def to(self, device) -> "IVFPQIndex":
+        """A full copy of the index on another device (device-to-device copies, over xGMI where peers are connected)."""
+        device = torch.device(device)
+        out = IVFPQIndex(self.d, self.M, self.nlist, device=device)
+        out.coarse = None if self.coarse is None else self.coarse.to(device)
+        out.pq_centroids = self.pq_centroids.to(device).clone()
+        out.codes, out.ids = self.codes.to(device), self.ids.to(device)
+        out.list_off = self.list_off.to(device)
+        out.ntotal = self.ntotal
+        if self.image is not None:                      # the permutation of row n depends on n mod 16 only: copy, not rebuild
+            out.image = self.image.to(device)
+        if device == self.device:                       # same device (virtual replica in the tests): real copies
+            out.codes, out.ids, out.list_off = out.codes.clone(), out.ids.clone(), out.list_off.clone()
+            out.image = None if out.image is None else out.image.clone()
+            out.coarse = None if out.coarse is None else out.coarse.clone()
+        return out
+
     # ---- search
     def probe(self, q: torch.Tensor, nprobe: int) -> torch.Tensor:
         """[nq, nprobe] cells by decreasing <q, centroid> (ties: lower cell id), int32."""

@@ -155,3 +155,43 @@ class ShardedPQIndex(_MultiIndex):
         if as_numpy:
             return scores.cpu().numpy(), ids.cpu().numpy()
         return scores.to(q.device) if q.is_cuda else scores, ids.to(q.device) if q.is_cuda else ids
+
+
+class ReplicatedIVFPQIndex:
+    """The IVF index of BASELINE configs[3] ("IVF nlist=5000 ADC search at 8 GPUs") in one process: a full copy of the
+    `IVFPQIndex` per device, every query batch split into contiguous slices searched concurrently, results concatenated
+    in query order — what `ReplicatedPQIndex` does for the flat index, with `search(x, k, nprobe)`."""
+
+    def __init__(self, index, devices: Optional[Sequence[int]] = None):
+        devices = list(devices) if devices is not None else _visible_devices()
+        self.parts = []
+        for d in devices:
+            same = index.device.index == d and not any(p is index for p in self.parts)
+            self.parts.append(index if same else index.to(torch.device("cuda", d)))
+        self.device, self.d, self.M, self.nlist = index.device, index.d, index.M, index.nlist
+        self._pool = ThreadPoolExecutor(max_workers=len(self.parts))
+
+    @property
+    def ntotal(self):
+        return self.parts[0].ntotal
+
+    def search(self, x, k: int, nprobe: int, method: str = "auto"):
+        as_numpy = not isinstance(x, torch.Tensor)
+        q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if as_numpy else x.float()
+        nq, G = q.shape[0], len(self.parts)
+        bounds = [(nq * i) // G for i in range(G + 1)]
+        jobs = [(self.parts[i], q[bounds[i]:bounds[i + 1]]) for i in range(G) if bounds[i + 1] > bounds[i]] or [(self.parts[0], q)]
+
+        def one(job):
+            part, qq = job
+            with torch.cuda.device(part.device):
+                s, i = part.search(qq.to(part.device, non_blocking=True), int(k), int(nprobe), method)
+                torch.cuda.current_stream(part.device).synchronize()
+                return s, i
+        res = [one(jobs[0])] if len(jobs) == 1 else list(self._pool.map(one, jobs))
+        home = self.parts[0].device
+        scores = torch.cat([r[0].to(home) for r in res], 0)
+        ids = torch.cat([r[1].to(home) for r in res], 0)
+        if as_numpy:
+            return scores.cpu().numpy(), ids.cpu().numpy()
+        return (scores.to(q.device), ids.to(q.device)) if q.is_cuda else (scores, ids)

@@ -1612,3 +1612,29 @@ def test_deferred_search_and_the_retry_path():
     parts = [search(qid[a:a + 6], q[a:a + 6], cid, idx, k) for a in range(0, nq, 6)]
     assert np.array_equal(i1, np.concatenate([p[1] for p in parts])) and np.array_equal(i1, cid[want_i])
     assert np.array_equal(s1, np.concatenate([p[0] for p in parts]))
+
+
+def test_replicated_ivf_index_splits_the_queries_over_the_replicas():
+    """BASELINE configs[3] in one process: a full IVF copy per device (here three virtual replicas on cuda:0), the query
+    batch split across them, results identical to the single index for numpy and tensor queries."""
+    from repconc_amd.ivf import IVFPQIndex
+    from repconc_amd.multi_index import ReplicatedIVFPQIndex
+    N, M, nlist, nq = 300000, 96, 200, 41
+    codes = synth.uniform_codes(801, N, M)
+    cells = np.random.default_rng(802).integers(0, nlist, N)
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(synth.gaussian(803, (M, 256, 768 // M)))
+    ivf.coarse = _t(synth.gaussian(804, (nlist, 768)))
+    ivf.set_lists(_t(codes), _t(cells))
+    rep = ReplicatedIVFPQIndex(ivf, devices=[0, 0, 0])
+    assert rep.ntotal == N and rep.parts[0] is ivf and rep.parts[1] is not ivf
+    assert rep.parts[1].codes.data_ptr() != ivf.codes.data_ptr() and torch.equal(rep.parts[2].image, ivf.image)
+    q = synth.gaussian(805, (nq, 768))
+    for nprobe, k in ((4, 10), (60, 300)):
+        s1, i1 = ivf.search(_t(q), k, nprobe)
+        s2, i2 = rep.search(_t(q), k, nprobe)
+        s3, i3 = rep.search(q, k, nprobe)
+        assert torch.equal(i1, i2) and torch.equal(s1, s2)
+        assert np.array_equal(i3, i1.cpu().numpy()) and np.array_equal(s3, s1.cpu().numpy())
+    s4, i4 = rep.search(q[:2], 5, 8)                      # fewer queries than replicas
+    assert np.array_equal(i4, ivf.search(q[:2], 5, 8)[1])
