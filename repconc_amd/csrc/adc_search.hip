@@ -962,8 +962,8 @@ struct adc_ivf_tasks {
     const uint8_t* qbyte;        // [nq][NP][256][SLOTS] per-query byte tables in slot layout
 };
 
-template <int M, int NP, int R, bool IVF = false>
-__global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_t* __restrict__ image, int64_t N,
+template <int M, int NP, int R, bool IVF = false, int THREADS = ADC_THREADS>
+__global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t* __restrict__ image, int64_t N,
                                                                     const uint8_t* __restrict__ qlut,
                                                                     const int* __restrict__ tint, int nq,
                                                                     unsigned* __restrict__ id_count,
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_
     using L = adc_cf<PM>;
     constexpr int STEPS = L::STEPS, NW = STEPS * ADC_IMG_ES / 4;   // code dwords per lane per chunk and phase
     static_assert(STEPS % 4 == 0, "whole dwords of codes per lane");
-    constexpr int NWAVES = ADC_THREADS / 64;
+    constexpr int NWAVES = THREADS / 64;
     constexpr int ROUND = NWAVES * R * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_
         if constexpr (!IVF) {
             const uint4* src = reinterpret_cast<const uint4*>(qsrc + (size_t)phase * L::TABLE_BYTES);
             uint4* dst = reinterpret_cast<uint4*>(smem);
-            for (int i = tid; i < L::TABLE_BYTES / 16; i += ADC_THREADS) {
+            for (int i = tid; i < L::TABLE_BYTES / 16; i += THREADS) {
                 uint4 v = src[i];
                 v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;   // l -> l - 128 (signed)
                 dst[i] = v;
@@ -1001,11 +1001,21 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_screen_cf_kernel(const uint8_
             // the LDS entry of one (code, slot) is the 8 queries' bytes side by side (two 4 x 4 byte transposes by v_perm)
             constexpr int QB = RC_K * L::SLOTS;                 // bytes of one query's table phase
             uint4* dst = reinterpret_cast<uint4*>(smem);
-            for (int i = tid; i < QB / 4; i += ADC_THREADS) {
-                unsigned d[8];
+            // all QB / 4 / THREADS x 8 loads of the thread are issued before the first transpose: the per-query tables
+            // (nq x 32 KiB) live in the memory-side cache at best, and a task is short (one cell) - with the loop rolled the
+            // fill was four dependent ~2 us round trips per phase, three quarters of a task's time
+            constexpr int FI = QB / 4 / THREADS;
+            static_assert(QB / 4 % THREADS == 0, "whole iterations");
+            unsigned dd[FI][8];
+#pragma unroll
+            for (int f = 0; f < FI; ++f)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    d[j] = tqid[j] >= 0 ? reinterpret_cast<const unsigned*>(T.qbyte + ((size_t)tqid[j] * NP + phase) * QB)[i] : 0u;
+                    dd[f][j] = tqid[j] >= 0 ? reinterpret_cast<const unsigned*>(T.qbyte + ((size_t)tqid[j] * NP + phase) * QB)[tid + f * THREADS] : 0u;
+#pragma unroll
+            for (int f = 0; f < FI; ++f) {
+                const int i = tid + f * THREADS;
+                const unsigned (&d)[8] = dd[f];
                 unsigned o[8];                                   // o[2 t] = queries 0-3 of entry t, o[2 t + 1] = queries 4-7
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
@@ -1239,6 +1249,10 @@ struct adc_ws_layout {
 static int adc_qs_for(int M) { (void)M; return 16; }   // table groups are sized for 16 queries (covers the 8- and 4-query kernels)
 // conflict-free screen (adc_screen_cf_kernel): M = 16, 32, 48, 64 in one table phase, 96 in two
 static bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M == 64 || M == 96; }
+// M = 96: two phases of 48 sub-quantisers (128 KiB of tables, one 1024-thread block per CU).  Tried and rejected in round 2:
+// three phases of 32 (64 KiB of tables, TWO 512-thread blocks per CU so that one block's refill hides behind the other's
+// gathers; 126 VGPRs, no spills, both blocks resident): 39 ms instead of 27 ms per 1200 queries flat, no change for the IVF
+// tasks — twice the refills per row and a third exposed code load per round cost more than the overlap returns.
 static int adc_cf_phase_m(int M) { return M == 96 ? 48 : M; }
 static size_t adc_cf_table_bytes(int M) {                  // per group of 8 queries, all phases
     const int PM = adc_cf_phase_m(M);
@@ -1378,8 +1392,9 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
     if (CF && image != nullptr) {
         if constexpr (CF) {
             constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP;
-            constexpr int R = (NP == 2) ? 8 : ((M == 64 || (ADC_IMG_ES == 2 && M == 48)) ? 2 : 4);   // register budget
-            auto kern = adc_screen_cf_kernel<M, NP, R>;
+            constexpr int R = (NP > 1) ? 8 : ((M == 64 || (ADC_IMG_ES == 2 && M == 48)) ? 2 : 4);   // register budget
+            constexpr int TH = ADC_THREADS;
+            auto kern = adc_screen_cf_kernel<M, NP, R, false, TH>;
             constexpr int sl = adc_cf<PM>::TABLE_BYTES;
             hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, b.qstat, b.tint);
             RC_LAUNCH_CHECK(h);
@@ -1389,7 +1404,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             const unsigned cf_tiles = (unsigned)((N + ADC_CF_TILE - 1) / ADC_CF_TILE);
-            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 7) / 8), cf_tiles), dim3(ADC_THREADS), sl, s, image, N, b.qlut,
+            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 7) / 8), cf_tiles), dim3(TH), sl, s, image, N, b.qlut,
                                b.tint, nq, b.idcnt, b.ids, adc_ivf_tasks{});
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             RC_LAUNCH_CHECK(h);
@@ -1658,7 +1673,8 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
                 const int* rows, const int* rank, int nprobe, int64_t sstride, int ss, const adc_ivf_tasks& T, int ntasks,
                 int k, float* scores, int64_t* out_ids, int* status, char* w, const ivfl_ws& L, hipStream_t s) {
     constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP;
-    constexpr int R = (NP == 2) ? 8 : (M == 64 ? 2 : 4);
+    constexpr int R = (NP > 1) ? 8 : (M == 64 ? 2 : 4);
+    constexpr int TH = ADC_THREADS;
     float* sample = (float*)(w + L.sample);
     float* thr = (float*)(w + L.thr);
     int* tint = (int*)(w + L.tint);
@@ -1688,13 +1704,13 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     RC_HIP_CHECK(h, hipMemsetAsync(idcnt, 0, (size_t)nq * sizeof(unsigned), s));
     RC_HIP_CHECK(h, hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(unsigned), s));
     {
-        auto kern = adc_screen_cf_kernel<M, NP, R, true>;
+        auto kern = adc_screen_cf_kernel<M, NP, R, true, TH>;
         constexpr int sl = adc_cf<PM>::TABLE_BYTES;
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
         adc_ivf_tasks TT = T;
         TT.qbyte = qbyte;
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-        hipLaunchKernelGGL(kern, dim3((unsigned)ntasks), dim3(ADC_THREADS), sl, s, image, N, (const uint8_t*)nullptr,
+        hipLaunchKernelGGL(kern, dim3((unsigned)ntasks), dim3(TH), sl, s, image, N, (const uint8_t*)nullptr,
                            (const int*)tint, nq, idcnt, ids, TT);
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         RC_LAUNCH_CHECK(h);
