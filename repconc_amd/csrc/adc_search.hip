@@ -46,9 +46,11 @@
 #define RC_ADC_IMG16 0         // 1: the permuted code image holds 16-bit codes (one v_mad_u32_u16 per gather address instead of bfe + lshl_add)
 #endif
 #define ADC_IMG_ES (RC_ADC_IMG16 ? 2 : 1)   // bytes per code in the image
-#ifndef ADC_CF_TILE
-#define ADC_CF_TILE 65536     // rows per block of the conflict-free screen: a 65536 x 48 B tile (3 MiB) still fits the XCD's 4 MiB L2; half the table fills
-#endif
+// Rows per block of the conflict-free screen.  Consecutive query groups re-read the same tile of the code image, which
+// therefore has to stay in the XCD's 4 MiB L2: 3 MiB of image per tile.  (Round 2 first used 65536 rows for every M: at
+// M = 96 the 6 MiB tile was re-fetched from HBM by every group - FETCH_SIZE 64 GB per 1200-query launch against 2.3 GB at
+// M = 48.)  Multiples of 2048 rows (16 waves x 8 chunks x 16 rows).
+__host__ __device__ constexpr int adc_cf_tile_rows(int M) { return M > 64 ? 32768 : (M > 48 ? 49152 : 65536); }
 
 __device__ __forceinline__ unsigned adc_order_key(float s) {
     const unsigned u = __float_as_uint(s);
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(RC_K) void adc_qbyte_write_kernel(const float* __re
 
 typedef int adc_i32x4v __attribute__((ext_vector_type(4)));
 
-// grid (groups of 8 queries, row tiles of ADC_CF_TILE rows), XCD-remapped like the other screens.
+// grid (groups of 8 queries, row tiles of adc_cf_tile_rows(M) rows), XCD-remapped like the other screens.
 // A wave owns R chunks of 16 rows per round; lanes (r = l & 15, g = l >> 4).
 // IVF mode (list-centric scan of csrc/ivf_search.hip's index): a block is a TASK = (coarse cell, up to 8 of the queries that
 // probe it); its rows are the cell's row range, its byte tables are transposed on the fly from the per-query tables
@@ -1061,8 +1063,9 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
         // 32 bits are the LDS address), so the gather address below needs no further base add
         off[s] = (unsigned)slot * 8u + static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     }
-    int64_t t0 = (int64_t)btile * ADC_CF_TILE;
-    int64_t t1 = (t0 + ADC_CF_TILE < N) ? t0 + ADC_CF_TILE : N;
+    constexpr int TILE = adc_cf_tile_rows(M);
+    int64_t t0 = (int64_t)btile * TILE;
+    int64_t t1 = (t0 + TILE < N) ? t0 + TILE : N;
     unsigned row_lo = 0;                                      // rows of the tile before this are not the task's
     if constexpr (IVF) {
         const int cell = T.task_list[blockIdx.x];
@@ -1074,8 +1077,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     }
     // Flat sequence of steps it = round * NP + i; a round covers ROUND rows and visits the NP table phases, odd rounds in
     // reverse order, so the tables already in LDS are used first (NP - 1 refills per round).  The codes of step it + 1 are
-    // loaded while step it is gathered (NP == 1; with two phases the eight chunks' codes are loaded at the start of the
-    // step — registers).  All row arithmetic is 32-bit and relative to the tile (<= 32768 rows x M bytes).
+    // loaded while step it is gathered (NP == 1, two buffers) or right after its last gather (two phases, one buffer).  All row arithmetic is 32-bit and relative to the tile (<= 32768 rows x M bytes).
     const unsigned nrows = (unsigned)(t1 - t0);
     const int nrounds = (int)((nrows + ROUND - 1) / ROUND);
     const int nsteps = nrounds * NP;
@@ -1111,8 +1113,6 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
         }
         if constexpr (PREFETCH) {
             if (it + 1 < nsteps) load_step(it + 1, wn);
-        } else {
-            load_step(it, w);
         }
         // Software pipeline over the R chunks of the step: all STEPS gathers of chunk c + 1 are issued before the MFMAs
         // of chunk c, so a wave keeps a whole chunk of LDS reads in flight.  Address of a gather: two VALU instructions,
@@ -1154,6 +1154,12 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             if (c + 2 < R) gather(c + 2, ea);
             if (c + 1 < R) fold(c + 1, eb);
         }
+        if constexpr (!PREFETCH) {
+            // several table phases: one code buffer.  Its contents are dead once the last gather address is formed, so the
+            // next step's codes are requested here — their latency runs under the epilogue, the barrier and the table refill
+            // of the next step instead of in front of its first gather
+            if (it + 1 < nsteps) load_step(it + 1, w);
+        }
         if (it % NP == NP - 1) {
             // survivors are rare (~2e-4 of the (row, query) pairs): one max over the round's accumulators decides
             int top = INT_MIN;
@@ -1185,6 +1191,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             if (it + 1 < nsteps) run_step(it + 1, wb, wa, in_lds);
         }
     } else {
+        if (nsteps > 0) load_step(0, wa);
         for (int it = 0; it < nsteps; ++it) run_step(it, wa, wb, in_lds);
     }
 }
@@ -1252,7 +1259,10 @@ static bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M 
 // M = 96: two phases of 48 sub-quantisers (128 KiB of tables, one 1024-thread block per CU).  Tried and rejected in round 2:
 // three phases of 32 (64 KiB of tables, TWO 512-thread blocks per CU so that one block's refill hides behind the other's
 // gathers; 126 VGPRs, no spills, both blocks resident): 39 ms instead of 27 ms per 1200 queries flat, no change for the IVF
-// tasks — twice the refills per row and a third exposed code load per round cost more than the overlap returns.
+// tasks — twice the refills per row and a third exposed code load per round cost more than the overlap returns.  Also without
+// effect on the 27 ms: requesting the next step's codes before the refill, and an XCD mapping of 8 groups x 4 tiles that
+// keeps the tables L2-resident.  What the two-phase screen pays over 2 x the one-phase time (20 ms) is the pipeline
+// drain and ramp-up of 16 waves around the two barriers of every 2048-row round.
 static int adc_cf_phase_m(int M) { return M == 96 ? 48 : M; }
 static size_t adc_cf_table_bytes(int M) {                  // per group of 8 queries, all phases
     const int PM = adc_cf_phase_m(M);
@@ -1403,7 +1413,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             RC_LAUNCH_CHECK(h);
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-            const unsigned cf_tiles = (unsigned)((N + ADC_CF_TILE - 1) / ADC_CF_TILE);
+            const unsigned cf_tiles = (unsigned)((N + adc_cf_tile_rows(M) - 1) / adc_cf_tile_rows(M));
             hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 7) / 8), cf_tiles), dim3(TH), sl, s, image, N, b.qlut,
                                b.tint, nq, b.idcnt, b.ids, adc_ivf_tasks{});
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
