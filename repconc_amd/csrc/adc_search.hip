@@ -50,7 +50,10 @@
 // therefore has to stay in the XCD's 4 MiB L2: 3 MiB of image per tile.  (Round 2 first used 65536 rows for every M: at
 // M = 96 the 6 MiB tile was re-fetched from HBM by every group - FETCH_SIZE 64 GB per 1200-query launch against 2.3 GB at
 // M = 48.)  Multiples of 2048 rows (16 waves x 8 chunks x 16 rows).
-__host__ __device__ constexpr int adc_cf_tile_rows(int M) { return M > 64 ? 32768 : (M > 48 ? 49152 : 65536); }
+#ifndef ADC_T96
+#define ADC_T96 32768
+#endif
+__host__ __device__ constexpr int adc_cf_tile_rows(int M) { return M > 64 ? ADC_T96 : (M > 48 ? 49152 : 65536); }
 
 __device__ __forceinline__ unsigned adc_order_key(float s) {
     const unsigned u = __float_as_uint(s);
