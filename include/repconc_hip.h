@@ -297,6 +297,18 @@ int rc_ivf_search_lists(rc_handle_t h, const uint8_t* codes, const uint8_t* imag
                         int64_t sstride, int ss, const int* task_list, const int* task_qstart, const int* task_qcnt,
                         const int* sorted_q, int ntasks, int k, float* scores, int64_t* out_ids, int* status, void* ws,
                         size_t ws_bytes, rc_stream_t stream);
+/* The same search with the plan made on the device: sample layout, threshold ranks and the task list are derived from
+ * `probes` by four small kernels (no host round trip).  probes [nq,nprobe]: distinct cells per query, nprobe <= nlist;
+ * sstride: capacity of a query's sample array, >= the largest possible number of sampled rows of nprobe cells;
+ * sel_slack: standard deviations of head-room in the threshold rank (6 is the default of the Python wrapper);
+ * keep_all_rows: queries probing no more rows than this re-score every probed row.  Status bits and results as above.
+ * ws: rc_ivf_search_probes_ws_bytes(M, nq, nprobe, nlist, sstride). */
+size_t rc_ivf_search_probes_ws_bytes(int M, int nq, int nprobe, int nlist, int64_t sstride);
+int rc_ivf_search_probes(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
+                         const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
+                         const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
+                         int keep_all_rows, float* scores, int64_t* out_ids, int* status, void* ws, size_t ws_bytes,
+                         rc_stream_t stream);
 size_t rc_ivf_search_ws_bytes(int nq, int64_t stride);
 int rc_ivf_search(rc_handle_t h, const uint8_t* codes, const int64_t* list_off, const int64_t* ids, int64_t N,
                   int M, int K, const float* lut, const int* probes, const int* base, const int* count, int nq,

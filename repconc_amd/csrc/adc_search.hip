@@ -989,6 +989,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     int tqid[8];
     if constexpr (IVF) {
         const int qs = T.task_qstart[blockIdx.x], qc = T.task_qcnt[blockIdx.x];
+        if (qc <= 0) return;                                  // padding of a device-planned task list (block-uniform)
 #pragma unroll
         for (int j = 0; j < 8; ++j) tqid[j] = (j < qc) ? T.sorted_q[qs + j] : -1;
     }
@@ -1169,17 +1170,51 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
 #pragma unroll
             for (int c = 0; c < R; ++c) top = max(top, max(max(acc[c][0], acc[c][1]), max(acc[c][2], acc[c][3])));
             if (__ballot(top >= tq)) {
+                // Flat search: survivors are rare (~2e-4), one atomic each.  IVF: a query keeps a few per cent of the rows it
+                // probes, and one atomic per survivor on 1200 counters was half of the screen's time (nprobe 32) - there the
+                // four lanes (r, g = 0..3) of a query reserve their slots with ONE atomic per wave and round.
                 const unsigned r0 = (unsigned)(it / NP) * ROUND + (unsigned)(wv * R * 16);
+                if constexpr (!IVF) {
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned n = r0 + 16u * c + 4u * g + e;   // D[row = 4 g + e][column = r]
+                            if (acc[c][e] >= tq && n < nrows && n >= row_lo) {
+                                const unsigned slot = atomicAdd(id_count + myq, 1u);
+                                if (slot < ADC_ID_CAP) ids[(size_t)myq * ADC_ID_CAP + slot] = (unsigned)(t0 + n);
+                            }
+                        }
+                    }
+                } else {
+                unsigned mine = 0;
 #pragma unroll
                 for (int c = 0; c < R; ++c) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const unsigned n = r0 + 16u * c + 4u * g + e;   // D[row = 4 g + e][column = r]
-                        if (acc[c][e] >= tq && n < nrows && n >= row_lo) {
-                            const unsigned slot = atomicAdd(id_count + myq, 1u);
-                            if (slot < ADC_ID_CAP) ids[(size_t)myq * ADC_ID_CAP + slot] = (unsigned)(t0 + n);
+                        mine += (acc[c][e] >= tq && n < nrows && n >= row_lo) ? 1u : 0u;
+                    }
+                }
+                const unsigned c0 = __shfl(mine, r), c1 = __shfl(mine, r + 16), c2 = __shfl(mine, r + 32), c3 = __shfl(mine, r + 48);
+                const unsigned total = c0 + c1 + c2 + c3;
+                unsigned base = 0;
+                if (g == 0 && total) base = atomicAdd(id_count + myq, total);      // total > 0 implies a live query
+                base = __shfl(base, r);
+                unsigned slot = base + (g > 0 ? c0 : 0u) + (g > 1 ? c1 : 0u) + (g > 2 ? c2 : 0u);
+                if (mine) {
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned n = r0 + 16u * c + 4u * g + e;
+                            if (acc[c][e] >= tq && n < nrows && n >= row_lo) {
+                                if (slot < ADC_ID_CAP) ids[(size_t)myq * ADC_ID_CAP + slot] = (unsigned)(t0 + n);
+                                ++slot;
+                            }
                         }
                     }
+                }
                 }
             }
         }
@@ -1574,8 +1609,11 @@ extern "C" int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint
 // grid (nq, slices): the query's sample entries 0 .. scount[qi] are dealt to the threads of its blocks; an entry finds its
 // cell by binary search over the query's sbase row (no per-cell loop: a probed cell contributes only a few dozen sampled
 // rows, and walking the cells one after the other would serialise two dependent loads per cell).
+// 1024 threads: the 4 M 256-byte table takes the CU's LDS, so the block is also the CU's whole occupancy (256 threads: 0.47 ms
+// per 1200 queries at nprobe 32, four waves per CU waiting on their row reads)
+#define IVF_SAMPLE_THREADS 1024
 template <int M>
-__global__ __launch_bounds__(256) void ivf_sample_scan_kernel(const uint8_t* __restrict__ codes,
+__global__ __launch_bounds__(IVF_SAMPLE_THREADS) void ivf_sample_scan_kernel(const uint8_t* __restrict__ codes,
                                                               const int64_t* __restrict__ list_off,
                                                               const float* __restrict__ lut, const int* __restrict__ probes,
                                                               const int* __restrict__ sbase, const int* __restrict__ scount,
@@ -1584,12 +1622,12 @@ __global__ __launch_bounds__(256) void ivf_sample_scan_kernel(const uint8_t* __r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tab = reinterpret_cast<float*>(smem);   // [M][256]
     const int qi = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < M * RC_K; i += 256) tab[i] = lut[(size_t)qi * M * RC_K + i];
+    for (int i = tid; i < M * RC_K; i += IVF_SAMPLE_THREADS) tab[i] = lut[(size_t)qi * M * RC_K + i];
     __syncthreads();
     const int n = scount[qi];
     const int* sb = sbase + (size_t)qi * nprobe;
     const int* pr = probes + (size_t)qi * nprobe;
-    for (int i = blockIdx.y * 256 + tid; i < n; i += gridDim.y * 256) {
+    for (int i = blockIdx.y * IVF_SAMPLE_THREADS + tid; i < n; i += gridDim.y * IVF_SAMPLE_THREADS) {
         int lo = 0, hi = nprobe - 1;                              // last probe p with sbase[p] <= i
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -1704,7 +1742,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
         // every block stages the query's 4 M 256-byte fp32 table: as few slices per query as keep ~2048 sampled rows each
         int64_t slices = (sstride + 2047) / 2048;
         if (slices > 16) slices = 16;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nq, (unsigned)(slices < 1 ? 1 : slices)), dim3(256), lds, s, codes, list_off, lut,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nq, (unsigned)(slices < 1 ? 1 : slices)), dim3(IVF_SAMPLE_THREADS), lds, s, codes, list_off, lut,
                            probes, sbase, scount, nprobe, sstride, ss, sample);
         RC_LAUNCH_CHECK(h);
     }
@@ -1783,6 +1821,210 @@ extern "C" int rc_ivf_search_lists(rc_handle_t h, const uint8_t* codes, const ui
                                         nprobe, sstride, ss, T, ntasks, k, scores, out_ids, status, w, L, s);
         IVFL_CASE(16) IVFL_CASE(32) IVFL_CASE(48) IVFL_CASE(64) IVFL_CASE(96)
 #undef IVFL_CASE
+        default: return RC_ESHAPE;
+    }
+}
+
+// ------------------------------------------------------------------------------------ device-side plan of the search
+// rc_ivf_search_probes: everything rc_ivf_search_lists expects from its caller (sample layout, ranks, the task list) is
+// derived on the device from the probes alone - four small kernels instead of ~40 framework launches and two host
+// synchronisations (task count, sample stride) per search.
+namespace {
+struct ivfp_ws {
+    size_t sbase, scount, rows, rank, per_cell, cell_start, first_task, cursor, ntasks, sorted_q, task_list, task_qstart,
+        task_qcnt, total;
+    int64_t ub;
+};
+ivfp_ws ivfp_layout(size_t base, int nq, int nprobe, int nlist) {
+    ivfp_ws P;
+    const size_t pairs = (size_t)nq * nprobe;
+    size_t ub = (size_t)nlist + pairs / 8 + 1;                // tasks: at most one partly filled group per probed cell
+    if (ub > pairs) ub = pairs;
+    P.ub = (int64_t)ub;
+    size_t o = base;
+    auto take = [&](size_t n) { const size_t at = o; o += rc_align_up(n * sizeof(int), 256); return at; };
+    P.sbase = take(pairs); P.scount = take(nq); P.rows = take(nq); P.rank = take(nq);
+    P.per_cell = take(nlist); P.cursor = take(nlist);         // adjacent: one memset clears both
+    P.cell_start = take(nlist); P.first_task = take(nlist); P.ntasks = take(1);
+    P.sorted_q = take(pairs); P.task_list = take(ub); P.task_qstart = take(ub); P.task_qcnt = take(ub);
+    P.total = o;
+    return P;
+}
+}  // namespace
+
+// exclusive scan of one int per thread over a 256-thread block; returns the block total through `total`
+__device__ __forceinline__ int ivfp_block_scan256(int v, int* s_wave, int& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) before += (j < wv) ? s_wave[j] : 0;
+    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return before + inc - v;
+}
+
+// One block per query: sample layout of its probes, totals, threshold rank; counts the queries probing every cell.
+__global__ __launch_bounds__(256) void ivf_plan_query_kernel(const int64_t* __restrict__ list_off, const int* __restrict__ probes,
+                                                             int nprobe, int ss, int k, double slack, int keep_all_rows,
+                                                             int* __restrict__ sbase, int* __restrict__ scount,
+                                                             int* __restrict__ rows, int* __restrict__ rank,
+                                                             int* __restrict__ per_cell) {
+    __shared__ int s_wave[4];
+    __shared__ long long s_rows[4];
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    int carry = 0;
+    long long rsum = 0;
+    for (int b0 = 0; b0 < nprobe; b0 += 256) {                // block-uniform
+        const int p = b0 + tid;
+        int ssz = 0;
+        long long size = 0;
+        if (p < nprobe) {
+            const int c = probes[(size_t)qi * nprobe + p];
+            size = list_off[c + 1] - list_off[c];
+            const long long run = 16ll * ss, rem = size % run;
+            ssz = (int)(16ll * (size / run) + (rem < 16 ? rem : 16));
+            atomicAdd(per_cell + c, 1);
+        }
+        int total;
+        const int ex = ivfp_block_scan256(ssz, s_wave, total);
+        if (p < nprobe) sbase[(size_t)qi * nprobe + p] = carry + ex;
+        carry += total;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) size += __shfl_xor(size, o);
+        if ((tid & 63) == 0) s_rows[tid >> 6] = size;             // per-wave totals of the row counts
+        __syncthreads();
+        rsum += s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const long long r = rsum > 0x7FFFFFFFll ? 0x7FFFFFFFll : rsum;
+        scount[qi] = carry;
+        rows[qi] = (int)r;
+        // rank of the sample score used as threshold: mu = expected number of the k best among the sampled rows; queries
+        // whose probed rows fit the candidate list comfortably keep every row (rank 0 -> threshold -inf)
+        const double den = (double)(r > 0 ? r : 1);
+        const double mu = (double)k * (double)carry / den;
+        double rk = floor(mu + slack * sqrt(mu + 1.0) + 4.0) + 1.0;
+        const double cap = floor(0.8 * (double)ADC_CAND_CAP * (double)carry / den);
+        if (rk > cap && cap >= mu + 2.5 * sqrt(mu + 1.0) + 2.0) rk = cap;
+        if (rk > (double)carry) rk = (double)carry;
+        if (rk < 0.0) rk = 0.0;
+        rank[qi] = (r <= keep_all_rows) ? 0 : (int)rk;
+    }
+}
+
+// One block: exclusive prefix sums over the cells of (queries probing the cell) and of (tasks of the cell).
+__global__ __launch_bounds__(256) void ivf_plan_cells_kernel(const int* __restrict__ per_cell, int nlist,
+                                                             int* __restrict__ cell_start, int* __restrict__ first_task,
+                                                             int* __restrict__ ntasks) {
+    __shared__ int s_wave[4];
+    int cq = 0, ct = 0;
+    for (int b0 = 0; b0 < nlist; b0 += 256) {
+        const int c = b0 + (int)threadIdx.x;
+        const int n = c < nlist ? per_cell[c] : 0, t = (n + 7) / 8;
+        int tq, tt;
+        const int eq = ivfp_block_scan256(n, s_wave, tq);
+        const int et = ivfp_block_scan256(t, s_wave, tt);
+        if (c < nlist) { cell_start[c] = cq + eq; first_task[c] = ct + et; }
+        cq += tq;
+        ct += tt;
+    }
+    if (threadIdx.x == 0) *ntasks = ct;
+}
+
+// (query, probe) pairs bucketed by cell; the order inside a cell is whatever the atomics give — it only decides which
+// queries share a task, never a result.
+__global__ __launch_bounds__(256) void ivf_plan_scatter_kernel(const int* __restrict__ probes, int64_t pairs, int nprobe,
+                                                               const int* __restrict__ cell_start, int* __restrict__ cursor,
+                                                               int* __restrict__ sorted_q) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pairs) return;
+    const int c = probes[i];
+    sorted_q[cell_start[c] + atomicAdd(cursor + c, 1)] = (int)(i / nprobe);
+}
+
+// task t -> (cell, first entry in sorted_q, number of queries); tasks past the device-side count get 0 queries
+__global__ __launch_bounds__(256) void ivf_plan_tasks_kernel(const int* __restrict__ per_cell, const int* __restrict__ cell_start,
+                                                             const int* __restrict__ first_task, const int* __restrict__ ntasks,
+                                                             int nlist, int64_t ub, int* __restrict__ task_list,
+                                                             int* __restrict__ task_qstart, int* __restrict__ task_qcnt) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ub) return;
+    int cell = 0, qs = 0, qc = 0;
+    if (t < *ntasks) {
+        int lo = 0, hi = nlist;                               // last cell with first_task <= t (the non-empty one of a plateau)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (first_task[mid] <= (int)t) lo = mid; else hi = mid;
+        }
+        cell = lo;
+        const int within = (int)t - first_task[cell];
+        qs = cell_start[cell] + 8 * within;
+        qc = per_cell[cell] - 8 * within;
+        qc = qc > 8 ? 8 : qc;
+    }
+    task_list[t] = cell;
+    task_qstart[t] = qs;
+    task_qcnt[t] = qc;
+}
+
+extern "C" size_t rc_ivf_search_probes_ws_bytes(int M, int nq, int nprobe, int nlist, int64_t sstride) {
+    if (!adc_cf_supported(M) || nq <= 0 || nprobe <= 0 || nlist <= 0 || sstride <= 0) return 0;
+    return ivfp_layout(ivfl_layout(M, nq, sstride).total, nq, nprobe, nlist).total;
+}
+
+// rc_ivf_search_lists with the plan made on the device.  probes [nq, nprobe]: distinct cells per query; sstride: capacity of
+// a query's sample array, >= the largest possible number of sampled rows of nprobe cells (a cell of n rows contributes
+// 16 floor(n / 16 ss) + min(16, n mod 16 ss)); sel_slack: standard deviations of head-room in the threshold rank;
+// keep_all_rows: queries probing no more rows than this re-score every row.  Same status bits, same results.
+extern "C" int rc_ivf_search_probes(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
+                                    const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
+                                    const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
+                                    int keep_all_rows, float* scores, int64_t* out_ids, int* status, void* ws,
+                                    size_t ws_bytes, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !codes || !image || !list_off || !rowmap || !lut || !probes || !scores || !out_ids || !status || N <= 0 ||
+        nq < 0 || nprobe <= 0 || nlist <= 0 || nprobe > nlist || sstride <= 0 || ss <= 0 || k <= 0)
+        return RC_EINVAL;
+    if (K != RC_K || !adc_cf_supported(M) || k > ADC_CAND_CAP / 2 || N > 0xFFFFFFFFll || RC_ADC_IMG16) return RC_ESHAPE;
+    if (nq == 0) return RC_OK;
+    const ivfl_ws L = ivfl_layout(M, nq, sstride);
+    const ivfp_ws P = ivfp_layout(L.total, nq, nprobe, nlist);
+    if (!ws || ws_bytes < P.total) return RC_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)ws;
+    auto I = [&](size_t off) { return (int*)(w + off); };
+    const int64_t pairs = (int64_t)nq * nprobe;
+    RC_HIP_CHECK(h, hipMemsetAsync(w + P.per_cell, 0, P.cell_start - P.per_cell, s));      // per_cell and cursor
+    hipLaunchKernelGGL(ivf_plan_query_kernel, dim3((unsigned)nq), dim3(256), 0, s, list_off, probes, nprobe, ss, k, sel_slack,
+                       keep_all_rows, I(P.sbase), I(P.scount), I(P.rows), I(P.rank), I(P.per_cell));
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(ivf_plan_cells_kernel, dim3(1), dim3(256), 0, s, (const int*)I(P.per_cell), nlist, I(P.cell_start),
+                       I(P.first_task), I(P.ntasks));
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(ivf_plan_scatter_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, probes, pairs, nprobe,
+                       (const int*)I(P.cell_start), I(P.cursor), I(P.sorted_q));
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(ivf_plan_tasks_kernel, dim3((unsigned)((P.ub + 255) / 256)), dim3(256), 0, s, (const int*)I(P.per_cell),
+                       (const int*)I(P.cell_start), (const int*)I(P.first_task), (const int*)I(P.ntasks), nlist, P.ub,
+                       I(P.task_list), I(P.task_qstart), I(P.task_qcnt));
+    RC_LAUNCH_CHECK(h);
+    adc_ivf_tasks T = {I(P.task_list), I(P.task_qstart), I(P.task_qcnt), I(P.sorted_q), list_off, nullptr};
+    switch (M) {
+#define IVFP_CASE(MM)                                                                                                  \
+        case MM: return ivfl_launch<MM>(h, codes, image, list_off, rowmap, N, lut, nq, probes, I(P.sbase), I(P.scount),  \
+                                        I(P.rows), I(P.rank), nprobe, sstride, ss, T, (int)P.ub, k, scores, out_ids,  \
+                                        status, w, L, s);
+        IVFP_CASE(16) IVFP_CASE(32) IVFP_CASE(48) IVFP_CASE(64) IVFP_CASE(96)
+#undef IVFP_CASE
         default: return RC_ESHAPE;
     }
 }

@@ -92,6 +92,7 @@ class IVFPQIndex:
         cnt = torch.bincount(list_ids, minlength=self.nlist)
         self.list_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=self.device), torch.cumsum(cnt, 0)]).contiguous()
         self.ntotal = codes.shape[0]
+        self._sizes_desc = np.sort(cnt.cpu().numpy())[::-1].astype(np.int64)     # host copy: bounds the sample array
         self.image = None
         if ops.adc_image_supported(self.M) and self.ntotal:
             self.image = torch.empty((self.ntotal, ops.adc_image_row_bytes(self.M)), dtype=torch.uint8, device=self.device)
@@ -130,6 +131,7 @@ class IVFPQIndex:
         out.codes, out.ids = self.codes.to(device), self.ids.to(device)
         out.list_off = self.list_off.to(device)
         out.ntotal = self.ntotal
+        out._sizes_desc = self._sizes_desc
         if self.image is not None:                      # the permutation of row n depends on n mod 16 only: copy, not rebuild
             out.image = self.image.to(device)
         if device == self.device:                       # same device (virtual replica in the tests): real copies
@@ -163,15 +165,16 @@ class IVFPQIndex:
         nq = q.shape[0]
         nprobe = min(int(nprobe), self.nlist)
         probes = self.probe(q, nprobe)
-        if method not in ("auto", "lists", "scan"):
-            raise ValueError("method must be auto|lists|scan")
-        if method == "lists" and self.image is None:
+        if method not in ("auto", "lists", "lists_host_plan", "scan"):
+            raise ValueError("method must be auto|lists|lists_host_plan|scan")
+        if method in ("lists", "lists_host_plan") and self.image is None:
             raise _lib.RepconcHipError(f"the list-centric search needs M in (16, 32, 48, 64, 96), not {self.M}")
         if method == "auto" and self.image is not None:
             # few probed rows per query: the per-query scan has less fixed work (task list, per-query byte tables)
             method = "lists" if self.ntotal * nprobe / max(self.nlist, 1) >= self.LISTS_MIN_ROWS else "scan"
-        if method == "lists" and nq > 0:
-            scores, ids = self._search_lists(q, probes, int(k), nprobe)
+        if method in ("lists", "lists_host_plan") and nq > 0:
+            fn = self._search_lists if method == "lists" else self._search_lists_host_plan
+            scores, ids = fn(q, probes, int(k), nprobe)
             return (scores.cpu().numpy(), ids.cpu().numpy()) if as_numpy else (scores, ids)
         sizes = (self.list_off[1:] - self.list_off[:-1])[probes.long()]                      # [nq, nprobe]
         csum = torch.cumsum(sizes, 1)
@@ -204,16 +207,52 @@ class IVFPQIndex:
     KEEP_ALL_ROWS = 4096            # queries probing no more rows than this re-score every row (no threshold)
     LISTS_MIN_ROWS = 32768          # "auto": average probed rows per query from which the list-centric search pays
 
+    def _sample_step(self, nprobe: int) -> int:
+        """about SAMPLE_ROWS exactly scored rows per query place the candidate threshold"""
+        ss = self.SAMPLE_STEP
+        while ss < 64 and self.ntotal * nprobe / max(self.nlist, 1) / (2 * ss) >= self.SAMPLE_ROWS:
+            ss *= 2
+        return ss
+
     def _search_lists(self, q: torch.Tensor, probes: torch.Tensor, k: int, nprobe: int, sel_slack: float = 6.0,
                       max_retries: int = 3):
+        """rc_ivf_search_probes: sample layout, ranks and the (cell, <= 8 queries) task list are made on the device."""
+        dev, nq = self.device, q.shape[0]
+        ss = self._sample_step(nprobe)
+        top = self._sizes_desc[:nprobe]                                    # the nprobe largest cells bound a query's sample
+        sstride = max(4, int((16 * (top // (16 * ss)) + np.minimum(top % (16 * ss), 16)).sum()))
+        lut = ops.adc_lut(self.pq_centroids, q)
+        lib, h = _lib.load(), _lib.handle(dev.index)
+        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        wsb = lib.rc_ivf_search_probes_ws_bytes(self.M, nq, nprobe, self.nlist, sstride)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        slack = float(sel_slack)
+        for _ in range(max_retries + 1):
+            status.zero_()
+            _lib.check(lib.rc_ivf_search_probes(h, p(self.codes), p(self.image), p(self.list_off), p(self.ids), self.ntotal,
+                                                self.nlist, self.M, 256, p(lut), nq, p(probes), nprobe, sstride, ss, int(k),
+                                                slack, self.KEEP_ALL_ROWS, p(scores), p(ids), p(status), p(ws), wsb, s),
+                       "rc_ivf_search_probes", h)
+            st = int(status.item())
+            if st == 0:
+                return scores, ids
+            slack = max(slack, 0.0) * 3.0 + 2.0 if (st & 1) else max(slack / 3.0, 0.0)
+        raise _lib.RepconcHipError(f"IVF candidate selection did not converge (status {st})")
+
+    def _search_lists_host_plan(self, q: torch.Tensor, probes: torch.Tensor, k: int, nprobe: int, sel_slack: float = 6.0,
+                                max_retries: int = 3):
+        """The same search through rc_ivf_search_lists, with the plan spelled out in torch (what round 2 first shipped; kept
+        as the readable statement of the plan and as the cross-check of the device-side planner in the tests)."""
         dev, nq = self.device, q.shape[0]
         pl = probes.long()
         sizes = (self.list_off[1:] - self.list_off[:-1])[pl]                                   # [nq, nprobe]
         rows = sizes.sum(1)
         # sample step: about SAMPLE_ROWS exactly scored rows per query place the candidate threshold
-        ss = self.SAMPLE_STEP
-        while ss < 64 and self.ntotal * nprobe / max(self.nlist, 1) / (2 * ss) >= self.SAMPLE_ROWS:
-            ss *= 2
+        ss = self._sample_step(nprobe)
         ssz = 16 * (sizes // (16 * ss)) + torch.clamp(sizes % (16 * ss), max=16)               # sampled rows per probe (runs of 16)
         scs = torch.cumsum(ssz, 1)
         sbase = (scs - ssz).to(torch.int32).contiguous()

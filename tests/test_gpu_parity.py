@@ -1504,9 +1504,11 @@ def test_ivf_list_centric_search_equals_per_query_scan(M):
     ivf.set_lists(_t(codes), _t(cells))
     q = _t(synth.gaussian(704 + M, (nq, 768)))
     for nprobe, k in ((3, 10), (40, 1000), (nlist, 200)):
-        s1, i1 = ivf.search(q, k, nprobe, method="lists")
+        s1, i1 = ivf.search(q, k, nprobe, method="lists")                 # plan made on the device (rc_ivf_search_probes)
         s2, i2 = ivf.search(q, k, nprobe, method="scan")
+        s3, i3 = ivf.search(q, k, nprobe, method="lists_host_plan")       # plan spelled out in torch (rc_ivf_search_lists)
         assert torch.equal(i1, i2) and torch.equal(s1, s2), (M, nprobe)
+        assert torch.equal(i3, i2) and torch.equal(s3, s2), (M, nprobe)
 
 
 def test_warmup_procedure_follows_the_oracle_round_by_round():
