@@ -928,22 +928,20 @@ __global__ __launch_bounds__(64) void adc_qlut_cf_write_kernel(const float* __re
 template <int PM>
 __global__ __launch_bounds__(RC_K) void adc_qbyte_write_kernel(const float* __restrict__ lut, const float* __restrict__ qstat,
                                                                int M, uint8_t* __restrict__ qbyte) {
-    constexpr int SLOTS = adc_cf<PM>::SLOTS;
+    // compact rows: [phase][code][PM] bytes, one per sub-quantiser (the second copy of a 16-block exists only in LDS)
     const int qi = blockIdx.x, c = threadIdx.x;
     const int NP = M / PM;
     const float* lq = lut + (size_t)qi * M * RC_K;
     const float* st = qstat + (size_t)qi * ADC_QSTAT_STRIDE;
     const float delta = st[ADC_QSTAT_STRIDE - 1];
     for (int phase = 0; phase < NP; ++phase) {
-        uint4* row = reinterpret_cast<uint4*>(qbyte + (((size_t)qi * NP + phase) * RC_K + c) * SLOTS);
+        uint4* row = reinterpret_cast<uint4*>(qbyte + (((size_t)qi * NP + phase) * RC_K + c) * PM);
 #pragma unroll
-        for (int s16 = 0; s16 < SLOTS / 16; ++s16) {
+        for (int s16 = 0; s16 < PM / 16; ++s16) {
             unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int sl = 16 * s16 + j;
-                const int mp = sl < PM ? sl : sl - 16;
-                const int m = phase * PM + mp;
+                const int m = phase * PM + 16 * s16 + j;
                 w[j >> 2] |= adc_quant8(lq[m * RC_K + c], st[m], delta) << (8 * (j & 3));
             }
             row[s16] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -964,7 +962,8 @@ struct adc_ivf_tasks {
     const int* task_qcnt;        // [tasks] 1 .. 8 queries
     const int* sorted_q;         // query ids ordered by probed cell
     const int64_t* list_off;     // [nlist + 1] row ranges of the cells
-    const uint8_t* qbyte;        // [nq][NP][256][SLOTS] per-query byte tables in slot layout
+    const uint8_t* qbyte;        // [nq][NP][256][PM] per-query byte tables, one byte per sub-quantiser
+    const int* ntasks;           // device-side task count when the list is padded (rc_ivf_search_probes), else NULL
 };
 
 template <int M, int NP, int R, bool IVF = false, int THREADS = ADC_THREADS>
@@ -985,10 +984,19 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     if constexpr (!IVF) adc_xcd_remap(bgroup, btile);
     const int q0 = (int)bgroup * 8;
     const uint8_t* qsrc = qlut + (size_t)bgroup * NP * L::TABLE_BYTES;
-    // IVF: the task's queries (block-uniform scalars), -1 = empty slot
+    // IVF: blocks are dealt to the XCDs round-robin; give every XCD a CONTIGUOUS range of the (cell-ordered) task list so
+    // that the tasks of one cell run on one XCD, close in time, and share its rows in that L2
+    unsigned task = blockIdx.x;
+    if constexpr (IVF) {
+        const unsigned total = T.ntasks ? (unsigned)*T.ntasks : gridDim.x;   // a padded list is split by its real length
+        const unsigned q = total / 8u, rr = total % 8u, xcd = blockIdx.x % 8u, j = blockIdx.x / 8u;
+        if (j >= q + (xcd < rr ? 1u : 0u)) return;                           // padding (block-uniform)
+        task = (xcd < rr ? xcd * (q + 1u) : rr * (q + 1u) + (xcd - rr) * q) + j;
+    }
+    // the task's queries (block-uniform scalars), -1 = empty slot
     int tqid[8];
     if constexpr (IVF) {
-        const int qs = T.task_qstart[blockIdx.x], qc = T.task_qcnt[blockIdx.x];
+        const int qs = T.task_qstart[task], qc = T.task_qcnt[task];
         if (qc <= 0) return;                                  // padding of a device-planned task list (block-uniform)
 #pragma unroll
         for (int j = 0; j < 8; ++j) tqid[j] = (j < qc) ? T.sorted_q[qs + j] : -1;
@@ -1003,13 +1011,13 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
                 dst[i] = v;
             }
         } else {
-            // byte transpose: dword i of each query's table holds the bytes of four consecutive (code, slot) entries;
-            // the LDS entry of one (code, slot) is the 8 queries' bytes side by side (two 4 x 4 byte transposes by v_perm)
-            constexpr int QB = RC_K * L::SLOTS;                 // bytes of one query's table phase
-            uint4* dst = reinterpret_cast<uint4*>(smem);
+            // byte transpose: dword i of a query's compact table ([code][PM] bytes) holds the bytes of sub-quantisers
+            // 4 u .. 4 u + 3 of one code; the LDS entry of one (code, slot) is the 8 queries' bytes side by side (two 4 x 4
+            // byte transposes by v_perm).  Slots of a 16-block are written twice (second copy 16 slots further).
+            constexpr int QB = RC_K * PM;                       // bytes of one query's table phase
+            constexpr int DPC = PM / 4;                         // dwords per code
             // all QB / 4 / THREADS x 8 loads of the thread are issued before the first transpose: the per-query tables
-            // (nq x 32 KiB) live in the memory-side cache at best, and a task is short (one cell) - with the loop rolled the
-            // fill was four dependent ~2 us round trips per phase, three quarters of a task's time
+            // (nq x M x 256 bytes) live in the memory-side cache at best, and a task is short (one cell)
             constexpr int FI = QB / 4 / THREADS;
             static_assert(QB / 4 % THREADS == 0, "whole iterations");
             unsigned dd[FI][8];
@@ -1021,6 +1029,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
 #pragma unroll
             for (int f = 0; f < FI; ++f) {
                 const int i = tid + f * THREADS;
+                const int code = i / DPC, u = i % DPC;           // constant divisor
                 const unsigned (&d)[8] = dd[f];
                 unsigned o[8];                                   // o[2 t] = queries 0-3 of entry t, o[2 t + 1] = queries 4-7
 #pragma unroll
@@ -1033,8 +1042,15 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
                     o[4 + hq] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
                     o[6 + hq] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
                 }
-                dst[2 * i] = make_uint4(o[0] ^ 0x80808080u, o[1] ^ 0x80808080u, o[2] ^ 0x80808080u, o[3] ^ 0x80808080u);
-                dst[2 * i + 1] = make_uint4(o[4] ^ 0x80808080u, o[5] ^ 0x80808080u, o[6] ^ 0x80808080u, o[7] ^ 0x80808080u);
+                const uint4 lo4 = make_uint4(o[0] ^ 0x80808080u, o[1] ^ 0x80808080u, o[2] ^ 0x80808080u, o[3] ^ 0x80808080u);
+                const uint4 hi4 = make_uint4(o[4] ^ 0x80808080u, o[5] ^ 0x80808080u, o[6] ^ 0x80808080u, o[7] ^ 0x80808080u);
+                uint4* e = reinterpret_cast<uint4*>(smem + ((size_t)code * L::SLOTS + 4 * u) * 8);   // slot 4 u of the code's row
+                e[0] = lo4;
+                e[1] = hi4;
+                if (L::HAS16 && 4 * u >= 32 * L::N32) {          // 16-block: second copy
+                    e[8] = lo4;
+                    e[9] = hi4;
+                }
             }
         }
     };
@@ -1072,7 +1088,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     int64_t t1 = (t0 + TILE < N) ? t0 + TILE : N;
     unsigned row_lo = 0;                                      // rows of the tile before this are not the task's
     if constexpr (IVF) {
-        const int cell = T.task_list[blockIdx.x];
+        const int cell = T.task_list[task];
         const int64_t a = T.list_off[cell];
         t1 = T.list_off[cell + 1];
         t0 = a & ~(int64_t)15;                                // chunks start on multiples of 16 rows: the image's permutation
@@ -1709,7 +1725,7 @@ ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
     L.thr = o;    o += rc_align_up((size_t)nq * sizeof(float), 256);
     L.tint = o;   o += rc_align_up((size_t)nq * sizeof(int), 256);
     L.qstat = o;  o += rc_align_up((size_t)nq * ADC_QSTAT_STRIDE * sizeof(float), 256);
-    L.qbyte = o;  o += rc_align_up((size_t)nq * (adc_cf_table_bytes(M) / 8), 256);
+    L.qbyte = o;  o += rc_align_up((size_t)nq * M * RC_K, 256);                 // compact per-query byte tables
     L.idcnt = o;  o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
     L.ids = o;    o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
     L.cnt = o;    o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
@@ -1807,7 +1823,7 @@ extern "C" int rc_ivf_search_lists(rc_handle_t h, const uint8_t* codes, const ui
     if (nq == 0) return RC_OK;
     const ivfl_ws L = ivfl_layout(M, nq, sstride);
     if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
-    adc_ivf_tasks T = {task_list, task_qstart, task_qcnt, sorted_q, list_off, nullptr};
+    adc_ivf_tasks T = {task_list, task_qstart, task_qcnt, sorted_q, list_off, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)ws;
     if (ntasks == 0) {                                        // nothing probed: empty results through the select kernel
@@ -2017,7 +2033,7 @@ extern "C" int rc_ivf_search_probes(rc_handle_t h, const uint8_t* codes, const u
                        (const int*)I(P.cell_start), (const int*)I(P.first_task), (const int*)I(P.ntasks), nlist, P.ub,
                        I(P.task_list), I(P.task_qstart), I(P.task_qcnt));
     RC_LAUNCH_CHECK(h);
-    adc_ivf_tasks T = {I(P.task_list), I(P.task_qstart), I(P.task_qcnt), I(P.sorted_q), list_off, nullptr};
+    adc_ivf_tasks T = {I(P.task_list), I(P.task_qstart), I(P.task_qcnt), I(P.sorted_q), list_off, nullptr, I(P.ntasks)};
     switch (M) {
 #define IVFP_CASE(MM)                                                                                                  \
         case MM: return ivfl_launch<MM>(h, codes, image, list_off, rowmap, N, lut, nq, probes, I(P.sbase), I(P.scount),  \
