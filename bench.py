@@ -529,7 +529,7 @@ def main():
         procrustes_rotation(Pm)
         torch.cuda.synchronize()
         t_polar = time.perf_counter() - t0
-        out["warmup"] = {
+        out["opq_pq_warmup"] = {
             "metric": "opq_pq_training_seconds", "value": round(t_opq + t_pq2, 3), "unit": "s", "higher_is_better": False,
             "train_rows": MAX_TRAIN_POINTS, "M": M,
             "opq_50_rounds_s": round(t_opq, 3), "final_pq_25_lloyd_iterations_s": round(t_pq2, 3),
