@@ -34,6 +34,13 @@ def test_size_helpers_need_no_gpu():
     assert lib.rc_pq_assign_sinkhorn_ws_bytes(B, M, 128) == 0   # K must be 256
     assert lib.rc_adc_search_ws_bytes(8841823, 48, 256, 1200, 1000) > 1200 * 48 * 256 * 4
     assert lib.rc_sk_ws_bytes(6144, 48, 256) % 256 == 0
+    # IVF list-centric search: the device-planned entry needs the explicit-plan workspace plus the plan itself
+    w_lists = lib.rc_ivf_search_lists_ws_bytes(96, 1200, 8192)
+    w_probes = lib.rc_ivf_search_probes_ws_bytes(96, 1200, 32, 5000, 8192)
+    pairs = 1200 * 32
+    assert w_lists > 0 and w_probes >= w_lists + 4 * (2 * pairs + 4 * 5000 + 3 * 1200)
+    assert lib.rc_ivf_search_probes_ws_bytes(24, 1200, 32, 5000, 8192) == 0      # no conflict-free screen for M = 24
+    assert lib.rc_ivf_search_probes_ws_bytes(96, 1200, 0, 5000, 8192) == 0
 
 
 def test_cpu_tensors_are_rejected_loudly():

@@ -1640,3 +1640,59 @@ def test_replicated_ivf_index_splits_the_queries_over_the_replicas():
         assert np.array_equal(i3, i1.cpu().numpy()) and np.array_equal(s3, s1.cpu().numpy())
     s4, i4 = rep.search(q[:2], 5, 8)                      # fewer queries than replicas
     assert np.array_equal(i4, ivf.search(q[:2], 5, 8)[1])
+
+
+def test_ivf_probes_entry_through_the_raw_c_abi():
+    """rc_ivf_search_probes called with plain pointers (no Python wrapper logic): argument checks, an empty-cell / ragged
+    probe list, and the result against the oracle's brute-force IVF search."""
+    import ctypes as C
+    from repconc_amd import _lib, ops
+    lib, h = _lib.load(), _lib.handle(0)
+    N, M, nlist, nq, k, nprobe = 120000, 32, 64, 19, 50, 5
+    rng = np.random.default_rng(901)
+    codes = synth.uniform_codes(902, N, M)
+    cells = rng.integers(0, nlist - 8, N)                     # the last 8 cells stay empty
+    order = np.argsort(cells, kind="stable")
+    list_off = np.concatenate([[0], np.cumsum(np.bincount(cells, minlength=nlist))]).astype(np.int64)
+    Cq = synth.gaussian(903, (M, 256, 768 // M))
+    q = synth.gaussian(904, (nq, 768))
+    probes = np.stack([rng.permutation(nlist)[:nprobe] for _ in range(nq)]).astype(np.int32)
+    probes[0, :] = np.arange(nlist - nprobe, nlist)           # a query that probes (almost) only empty cells
+    d_codes, d_off, d_ids = _t(codes[order]), _t(list_off), _t(order.astype(np.int64))
+    image = torch.empty((N, ops.adc_image_row_bytes(M)), dtype=torch.uint8, device=DEV)
+    ops.adc_scan_image_(d_codes, image)
+    lut = ops.adc_lut(_t(Cq), _t(q))
+    d_probes = _t(probes)
+    sizes = np.sort(np.diff(list_off))[::-1][:nprobe]
+    ss = 8
+    sstride = int((16 * (sizes // (16 * ss)) + np.minimum(sizes % (16 * ss), 16)).sum())
+    wsb = lib.rc_ivf_search_probes_ws_bytes(M, nq, nprobe, nlist, sstride)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=DEV)
+    scores = torch.empty((nq, k), dtype=torch.float32, device=DEV)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=DEV)
+    status = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = [h, p(d_codes), p(image), p(d_off), p(d_ids), N, nlist, M, 256, p(lut), nq, p(d_probes), nprobe, sstride, ss, k,
+            6.0, 4096, p(scores), p(ids), p(status), p(ws), wsb, s]
+    assert lib.rc_ivf_search_probes(*args) == 0
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    # oracle: brute force over the probed rows
+    got_s, got_i = scores.cpu().numpy(), ids.cpu().numpy()
+    lut_h = pq_oracle.adc_lut(q, Cq)
+    for qi in range(nq):
+        rows = np.concatenate([order[list_off[c]:list_off[c + 1]] for c in probes[qi]]) if nprobe else np.empty(0, np.int64)
+        sc = pq_oracle.adc_scores(lut_h[qi:qi + 1], codes[rows])[0] if len(rows) else np.empty(0, np.float32)
+        top = np.lexsort((rows, -sc.astype(np.float64)))[:k]
+        want_i = np.full(k, -1, np.int64)
+        want_i[:len(top)] = rows[top]
+        assert np.array_equal(got_i[qi], want_i), qi
+        assert np.array_equal(got_s[qi][:len(top)].view(np.uint32), sc[top].view(np.uint32)), qi
+    # argument checks
+    bad = list(args); bad[12] = nlist + 1                      # nprobe > nlist
+    assert lib.rc_ivf_search_probes(*bad) == _lib.RC_EINVAL
+    bad = list(args); bad[22] = wsb - 1                        # workspace too small
+    assert lib.rc_ivf_search_probes(*bad) == _lib.RC_EWORKSPACE
+    bad = list(args); bad[7] = 24                              # no screen for this M
+    assert lib.rc_ivf_search_probes(*bad) == _lib.RC_ESHAPE
