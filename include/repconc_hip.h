@@ -303,6 +303,11 @@ int rc_ivf_search_lists(rc_handle_t h, const uint8_t* codes, const uint8_t* imag
  * sel_slack: standard deviations of head-room in the threshold rank (6 is the default of the Python wrapper);
  * keep_all_rows: queries probing no more rows than this re-score every probed row.  Status bits and results as above.
  * ws: rc_ivf_search_probes_ws_bytes(M, nq, nprobe, nlist, sstride). */
+/* Probe selection for the calls below: per query the nprobe cells with the largest coarse score (scores [nq,nlist] fp32,
+ * e.g. q @ coarse^T from a library GEMM; ties at the boundary go to the lower cell id), written in ASCENDING CELL ORDER to
+ * probes [nq,nprobe] int32 — the searches need the set of cells, not their ranking.  nlist <= 16384. */
+int rc_ivf_select_probes(rc_handle_t h, const float* scores, int nq, int nlist, int nprobe, int* probes,
+                         rc_stream_t stream);
 size_t rc_ivf_search_probes_ws_bytes(int M, int nq, int nprobe, int nlist, int64_t sstride);
 int rc_ivf_search_probes(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
                          const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,

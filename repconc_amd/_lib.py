@@ -67,6 +67,7 @@ PROTOTYPES = {
     "rc_ivf_search_lists_ws_bytes": (_sz, [_i, _i, _i64]),
     "rc_ivf_search_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i,
                                  _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rc_ivf_select_probes": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rc_ivf_search_probes_ws_bytes": (_sz, [_i, _i, _i, _i, _i64]),
     "rc_ivf_search_probes": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _i, _d, _i,
                                   _vp, _vp, _vp, _vp, _sz, _vp]),

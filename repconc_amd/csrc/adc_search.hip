@@ -1992,6 +1992,100 @@ __global__ __launch_bounds__(256) void ivf_plan_tasks_kernel(const int* __restri
     task_qcnt[t] = qc;
 }
 
+// Probe selection: the nprobe cells with the largest coarse score of every query (ties at the boundary: lower cell id),
+// written in ascending cell order — the search needs the SET of probed cells, not their ranking.  One block per query: the
+// nlist scores as order-preserving keys in LDS, 4-pass radix select of the nprobe-th largest key, ordered compaction.
+// (The framework's topk + sort + gather + argsort chain cost 0.15 ms per 1200 queries, a tenth of a search at nprobe 32.)
+__global__ __launch_bounds__(1024) void ivf_probe_select_kernel(const float* __restrict__ scores, int nlist, int nprobe,
+                                                                int* __restrict__ probes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* keys = reinterpret_cast<unsigned*>(smem);  // [nlist]
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_rank;
+    __shared__ int s_gt[16], s_eq[16];
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < nlist; i += 1024) keys[i] = adc_order_key(scores[(size_t)qi * nlist + i]);
+    if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)nprobe; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = sel_prefix;
+        const unsigned himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < nlist; i += 1024) {
+            const unsigned k = keys[i];
+            if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned need = sel_rank, b = 255;
+            for (;; --b) {
+                if (hist[b] >= need) break;
+                need -= hist[b];
+                if (b == 0) break;
+            }
+            sel_prefix = prefix | (b << shift);
+            sel_rank = need;
+        }
+        __syncthreads();
+    }
+    const unsigned T = sel_prefix;
+    const int need = (int)sel_rank;                        // how many of the cells tied at T belong to the selection
+    const int chunk = (nlist + 1023) / 1024;
+    const int c0 = tid * chunk, c1 = (c0 + chunk < nlist) ? c0 + chunk : nlist;
+    int gt = 0, eq = 0;
+    for (int c = c0; c < c1; ++c) {
+        const unsigned k = keys[c];
+        gt += (k > T) ? 1 : 0;
+        eq += (k == T) ? 1 : 0;
+    }
+    // exclusive prefix sums of (gt, eq) over the 1024 threads
+    const int lane = tid & 63, wv = tid >> 6;
+    int igt = gt, ieq = eq;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int a = __shfl_up(igt, o), b = __shfl_up(ieq, o);
+        if (lane >= o) { igt += a; ieq += b; }
+    }
+    if (lane == 63) { s_gt[wv] = igt; s_eq[wv] = ieq; }
+    __syncthreads();
+    int bgt = 0, beq = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        bgt += (j < wv) ? s_gt[j] : 0;
+        beq += (j < wv) ? s_eq[j] : 0;
+    }
+    const int gt_before = bgt + igt - gt;
+    int eq_seen = beq + ieq - eq;
+    int pos = gt_before + (eq_seen < need ? eq_seen : need);
+    int* out = probes + (size_t)qi * nprobe;
+    for (int c = c0; c < c1; ++c) {
+        const unsigned k = keys[c];
+        if (k > T) {
+            out[pos++] = c;
+        } else if (k == T) {
+            if (eq_seen < need) out[pos++] = c;
+            ++eq_seen;
+        }
+    }
+}
+
+// scores: [nq, nlist] fp32 coarse scores (larger = closer); probes: [nq, nprobe] int32, ascending cell ids.
+extern "C" int rc_ivf_select_probes(rc_handle_t h, const float* scores, int nq, int nlist, int nprobe, int* probes,
+                                    rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !scores || !probes || nq < 0 || nlist <= 0 || nprobe <= 0 || nprobe > nlist) return RC_EINVAL;
+    if (nlist > 16384) return RC_ESHAPE;                    // the keys of a query live in 64 KiB of LDS
+    if (nq == 0) return RC_OK;
+    const size_t lds = (size_t)nlist * sizeof(unsigned);
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)ivf_probe_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ivf_probe_select_kernel, dim3((unsigned)nq), dim3(1024), lds, (hipStream_t)stream, scores, nlist, nprobe,
+                       probes);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
 extern "C" size_t rc_ivf_search_probes_ws_bytes(int M, int nq, int nprobe, int nlist, int64_t sstride) {
     if (!adc_cf_supported(M) || nq <= 0 || nprobe <= 0 || nlist <= 0 || sstride <= 0) return 0;
     return ivfp_layout(ivfl_layout(M, nq, sstride).total, nq, nprobe, nlist).total;

@@ -141,9 +141,18 @@ class IVFPQIndex:
         return out
 
     # ---- search
-    def probe(self, q: torch.Tensor, nprobe: int) -> torch.Tensor:
-        """[nq, nprobe] cells by decreasing <q, centroid> (ties: lower cell id), int32."""
+    def probe(self, q: torch.Tensor, nprobe: int, ordered: bool = True) -> torch.Tensor:
+        """[nq, nprobe] int32: the nprobe cells with the largest <q, centroid> (ties at the boundary: lower cell id).
+        ordered=True ranks them by decreasing score (ties: lower cell id); ordered=False — what the searches use — returns
+        the same set in ascending cell order from one HIP kernel (rc_ivf_select_probes) after the library GEMM."""
         s = q.float() @ self.coarse.T
+        if not ordered and self.nlist <= 16384 and q.shape[0] > 0:
+            s = s.contiguous()
+            out = torch.empty((q.shape[0], nprobe), dtype=torch.int32, device=s.device)
+            lib, h, st, _ = ops._ctx(s)
+            _lib.check(lib.rc_ivf_select_probes(h, C.c_void_p(s.data_ptr()), s.shape[0], self.nlist, int(nprobe),
+                                                C.c_void_p(out.data_ptr()), st), "rc_ivf_select_probes", h)
+            return out
         if nprobe * 4 <= self.nlist:
             # select first, then order the selected cells by (score desc, cell asc): a full stable sort of nlist scores
             # per query costs more than the search itself at small nprobe
@@ -164,7 +173,7 @@ class IVFPQIndex:
         q = q.contiguous()
         nq = q.shape[0]
         nprobe = min(int(nprobe), self.nlist)
-        probes = self.probe(q, nprobe)
+        probes = self.probe(q, nprobe, ordered=False)
         if method not in ("auto", "lists", "lists_host_plan", "scan"):
             raise ValueError("method must be auto|lists|lists_host_plan|scan")
         if method in ("lists", "lists_host_plan") and self.image is None:

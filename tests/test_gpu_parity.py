@@ -1696,3 +1696,30 @@ def test_ivf_probes_entry_through_the_raw_c_abi():
     assert lib.rc_ivf_search_probes(*bad) == _lib.RC_EWORKSPACE
     bad = list(args); bad[7] = 24                              # no screen for this M
     assert lib.rc_ivf_search_probes(*bad) == _lib.RC_ESHAPE
+
+
+def test_probe_selection_kernel_picks_the_ordered_probe_set():
+    """rc_ivf_select_probes: same cells as the ranked selection (torch path), in ascending cell order; exact ties at the
+    boundary go to the lower cell ids; nprobe = 1, = nlist and a nlist that is no multiple of anything."""
+    from repconc_amd.ivf import IVFPQIndex
+    for nlist, nq in ((5000, 67), (257, 5), (64, 3)):
+        ivf = IVFPQIndex(768, 48, nlist, device=DEV)
+        ivf.coarse = _t(synth.gaussian(950 + nlist, (nlist, 768)))
+        q = _t(synth.gaussian(951 + nlist, (nq, 768)))
+        for nprobe in (1, 7, 32, nlist // 3 + 1, nlist):
+            a = ivf.probe(q, nprobe, ordered=True).cpu().numpy()
+            b = ivf.probe(q, nprobe, ordered=False).cpu().numpy()
+            assert b.dtype == np.int32 and np.all(np.diff(b, axis=1) > 0)
+            assert np.array_equal(np.sort(a, axis=1), b), (nlist, nprobe)
+    # exact ties: scores take four values only -> the boundary value is shared by many cells
+    from repconc_amd import _lib
+    import ctypes as C
+    lib, h = _lib.load(), _lib.handle(0)
+    nlist, nq, nprobe = 1000, 9, 300
+    sc = np.random.default_rng(960).integers(0, 4, (nq, nlist)).astype(np.float32)
+    d_sc, out = _t(sc), torch.empty((nq, nprobe), dtype=torch.int32, device=DEV)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.rc_ivf_select_probes(h, C.c_void_p(d_sc.data_ptr()), nq, nlist, nprobe, C.c_void_p(out.data_ptr()), s) == 0
+    want = np.sort(np.lexsort((np.broadcast_to(np.arange(nlist), sc.shape), -sc), axis=1)[:, :nprobe], axis=1)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert lib.rc_ivf_select_probes(h, C.c_void_p(d_sc.data_ptr()), nq, nlist, nlist + 1, C.c_void_p(out.data_ptr()), s) == _lib.RC_EINVAL
