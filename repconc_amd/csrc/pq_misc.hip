@@ -331,7 +331,8 @@ template <int JN>
 __global__ __launch_bounds__(256) void kmeans_stats_det_kernel(const float* __restrict__ x, int64_t ldx,
                                                                const uint8_t* __restrict__ codes, int64_t n, int M, int dsub,
                                                                int j0, int64_t rows_per_strip, double* __restrict__ part,
-                                                               unsigned* __restrict__ pcnt) {
+                                                               unsigned* __restrict__ pcnt, const unsigned* __restrict__ gate) {
+    if (gate && *gate < 0x7F800000u) return;              // finite input: the fixed-point path has done this call
     __shared__ uint8_t cs[KM_CHUNK];
     const int tid = threadIdx.x, m = blockIdx.y, wave = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_strip;
@@ -375,9 +376,10 @@ __global__ __launch_bounds__(256) void kmeans_stats_det_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void kmeans_stats_reduce_kernel(const double* __restrict__ part, const unsigned* __restrict__ pcnt,
                                                                   int strips, int64_t per_strip, int dsub,
-                                                                  double* __restrict__ sums, unsigned long long* __restrict__ counts) {
+                                                                  double* __restrict__ sums, unsigned long long* __restrict__ counts,
+                                                                  const unsigned* __restrict__ gate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per_strip) return;
+    if (i >= per_strip || (gate && *gate < 0x7F800000u)) return;
     double s = 0.0;
     for (int t = 0; t < strips; ++t) s += part[(size_t)t * per_strip + i];
     sums[i] += s;
@@ -388,6 +390,105 @@ __global__ __launch_bounds__(256) void kmeans_stats_reduce_kernel(const double* 
     }
 }
 
+// ---- exact fixed-point statistics (the default path) --------------------------------------------------------------
+// The strip kernel above is deterministic because every centroid's rows are added in row order by ONE thread — 1/256 of
+// the lanes at work, 1.3 ms for 65 536 rows (it was 90 % of a Lloyd iteration of the warm-up).  Integer addition does not
+// care about the order: every value is split as  x S = hi + r,  hi = rint(x S),  lo = rint(r 2^38)  (S a power of two sized
+// so that n values cannot overflow 63 bits; both parts exact for every x down to max|x| 2^-52) and (hi, lo) are summed with
+// 64-bit integer atomics — LDS accumulators per (strip, sub-quantiser), then global.  Any order gives the same integers,
+// the final conversion is one fp64 expression: bit-identical run to run, and closer to the real sum than a running fp64 sum.
+// Non-finite input (max|x| = inf / NaN) takes the strip kernels, which propagate it as the reference would.
+#define KM_FX_LO_BITS 38
+#define KM_FX_JN 32                                     // dimensions of a sub-vector per pass: 256 x 32 x 16 B = 128 KiB of LDS
+
+__global__ __launch_bounds__(256) void kmeans_absmax_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int D,
+                                                            unsigned* __restrict__ out) {
+    __shared__ unsigned s_w[4];
+    unsigned mx = 0u;
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const unsigned u = __float_as_uint(x[(i / D) * ldx + (i % D)]) & 0x7FFFFFFFu;   // |x| as ordered bits; NaN > inf
+        mx = u > mx ? u : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)mx, o);
+        mx = t > mx ? t : mx;
+    }
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = s_w[0] > s_w[1] ? s_w[0] : s_w[1], b = s_w[2] > s_w[3] ? s_w[2] : s_w[3];
+        atomicMax(out, a > b ? a : b);
+    }
+}
+
+// grid (strips, M); dynamic LDS: hi[256][jn] | lo[256][jn] (int64) | cnt[256] (u32)
+__global__ __launch_bounds__(256) void kmeans_stats_fx_kernel(const float* __restrict__ x, int64_t ldx,
+                                                              const uint8_t* __restrict__ codes, int64_t n, int M, int dsub,
+                                                              int j0, int jn, int64_t rows_per_strip,
+                                                              const unsigned* __restrict__ absmax, int log2n,
+                                                              unsigned long long* __restrict__ ghi,
+                                                              unsigned long long* __restrict__ glo,
+                                                              unsigned long long* __restrict__ gcnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
+    unsigned long long* hi = reinterpret_cast<unsigned long long*>(km_smem);
+    unsigned long long* lo = hi + RC_K * jn;
+    unsigned* cnt = reinterpret_cast<unsigned*>(lo + RC_K * jn);
+    const unsigned am = *absmax;
+    if (am >= 0x7F800000u) return;                         // inf / NaN somewhere: the strip kernels take this call
+    const int tid = threadIdx.x, m = blockIdx.y;
+    for (int i = tid; i < 2 * RC_K * jn; i += 256) hi[i] = 0ull;
+    cnt[tid] = 0u;
+    __syncthreads();
+    // S = 2^sexp with max|x| S < 2^(61 - log2n): the largest exponent of the data is (am >> 23) - 127
+    const int sexp = 61 - log2n - ((int)(am >> 23) - 127 + 1);
+    const double S = ldexp(1.0, sexp);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_strip;
+    const int64_t r1 = (r0 + rows_per_strip < n) ? r0 + rows_per_strip : n;
+    const int tpr = jn / 4, rpi = 256 / tpr;               // threads per row (one float4 each), rows per iteration
+    const int q = tid % tpr;
+    if (tid < rpi * tpr) {
+        for (int64_t r = r0 + tid / tpr; r < r1; r += rpi) {
+            const int k = codes[r * M + m];
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + m * dsub + j0 + 4 * q);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double d = (double)vv[e] * S;
+                const double h = rint(d);
+                const long long hl = (long long)h;
+                const long long ll = (long long)rint((d - h) * (double)(1ull << KM_FX_LO_BITS));
+                if (hl) atomicAdd(&hi[k * jn + 4 * q + e], (unsigned long long)hl);
+                if (ll) atomicAdd(&lo[k * jn + 4 * q + e], (unsigned long long)ll);
+            }
+            if (q == 0 && j0 == 0) atomicAdd(&cnt[k], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < RC_K * jn; i += 256) {
+        const size_t g = ((size_t)m * RC_K + i / jn) * dsub + j0 + i % jn;
+        if (hi[i]) atomicAdd(&ghi[g], hi[i]);
+        if (lo[i]) atomicAdd(&glo[g], lo[i]);
+    }
+    if (j0 == 0 && cnt[tid]) atomicAdd(&gcnt[(size_t)m * RC_K + tid], (unsigned long long)cnt[tid]);
+}
+
+__global__ __launch_bounds__(256) void kmeans_stats_fx_finish_kernel(const unsigned long long* __restrict__ ghi,
+                                                                     const unsigned long long* __restrict__ glo,
+                                                                     const unsigned long long* __restrict__ gcnt,
+                                                                     const unsigned* __restrict__ absmax, int log2n,
+                                                                     int64_t total, int dsub, double* __restrict__ sums,
+                                                                     unsigned long long* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned am = *absmax;
+    if (i >= total || am >= 0x7F800000u) return;
+    const int sexp = 61 - log2n - ((int)(am >> 23) - 127 + 1);
+    const double h = (double)(long long)ghi[i], l = (double)(long long)glo[i];
+    sums[i] += ldexp(h, -sexp) + ldexp(l, -sexp - KM_FX_LO_BITS);
+    if (i % dsub == 0) counts[i / dsub] += gcnt[i / dsub];
+}
+
 extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const uint8_t* codes, int64_t n, int D,
                                int M, int K, double* sums, int64_t* counts, rc_stream_t stream) {
     rc_device_guard device_guard_(h);
@@ -396,6 +497,53 @@ extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const
     const int dsub = D / M;
     if (dsub > 256) return RC_ESHAPE;
     if (n == 0) return RC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0) && (dsub % 4 == 0);
+    const int64_t per_strip = (int64_t)M * RC_K * dsub;
+    // exact fixed-point path (see above): float4 rows, n < 2^24 per call, finite input (checked on the device)
+    const bool fx = vec && n < (1ll << 24) && !rc_env_set("RC_KMEANS_STRIPS");
+    const unsigned* gate = nullptr;                                // device word: strip kernels run iff it is not finite
+    if (fx) {
+        int log2n = 0;
+        while ((1ll << log2n) < n) ++log2n;
+        const size_t lbytes = rc_align_up((size_t)per_strip * sizeof(unsigned long long), 256);
+        const size_t cb = rc_align_up((size_t)M * RC_K * sizeof(unsigned long long), 256);
+        // the strip fall-back below reuses the same scratch block; the absmax word sits behind its partials
+        int64_t rps0 = 8192;
+        int st0 = (int)((n + rps0 - 1) / rps0);
+        if (st0 > KM_MAX_STRIPS) st0 = KM_MAX_STRIPS;
+        const size_t strip_bytes = rc_align_up((size_t)st0 * per_strip * sizeof(double), 256) +
+                                   rc_align_up((size_t)st0 * M * RC_K * sizeof(unsigned), 256);
+        const size_t need = (2 * lbytes + cb + 256 > strip_bytes ? 2 * lbytes + cb + 256 : strip_bytes + 256);
+        char* ws = (char*)rc_scratch(h, need);
+        if (!ws) return RC_EHIP;
+        unsigned long long* ghi = (unsigned long long*)ws;
+        unsigned long long* glo = (unsigned long long*)(ws + lbytes);
+        unsigned long long* gcnt = (unsigned long long*)(ws + 2 * lbytes);
+        unsigned* absmax = (unsigned*)(ws + need - 256);
+        RC_HIP_CHECK(h, hipMemsetAsync(ws, 0, 2 * lbytes + cb, s));
+        RC_HIP_CHECK(h, hipMemsetAsync(absmax, 0, sizeof(unsigned), s));
+        int64_t ab = (n * D + 255) / 256;
+        if (ab > 4096) ab = 4096;
+        hipLaunchKernelGGL(kmeans_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, s, x, ldx, n, D, absmax);
+        RC_LAUNCH_CHECK(h);
+        int64_t rps = 2048;
+        if ((n + rps - 1) / rps > 1024) rps = (n + 1023) / 1024;
+        const unsigned strips = (unsigned)((n + rps - 1) / rps);
+        for (int j0 = 0; j0 < dsub; j0 += KM_FX_JN) {
+            const int jn = dsub - j0 < KM_FX_JN ? dsub - j0 : KM_FX_JN;
+            const size_t lds = (size_t)2 * RC_K * jn * sizeof(unsigned long long) + RC_K * sizeof(unsigned);
+            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmeans_stats_fx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kmeans_stats_fx_kernel, dim3(strips, (unsigned)M), dim3(256), lds, s, x, ldx, codes, n, M, dsub, j0, jn,
+                               rps, (const unsigned*)absmax, log2n, ghi, glo, gcnt);
+            RC_LAUNCH_CHECK(h);
+        }
+        hipLaunchKernelGGL(kmeans_stats_fx_finish_kernel, dim3((unsigned)((per_strip + 255) / 256)), dim3(256), 0, s,
+                           (const unsigned long long*)ghi, (const unsigned long long*)glo, (const unsigned long long*)gcnt,
+                           (const unsigned*)absmax, log2n, per_strip, dsub, sums, reinterpret_cast<unsigned long long*>(counts));
+        RC_LAUNCH_CHECK(h);
+        gate = absmax;            // the strip kernels below leave at once unless max|x| is inf / NaN (decided on the device)
+    }
     int64_t rps = 8192;                                            // rows per strip
     int strips = (int)((n + rps - 1) / rps);
     if (strips > KM_MAX_STRIPS) {
@@ -404,35 +552,32 @@ extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const
         rps = (rps + KM_CHUNK - 1) / KM_CHUNK * KM_CHUNK;
         strips = (int)((n + rps - 1) / rps);
     }
-    const int64_t per_strip = (int64_t)M * RC_K * dsub;
     const size_t pbytes = rc_align_up((size_t)strips * per_strip * sizeof(double), 256);
     const size_t cbytes = rc_align_up((size_t)strips * M * RC_K * sizeof(unsigned), 256);
     char* ws = (char*)rc_scratch(h, pbytes + cbytes);
     if (!ws) return RC_EHIP;
     double* part = (double*)ws;
     unsigned* pcnt = (unsigned*)(ws + pbytes);
-    hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)strips, (unsigned)M);
-    const bool vec = (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0) && (dsub % 4 == 0);
     for (int j0 = 0; j0 < dsub;) {
         const int left = dsub - j0;
         if (vec && left >= 16) {
-            hipLaunchKernelGGL(kmeans_stats_det_kernel<16>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt);
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<16>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt, gate);
             j0 += 16;
         } else if (vec && left >= 8) {
-            hipLaunchKernelGGL(kmeans_stats_det_kernel<8>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt);
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<8>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt, gate);
             j0 += 8;
         } else if (vec && left >= 4) {
-            hipLaunchKernelGGL(kmeans_stats_det_kernel<4>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt);
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<4>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt, gate);
             j0 += 4;
         } else {
-            hipLaunchKernelGGL(kmeans_stats_det_kernel<1>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt);
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<1>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt, gate);
             j0 += 1;
         }
         RC_LAUNCH_CHECK(h);
     }
     hipLaunchKernelGGL(kmeans_stats_reduce_kernel, dim3((unsigned)((per_strip + 255) / 256)), dim3(256), 0, s, (const double*)part,
-                       (const unsigned*)pcnt, strips, per_strip, dsub, sums, reinterpret_cast<unsigned long long*>(counts));
+                       (const unsigned*)pcnt, strips, per_strip, dsub, sums, reinterpret_cast<unsigned long long*>(counts), gate);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }

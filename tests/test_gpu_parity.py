@@ -1485,6 +1485,31 @@ def test_kmeans_statistics_are_deterministic_and_match_the_oracle():
         s3, c3 = ops.kmeans_stats(xt, ct, s1.clone(), c1.clone())                    # accumulates
         np.testing.assert_allclose(s3.cpu().numpy(), 2 * ws, rtol=1e-12, atol=1e-9)
         assert np.array_equal(c3.cpu().numpy(), 2 * wc)
+    # the default path sums exact fixed-point parts with integer atomics; the fixed-order strip kernels (forced here) must
+    # agree to fp64 rounding, and take over by themselves when the input is not finite
+    M, n = 48, 20000
+    x = synth.gaussian(70, (n, 768)) * np.float32(37.5)
+    x[:, 5] *= np.float32(1e-6)                                                    # a column 2^-20 below the rest
+    codes = synth.uniform_codes(71, n, M)
+    s_fx, c_fx = ops.kmeans_stats(_t(x), _t(codes))
+    os.environ["RC_KMEANS_STRIPS"] = "1"
+    try:
+        s_st, c_st = ops.kmeans_stats(_t(x), _t(codes))
+    finally:
+        del os.environ["RC_KMEANS_STRIPS"]
+    ws, wc = pq_oracle.kmeans_stats(x, codes, M)
+    assert torch.equal(c_fx, c_st) and np.array_equal(c_fx.cpu().numpy(), wc)
+    np.testing.assert_allclose(s_fx.cpu().numpy(), ws, rtol=1e-13, atol=1e-10)
+    np.testing.assert_allclose(s_st.cpu().numpy(), ws, rtol=1e-12, atol=1e-9)
+    xbad = x.copy()
+    xbad[123, 40] = np.inf
+    xbad[456, 700] = np.nan
+    s_bad, c_bad = ops.kmeans_stats(_t(xbad), _t(codes))
+    sb = s_bad.cpu().numpy()
+    assert np.isinf(sb[40 // 16, codes[123, 40 // 16], 40 % 16]) and np.isnan(sb[700 // 16, codes[456, 700 // 16], 700 % 16])
+    good = np.isfinite(sb)
+    assert good.sum() == sb.size - 2 and np.array_equal(c_bad.cpu().numpy(), wc)
+    np.testing.assert_allclose(sb[good], ws[good], rtol=1e-12, atol=1e-9)
 
 
 @pytest.mark.parametrize("M", [16, 32, 48, 64])
