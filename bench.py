@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-adc", action="store_true", help="skip the ADC leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-opq", action="store_true",
+                    help="skip the OPQ / PQ training leg (profiling runs: its many small launches of the assignment "
+                         "kernels would dilute the per-kernel means of the index-build leg)")
     ap.add_argument("--no-per-rank", action="store_true",
                     help="skip the per_rank_6144 leg (profiling runs: its launches of the sweep kernel would mix into "
                          "the per-kernel averages of the timed 49152-row configuration)")
@@ -498,7 +501,7 @@ def main():
         del xb
 
     # ------------------------------------------------------------------ warm-up leg (OPQ + PQ training, a-12)
-    if world == 1 and not args.no_adc:
+    if world == 1 and not args.no_adc and not args.no_opq:
         from repconc_amd.train.run_warmup import MAX_TRAIN_POINTS, train_opq, train_pq
         gw = torch.Generator(device=dev).manual_seed(20226)
         xt = torch.randn((MAX_TRAIN_POINTS, D), device=dev, generator=gw)

@@ -15,12 +15,15 @@ ALG = {  # SURVEY 8(d) per-unit bytes x units per launch
     "assign_mfma_kernel": ("assign_mfma_kernel<16>", NB * (768 * 4 + M)),
 }
 out = {"_how": "tools/pmc_collect.sh: rocprofv3 --pmc <group> --kernel-trace, one pass per counter group, over "
-               "`python bench.py --steps 1 --warmup 1 --no-cpu --no-per-rank --adc-batches 1`; means per launch. FETCH_SIZE/WRITE_SIZE are "
+               "`python bench.py --steps 1 --warmup 1 --no-cpu --no-per-rank --no-opq --adc-batches 1`; means per launch. FETCH_SIZE/WRITE_SIZE are "
                "KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md. " + note}
 for key, (kname, alg) in ALG.items():
     c = raw.get(kname)
-    if not c:
-        continue
+    if not c:                                              # template argument lists grow: match on the leading arguments
+        hits = [k for k in raw if k.startswith(kname.rstrip(">"))]
+        if not hits:
+            continue
+        kname, c = hits[0], raw[hits[0]]
     f, w = c.get("FETCH_SIZE", {}).get("mean"), c.get("WRITE_SIZE", {}).get("mean")
     e = {"kernel": kname, "launches": c.get("FETCH_SIZE", {}).get("n"), "fetch_size_kib_mean": f, "write_size_kib_mean": w,
          "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024) if f is not None and w is not None else None,
