@@ -1097,7 +1097,9 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     }
     // Flat sequence of steps it = round * NP + i; a round covers ROUND rows and visits the NP table phases, odd rounds in
     // reverse order, so the tables already in LDS are used first (NP - 1 refills per round).  The codes of step it + 1 are
-    // loaded while step it is gathered (NP == 1, two buffers) or right after its last gather (two phases, one buffer).  All row arithmetic is 32-bit and relative to the tile (<= 32768 rows x M bytes).
+    // loaded while step it is gathered (NP == 1, two buffers); with two phases the eight chunks' codes are loaded at the start
+    // of the step (requesting them right after the previous step's last gather instead was tried: it keeps them live across
+    // the epilogue, 24 bytes of scratch per lane, and the M = 96 screen got 3 % slower).  All row arithmetic is 32-bit and relative to the tile (<= 32768 rows x M bytes).
     const unsigned nrows = (unsigned)(t1 - t0);
     const int nrounds = (int)((nrows + ROUND - 1) / ROUND);
     const int nsteps = nrounds * NP;
@@ -1116,7 +1118,9 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             for (int j = 0; j < NW; ++j) dst[c][j] = cp[j];
         }
     };
-    constexpr bool PREFETCH = (NP == 1);
+    // ping-pong code buffers only where the registers allow: the IVF variant at 48 sub-quantisers per phase (table transpose +
+    // aggregated survivor slots on top of the 12-step gather pipeline) spilled 100 bytes per lane with them
+    constexpr bool PREFETCH = (NP == 1) && !(IVF && PM == 48);
     adc_i32x4v acc[R];
     // one step: gather + fold the R chunks of step `it` from the codes in `w`; the next step's codes go to `wn`
     auto run_step = [&](int it, unsigned (&w)[R][NW], unsigned (&wn)[PREFETCH ? R : 1][NW], int& in_lds) {
@@ -1133,6 +1137,8 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
         }
         if constexpr (PREFETCH) {
             if (it + 1 < nsteps) load_step(it + 1, wn);
+        } else {
+            load_step(it, w);
         }
         // Software pipeline over the R chunks of the step: all STEPS gathers of chunk c + 1 are issued before the MFMAs
         // of chunk c, so a wave keeps a whole chunk of LDS reads in flight.  Address of a gather: two VALU instructions,
@@ -1173,12 +1179,6 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             fold(c, ea);
             if (c + 2 < R) gather(c + 2, ea);
             if (c + 1 < R) fold(c + 1, eb);
-        }
-        if constexpr (!PREFETCH) {
-            // several table phases: one code buffer.  Its contents are dead once the last gather address is formed, so the
-            // next step's codes are requested here — their latency runs under the epilogue, the barrier and the table refill
-            // of the next step instead of in front of its first gather
-            if (it + 1 < nsteps) load_step(it + 1, w);
         }
         if (it % NP == NP - 1) {
             // survivors are rare (~2e-4 of the (row, query) pairs): one max over the round's accumulators decides
@@ -1245,7 +1245,6 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             if (it + 1 < nsteps) run_step(it + 1, wb, wa, in_lds);
         }
     } else {
-        if (nsteps > 0) load_step(0, wa);
         for (int it = 0; it < nsteps; ++it) run_step(it, wa, wb, in_lds);
     }
 }
@@ -1314,7 +1313,7 @@ static bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M 
 // three phases of 32 (64 KiB of tables, TWO 512-thread blocks per CU so that one block's refill hides behind the other's
 // gathers; 126 VGPRs, no spills, both blocks resident): 39 ms instead of 27 ms per 1200 queries flat, no change for the IVF
 // tasks — twice the refills per row and a third exposed code load per round cost more than the overlap returns.  Also without
-// effect on the 27 ms: requesting the next step's codes before the refill, and an XCD mapping of 8 groups x 4 tiles that
+// effect on the 27 ms (or worse): requesting the next step's codes before the refill, and an XCD mapping of 8 groups x 4 tiles that
 // keeps the tables L2-resident.  What the two-phase screen pays over 2 x the one-phase time (20 ms) is the pipeline
 // drain and ramp-up of 16 waves around the two barriers of every 2048-row round.
 static int adc_cf_phase_m(int M) { return M == 96 ? 48 : M; }
