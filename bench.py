@@ -455,7 +455,7 @@ def main():
                                            "peak": 157.3, "unit": "TFLOP/s",
                                            "frac": round(2.0 * (1 << 18) * nlist * D / cdt / 1e12 / 157.3, 4)}},
             "roofline": {"kernel": "adc_screen_cf_kernel<96,2,8,IVF> (list-centric: one block per (cell, <= 8 probing queries), "
-                                   "conflict-free 8-bit screen + exact rescoring); nprobe 8 takes the per-query scan",
+                                   "conflict-free 8-bit screen + exact rescoring); nprobe < 6 takes the per-query scan",
                          "bound": "hbm", "achieved": round(nq_batch * rows128 * M3 / t128 / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(nq_batch * rows128 * M3 / t128 / 1e9 / HBM_PEAK_GBS, 4),
                          "note": "nprobe = 128: rows probed x M code bytes per query / whole-search time (task list, LUT, "

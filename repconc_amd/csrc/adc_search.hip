@@ -63,6 +63,40 @@ __device__ __forceinline__ float adc_unorder_key(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+// One step of the 8-bit radix select: from the 256-bin histogram of the keys that match `prefix`, the bin that holds the
+// need-th largest key, i.e. the largest b with sum_{j >= b} hist[j] >= need — computed by 256 threads with a wave scan.
+// (One thread walking down from bin 255 is a chain of dependent LDS reads: ~10 us per pass, 40 of the 46 us a threshold
+// block took.)  Called by every thread of a block of >= 256 threads; `need` must have been read before; ends in a barrier.
+__device__ __forceinline__ void adc_pick_bin(const unsigned* hist, unsigned need, unsigned prefix, int shift, unsigned* s_scan,
+                                             unsigned* sel_prefix, unsigned* sel_rank) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned v = 0u, incl = 0u;
+    if (tid < 256) {
+        v = hist[255 - tid];                                  // thread t owns bin 255 - t: prefix over t = suffix over bins
+        incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = (unsigned)__shfl_up((int)incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_scan[wv] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) incl += (w < wv) ? s_scan[w] : 0u;
+        const unsigned excl = incl - v;
+        if (incl >= need && excl < need) {
+            *sel_prefix = prefix | ((unsigned)(255 - tid) << shift);
+            *sel_rank = need - excl;
+        } else if (tid == 255 && incl < need) {               // fewer matching keys than asked for: what the walk did
+            *sel_prefix = prefix;
+            *sel_rank = need - incl;
+        }
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------ 1. LUT
 // grid (nq, M), block 256 (= k).  j-ascending multiply then add, each rounded (no FMA).
 __global__ __launch_bounds__(RC_K) void adc_lut_kernel(const float* __restrict__ C, const float* __restrict__ q,
@@ -218,6 +252,7 @@ __global__ __launch_bounds__(1024) void adc_threshold_kernel(const float* __rest
     unsigned* keys = reinterpret_cast<unsigned*>(smem);  // [S]
     __shared__ unsigned hist[256];
     __shared__ unsigned sel_prefix, sel_rank;
+    __shared__ unsigned s_scan[4];
     const int qi = blockIdx.x, tid = threadIdx.x;
     if (r <= 0 || r > S) {
         if (tid == 0) thr[qi] = -INFINITY;
@@ -237,17 +272,7 @@ __global__ __launch_bounds__(1024) void adc_threshold_kernel(const float* __rest
             if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned need = sel_rank, b = 255;
-            for (;; --b) {
-                if (hist[b] >= need) break;
-                need -= hist[b];
-                if (b == 0) break;
-            }
-            sel_prefix = prefix | (b << shift);
-            sel_rank = need;
-        }
-        __syncthreads();
+        adc_pick_bin(hist, sel_rank, prefix, shift, s_scan, &sel_prefix, &sel_rank);
     }
     if (tid == 0) thr[qi] = adc_unorder_key(sel_prefix);
 }
@@ -280,6 +305,7 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __
     // sort network then runs on ~k keys instead of the whole list.
     __shared__ unsigned hist[256];
     __shared__ unsigned sel_prefix, sel_rank, survivors;
+    __shared__ unsigned s_scan[4];
     int n = cnt;
     if (in_lds && cnt > 2048 && cnt > 2 * k) {
         if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)k; survivors = 0u; }
@@ -295,17 +321,7 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __
                 if ((sk & himask) == prefix) atomicAdd(&hist[(sk >> shift) & 0xFFu], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned need = sel_rank, b = 255;
-                for (;; --b) {
-                    if (hist[b] >= need) break;
-                    need -= hist[b];
-                    if (b == 0) break;
-                }
-                sel_prefix = prefix | (b << shift);
-                sel_rank = need;
-            }
-            __syncthreads();
+            adc_pick_bin(hist, sel_rank, prefix, shift, s_scan, &sel_prefix, &sel_rank);
         }
         const unsigned kth = sel_prefix;                      // k-th largest score key
         for (int i = tid; i < cnt; i += 1024) {
@@ -1251,8 +1267,11 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
 
 // One block per query: exact fp32 score (m ascending, from 0) of every screened row; rows with score >= tau go
 // to the key list exactly as adc_scan_kernel<FILTER> would have put them.
+// 512 threads: a block's table is 4 M x 256 bytes of LDS (three blocks per CU at M = 48), and every survivor costs one
+// dependent 48-byte read from HBM - more rows in flight per CU
+#define ADC_RESCORE_THREADS 512
 template <int M>
-__global__ __launch_bounds__(256) void adc_rescore_kernel(const uint8_t* __restrict__ codes,
+__global__ __launch_bounds__(ADC_RESCORE_THREADS) void adc_rescore_kernel(const uint8_t* __restrict__ codes,
                                                           const float* __restrict__ lut,
                                                           const float* __restrict__ thr,
                                                           const unsigned* __restrict__ id_count,
@@ -1264,13 +1283,13 @@ __global__ __launch_bounds__(256) void adc_rescore_kernel(const uint8_t* __restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tab = reinterpret_cast<float*>(smem);  // [M][256]
     const int qi = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < M * RC_K; i += 256) tab[i] = lut[(size_t)qi * M * RC_K + i];
+    for (int i = tid; i < M * RC_K; i += ADC_RESCORE_THREADS) tab[i] = lut[(size_t)qi * M * RC_K + i];
     const unsigned raw = id_count[qi];
     const unsigned cnt = raw > ADC_ID_CAP ? ADC_ID_CAP : raw;
     if (tid == 0 && raw > ADC_ID_CAP) atomicOr(status, 2);
     const float tau = thr[qi];
     __syncthreads();
-    for (unsigned i0 = 0; i0 < cnt; i0 += 256) {
+    for (unsigned i0 = 0; i0 < cnt; i0 += ADC_RESCORE_THREADS) {
         const unsigned i = i0 + tid;
         const bool live = i < cnt;
         const unsigned n = ids[(size_t)qi * ADC_ID_CAP + (live ? i : 0)];
@@ -1494,7 +1513,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
     auto krescore = adc_rescore_kernel<M>;
     const size_t rl = (size_t)M * RC_K * sizeof(float);
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-    hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(256), rl, s, codes, b.lut, b.thr, b.idcnt, b.ids, b.cnt, b.cand,
+    hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(ADC_RESCORE_THREADS), rl, s, codes, b.lut, b.thr, b.idcnt, b.ids, b.cnt, b.cand,
                        status, (const int64_t*)nullptr);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
@@ -1670,6 +1689,7 @@ __global__ __launch_bounds__(1024) void ivf_rank_select_kernel(const float* __re
                                                                float* __restrict__ thr) {
     __shared__ unsigned hist[256];
     __shared__ unsigned sel_prefix, sel_rank;
+    __shared__ unsigned s_scan[4];
     const int qi = blockIdx.x, tid = threadIdx.x;
     const int n = scount[qi], k = rank[qi];
     if (k <= 0 || k > n) {
@@ -1690,17 +1710,7 @@ __global__ __launch_bounds__(1024) void ivf_rank_select_kernel(const float* __re
             if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFFu], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned need = sel_rank, b = 255;
-            for (;; --b) {
-                if (hist[b] >= need) break;
-                need -= hist[b];
-                if (b == 0) break;
-            }
-            sel_prefix = prefix | (b << shift);
-            sel_rank = need;
-        }
-        __syncthreads();
+        adc_pick_bin(hist, sel_rank, prefix, shift, s_scan, &sel_prefix, &sel_rank);
     }
     if (tid == 0) thr[qi] = adc_unorder_key(sel_prefix);
 }
@@ -1785,7 +1795,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
         auto krescore = adc_rescore_kernel<M>;
         const size_t rl = (size_t)M * RC_K * sizeof(float);
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-        hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(256), rl, s, codes, lut, (const float*)thr, (const unsigned*)idcnt,
+        hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(ADC_RESCORE_THREADS), rl, s, codes, lut, (const float*)thr, (const unsigned*)idcnt,
                            (const unsigned*)ids, cnt, cand, status, rowmap);
         RC_LAUNCH_CHECK(h);
     }
@@ -2001,6 +2011,7 @@ __global__ __launch_bounds__(1024) void ivf_probe_select_kernel(const float* __r
     unsigned* keys = reinterpret_cast<unsigned*>(smem);  // [nlist]
     __shared__ unsigned hist[256];
     __shared__ unsigned sel_prefix, sel_rank;
+    __shared__ unsigned s_scan[4];
     __shared__ int s_gt[16], s_eq[16];
     const int qi = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < nlist; i += 1024) keys[i] = adc_order_key(scores[(size_t)qi * nlist + i]);
@@ -2017,17 +2028,7 @@ __global__ __launch_bounds__(1024) void ivf_probe_select_kernel(const float* __r
             if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned need = sel_rank, b = 255;
-            for (;; --b) {
-                if (hist[b] >= need) break;
-                need -= hist[b];
-                if (b == 0) break;
-            }
-            sel_prefix = prefix | (b << shift);
-            sel_rank = need;
-        }
-        __syncthreads();
+        adc_pick_bin(hist, sel_rank, prefix, shift, s_scan, &sel_prefix, &sel_rank);
     }
     const unsigned T = sel_prefix;
     const int need = (int)sel_rank;                        // how many of the cells tied at T belong to the selection

@@ -214,7 +214,7 @@ class IVFPQIndex:
     SAMPLE_ROWS = 6144              # ... so that about this many sampled rows per query place the candidate threshold
     CAND_CAP = 16384                # candidate keys per query (ADC_CAND_CAP)
     KEEP_ALL_ROWS = 4096            # queries probing no more rows than this re-score every row (no threshold)
-    LISTS_MIN_ROWS = 16384          # "auto": average probed rows per query from which the list-centric search pays (M = 96, 1200 queries: equal at 14 k)
+    LISTS_MIN_ROWS = 10000          # "auto": average probed rows per query from which the list-centric search pays (M = 96, 1200 queries: equal at ~8 k)
 
     def _sample_step(self, nprobe: int) -> int:
         """about SAMPLE_ROWS exactly scored rows per query place the candidate threshold"""
