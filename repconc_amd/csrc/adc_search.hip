@@ -855,27 +855,24 @@ __global__ __launch_bounds__(256) void adc_scan_image_kernel(const uint8_t* __re
 #define ADC_QSTAT_STRIDE 128          // floats per query: lo[0..M), delta at [127]
 __global__ __launch_bounds__(RC_K) void adc_qstats_kernel(const float* __restrict__ lut, const float* __restrict__ thr,
                                                           int M, float* __restrict__ qstat, int* __restrict__ tint) {
-    __shared__ float s_lo[4][ADC_QSTAT_STRIDE], s_hi[4][ADC_QSTAT_STRIDE];
+    __shared__ float s_lo[ADC_QSTAT_STRIDE];
     __shared__ float s_rng[ADC_QSTAT_STRIDE];
-    const int qi = blockIdx.x, c = threadIdx.x;
+    const int qi = blockIdx.x, c = threadIdx.x, lane = c & 63, wv = c >> 6;
     const float* lq = lut + (size_t)qi * M * RC_K;
-    for (int m = 0; m < M; ++m) {
-        const float v = lq[m * RC_K + c];
-        float lo = v, hi = v;
+    // a wave owns sub-quantisers wv, wv + 4, ...: four codes per lane, one wave reduction per sub-quantiser
+    for (int m = wv; m < M; m += 4) {
+        const float4 v = reinterpret_cast<const float4*>(lq + (size_t)m * RC_K)[lane];
+        float lo = fminf(fminf(v.x, v.y), fminf(v.z, v.w)), hi = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             lo = fminf(lo, __shfl_xor(lo, o));
             hi = fmaxf(hi, __shfl_xor(hi, o));
         }
-        if ((c & 63) == 0) { s_lo[c >> 6][m] = lo; s_hi[c >> 6][m] = hi; }
-    }
-    __syncthreads();
-    if (c < M) {
-        const float lo = fminf(fminf(s_lo[0][c], s_lo[1][c]), fminf(s_lo[2][c], s_lo[3][c]));
-        const float hi = fmaxf(fmaxf(s_hi[0][c], s_hi[1][c]), fmaxf(s_hi[2][c], s_hi[3][c]));
-        qstat[(size_t)qi * ADC_QSTAT_STRIDE + c] = lo;
-        s_lo[0][c] = lo;
-        s_rng[c] = hi - lo;
+        if (lane == 0) {
+            qstat[(size_t)qi * ADC_QSTAT_STRIDE + m] = lo;
+            s_lo[m] = lo;
+            s_rng[m] = hi - lo;
+        }
     }
     __syncthreads();
     if (c == 0) {
@@ -883,7 +880,7 @@ __global__ __launch_bounds__(RC_K) void adc_qstats_kernel(const float* __restric
         double A = 0.0;
         for (int m = 0; m < M; ++m) {
             maxrange = fmaxf(maxrange, s_rng[m]);
-            A += (double)s_lo[0][m];
+            A += (double)s_lo[m];
         }
         float delta = maxrange / 255.0f;
         if (!(delta > 0.f)) delta = 1.0f;
