@@ -16,17 +16,28 @@
 // with the VALU, so the screen splits every fp32 operand in two bf16 pieces, v = vh + vl + (|rest| <= 2^-18 |v|), and
 // takes three products  wh.xh + wh.xl + wl.xh  (w = -2c) accumulated in fp32:
 //     dropped terms  <= 3.1 * 2^-18 * sum|w_j x_j|  <= 1.2e-5 (||x||^2 + ||c||^2)
-//     fp32 accumulation of 3*KP+3 terms (||c||^2 enters as 3 exact bf16 pieces times 1.0), each <= 1 ulp of a partial sum <= 2 (||x||^2+||c||^2):  (3 KP + 1) 2.4e-7
-//     ||c||^2 and the reference's own d: (dsub+2) 1.2e-7 each; the 4 tag bits (below): 3.8e-6
-// => E = [1.6e-5 + (3 KP + 2 dsub + 5) 2.4e-7] (||x||^2 + max_k ||c_k||^2),  margin = 2 E.
+//     fp32 accumulation of 3*KP+6 terms (||c||^2 and the document offset below enter as 3 exact bf16 pieces each), each
+//       <= 1 ulp of a partial sum <= 3 (||x||^2+||c||^2):  (3 KP + 7) 3.6e-7
+//     ||c||^2 and the reference's own d: (dsub+2) 1.2e-7 each; the 4 tag bits (below): 5.7e-6
+// => E = [1.8e-5 + (3 KP + 7) 3.6e-7 + (2 dsub + 4) 1.2e-7] (||x||^2 + max_k ||c_k||^2),  margin = 2 E.
 //
 // Mapping (v_mfma_f32_32x32x16_bf16, 32 cycles): D = A*B + C with A[i][kk] = piece of -2 c_{32 kt + i}[kk] (LDS, 16 B
-// per lane), B[kk][j] = piece of x_{b0 + j}[kk] (registers), C = ||c||^2; rows of D = centroids, columns = documents,
-// so a lane holds 16 centroids of ONE document per tile and the running (min, second min) needs no cross-lane traffic
-// until the two half-waves merge once per sub-quantiser.  A wave owns 64 documents (two column sets): the A fragments
-// and ||c||^2 of a centroid tile are read once for both, and the two accumulator tiles ping-pong so that the VALU
-// epilogue of one overlaps the MFMAs of the next.  The kernel is then bound by that epilogue: 3 VALU ops per
-// (document, centroid) pair — v_and_or (tag), v_med3 (second min), v_med3 (min).
+// per lane), B[kk][j] = piece of x_{b0 + j}[kk] (registers); one more MFMA adds ||c||^2 (three pieces against 1.0) and a
+// per-document offset ||x_b||^2 + margin (1.0 against its three pieces) — so every screened value is distance^2 + margin > 0,
+// the float bits order like signed integers, and the epilogue may mix v_med3_f32 with v_min3_i32 (integer instructions
+// need no canonicalisation of the bit-tagged operands).  Rows of D = centroids, columns = documents, so a lane holds 16
+// centroids of ONE document per tile and the running (min, second min) needs no cross-lane traffic until the two
+// half-waves merge once per sub-quantiser.  A wave owns 64 documents (two column sets): the A fragments of a centroid tile
+// are read once for both, and the two accumulator tiles ping-pong so that the VALU epilogue of one overlaps the MFMAs of
+// the next.  Epilogue per (document, centroid) pair: v_and_or (tag) + 1.25 instructions — candidates are folded in pairs,
+// t = med3(m1, u1, u2), m2' = min(m2, t), m1' = min3(m1, u1, u2), and the compiler merges the m2 updates of two pairs
+// into one min3 (round 1/2a: two v_med3 per candidate, 3 instructions in all).  The staged centroids (bf16 pieces, norms)
+// are the same for every block: assign_prep_kernel writes them once per call and the blocks fetch them with
+// global_load_lds_dwordx4 straight into the free LDS buffer (no registers, no conversion per block).
+// [MI355X] 2^20 rows, M = 48: 2.29 ms = 458 M vectors/s (2.40-2.45 ms before the pair folding and the prepared
+// centroids); VALU instructions per wave and sub-quantiser 1150 -> ~870, matrix pipe 35 % busy — what is left is not
+// issue-bound on either pipe (waves wait ~45 % of their cycles: LDS operand reads ahead of every MFMA, one barrier per
+// sub-quantiser).
 #include "rc_common.h"
 
 #include <type_traits>
@@ -120,6 +131,54 @@ struct mf_geom {
     static constexpr int BUF_BYTES = RC_K * KP * 2 * 2 + RC_K * 16 + 32;  // hi | lo | cn pieces | wave maxima
 };
 
+// Staged centroids of every sub-quantiser, in the LDS layout of assign_mfma_kernel: grid M, block 256 (thread = centroid).
+template <int DSUB>
+__global__ __launch_bounds__(256) void assign_prep_kernel(const float* __restrict__ C, unsigned char* __restrict__ cpre) {
+    using G = mf_geom<DSUB>;
+    constexpr int KP = G::KP;
+    const int tid = threadIdx.x, m = blockIdx.x, wv = tid >> 6, l = tid & 63;
+    unsigned char* buf = cpre + (size_t)m * G::BUF_BYTES;
+    float4 cst[DSUB / 4];
+    const float4* cp = reinterpret_cast<const float4*>(C + ((size_t)m * RC_K + tid) * DSUB);
+#pragma unroll
+    for (int j4 = 0; j4 < DSUB / 4; ++j4) cst[j4] = cp[j4];
+    uint4* whi = reinterpret_cast<uint4*>(buf) + (size_t)tid * (KP / 8);
+    uint4* wlo = reinterpret_cast<uint4*>(buf + RC_K * KP * 2) + (size_t)tid * (KP / 8);
+    uint4* cn3 = reinterpret_cast<uint4*>(buf + RC_K * KP * 4);
+    float* wmax = reinterpret_cast<float*>(buf + RC_K * KP * 4 + RC_K * 16);
+    float nrm = 0.f;
+#pragma unroll
+    for (int g = 0; g < KP / 8; ++g) {                          // 8 elements -> one 16-byte chunk of each piece
+        unsigned h[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (8 * g + 4 * q < DSUB) {
+                const float4 v = cst[2 * g + q];
+                mf_split2(-2.0f * v.x, -2.0f * v.y, h[2 * q], lo[2 * q]);
+                mf_split2(-2.0f * v.z, -2.0f * v.w, h[2 * q + 1], lo[2 * q + 1]);
+                nrm = __builtin_fmaf(v.x, v.x, nrm);
+                nrm = __builtin_fmaf(v.y, v.y, nrm);
+                nrm = __builtin_fmaf(v.z, v.z, nrm);
+                nrm = __builtin_fmaf(v.w, v.w, nrm);
+            }
+        }
+        whi[g] = make_uint4(h[0], h[1], h[2], h[3]);
+        wlo[g] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    {   // ||c||^2 = p0 + p1 + p2 exactly (3 x 8 significant bits); it enters the tile as one more MFMA against ones
+        unsigned p01, r01, p2, dummy;
+        mf_split2(nrm, 0.f, p01, r01);                           // p01.lo16 = p0, r01.lo16 = p1
+        const float rest = (nrm - __uint_as_float(p01 << 16)) - __uint_as_float(r01 << 16);
+        mf_split2(rest, 0.f, p2, dummy);
+        // k-slots 0-2: the pieces of ||c||^2 (against 1.0);  k-slots 3-5: 1.0 against the pieces of the document's offset
+        cn3[tid] = make_uint4((p01 & 0xFFFFu) | (r01 << 16), (p2 & 0xFFFFu) | 0x3F800000u, 0x3F803F80u, 0u);
+    }
+    float mx = nrm;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (l == 0) wmax[wv] = mx;
+}
+
 // LDS per block: NBUF x { whi[256][KP] bf16 | wlo[256][KP] bf16 | cn3[256] (3 bf16 pieces of ||c||^2, 16 B) | wave
 // maxima[8] } | code tile [256][M].
 // NBUF = 2: sub-quantiser m+1's centroids are fetched into registers before the tile loop of m and written to the other
@@ -129,7 +188,7 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
                                                           const float* __restrict__ C, int64_t B, int M,
                                                           uint8_t* __restrict__ codes_u8, int64_t* __restrict__ codes_i64,
                                                           unsigned* __restrict__ redo_count, unsigned* __restrict__ redo,
-                                                          unsigned redo_cap, int MC) {
+                                                          unsigned redo_cap, int MC, const unsigned char* __restrict__ cpre) {
     // blockIdx.y selects a chunk of MC sub-quantisers (small batches: more blocks than B / 256 alone would give)
     using G = mf_geom<DSUB>;
     constexpr int KP = G::KP, KS = G::KS, NBUF = G::NBUF;
@@ -148,48 +207,23 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
         xrow[s] = x + (brow[s] < B ? brow[s] : (B - 1)) * ldx;
     }
 
-    float4 cst[DSUB / 4];                                           // centroid `tid` of the sub-quantiser being staged
-    auto fetch_c = [&](int m) {
-        const float4* cp = reinterpret_cast<const float4*>(C + ((size_t)m * RC_K + tid) * DSUB);
+    // The staged form of a sub-quantiser's centroids (bf16 pieces of -2 c, pieces of ||c||^2, wave maxima) is the same for
+    // every block: assign_prep_kernel writes it once per call, in the LDS layout; here it is a plain copy (fetched into
+    // registers early, stored to the free buffer later).  Converting in every block cost ~90 VALU per wave and sub-quantiser.
+    constexpr int CH_TOTAL = G::BUF_BYTES / 16, CH_PER = (CH_TOTAL + 255) / 256;
+    // asynchronous copy global -> LDS (global_load_lds_dwordx4: 16 bytes per lane, a wave fills 1 KiB of consecutive LDS; no
+    // registers in between).  Completion = vmcnt, awaited with stage_wait() before the barrier that publishes the buffer.
+    auto stage = [&](int m, unsigned char* buf) {
+        const unsigned char* src = cpre + (size_t)m * G::BUF_BYTES;
 #pragma unroll
-        for (int j4 = 0; j4 < DSUB / 4; ++j4) cst[j4] = cp[j4];
-    };
-    auto store_c = [&](unsigned char* buf) {                        // pieces of -2 c_k, cn[k] = sum_j c_kj^2
-        uint4* whi = reinterpret_cast<uint4*>(buf) + (size_t)tid * (KP / 8);
-        uint4* wlo = reinterpret_cast<uint4*>(buf + RC_K * KP * 2) + (size_t)tid * (KP / 8);
-        uint4* cn3 = reinterpret_cast<uint4*>(buf + RC_K * KP * 4);
-        float* wmax = reinterpret_cast<float*>(buf + RC_K * KP * 4 + RC_K * 16);
-        float nrm = 0.f;
-#pragma unroll
-        for (int g = 0; g < KP / 8; ++g) {                          // 8 elements -> one 16-byte chunk of each piece
-            unsigned h[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (8 * g + 4 * q < DSUB) {
-                    const float4 v = cst[2 * g + q];
-                    mf_split2(-2.0f * v.x, -2.0f * v.y, h[2 * q], lo[2 * q]);
-                    mf_split2(-2.0f * v.z, -2.0f * v.w, h[2 * q + 1], lo[2 * q + 1]);
-                    nrm = __builtin_fmaf(v.x, v.x, nrm);
-                    nrm = __builtin_fmaf(v.y, v.y, nrm);
-                    nrm = __builtin_fmaf(v.z, v.z, nrm);
-                    nrm = __builtin_fmaf(v.w, v.w, nrm);
-                }
-            }
-            whi[g] = make_uint4(h[0], h[1], h[2], h[3]);
-            wlo[g] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        for (int j = 0; j < CH_PER; ++j) {
+            const int w0 = 256 * j + (tid & ~63);                    // first chunk of this wave (wave-uniform)
+            if (w0 + l < CH_TOTAL)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(w0 + l) * 16),
+                                                 (__attribute__((address_space(3))) void*)(buf + (size_t)w0 * 16), 16, 0, 0);
         }
-        {   // ||c||^2 = p0 + p1 + p2 exactly (3 x 8 significant bits); it enters the tile as one more MFMA against ones
-            unsigned p01, r01, p2, dummy;
-            mf_split2(nrm, 0.f, p01, r01);                           // p01.lo16 = p0, r01.lo16 = p1
-            const float rest = (nrm - __uint_as_float(p01 << 16)) - __uint_as_float(r01 << 16);
-            mf_split2(rest, 0.f, p2, dummy);
-            cn3[tid] = make_uint4((p01 & 0xFFFFu) | (r01 << 16), p2 & 0xFFFFu, 0u, 0u);
-        }
-        float mx = nrm;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        if (l == 0) wmax[wv] = mx;
     };
+    auto stage_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     // this lane's 8 elements of k-step ks: [16 ks + 8 half, +8); zero beyond DSUB
     float4 xq[MF_SETS][KS][2];
     auto fetch_x = [&](int m) {
@@ -207,9 +241,9 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
 
     const int m0 = blockIdx.y * MC;
     const int mc = (m0 + MC <= M) ? MC : (M - m0);
-    fetch_c(m0);
+    stage(m0, mf_smem);
     fetch_x(m0);
-    store_c(mf_smem);
+    stage_wait();
     __syncthreads();
 
     for (int mi = 0; mi < mc; ++mi) {
@@ -245,22 +279,37 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
             }
             xn[s] = nrm + __shfl_xor(nrm, 32);
         }
+        // rounding bound of the screen (file header): margin = 2 E
+        constexpr float MARGIN = 2.0f * (1.8e-5f + (float)(3 * KP + 7) * 3.6e-7f + (float)(2 * DSUB + 4) * 1.2e-7f);
+        // B operand of the ||c||^2 MFMA: 1.0 in k-slots 0-2, and in k-slots 3-5 the three bf16 pieces of the document's
+        // offset ||x||^2 + margin: every screened value becomes (distance^2 + margin) > 0, so the float bits order like
+        // signed integers and the epilogue can use v_min3_i32 / v_min_i32 next to v_med3_f32
+        mf_bf16x8 bcn[MF_SETS];
+#pragma unroll
+        for (int s = 0; s < MF_SETS; ++s) {
+            const float off = xn[s] + MARGIN * (xn[s] + cnmax);
+            unsigned p01, r01, p2, dummy;
+            mf_split2(off, 0.f, p01, r01);
+            const float rest = (off - __uint_as_float(p01 << 16)) - __uint_as_float(r01 << 16);
+            mf_split2(rest, 0.f, p2, dummy);
+            bcn[s] = __builtin_bit_cast(mf_bf16x8, make_uint4(0x3F803F80u, 0x00003F80u | (p01 << 16),
+                                                              (r01 & 0xFFFFu) | (p2 << 16), 0u));
+        }
         const int mn = (mi + 1 < mc) ? m + 1 : m;
         fetch_x(mn);                                                // in flight during the tile loop
-        if (NBUF == 2) fetch_c(mn);
+        if (NBUF == 2 && mi + 1 < mc)                               // the other buffer: last read before the previous barrier
+            stage(m + 1, mf_smem + ((mi + 1) & 1) * G::BUF_BYTES);
 
         // Tiles T(kt, set), accumulators ping-pong: MFMAs of one tile  ||  epilogue of the previous one.
         // Epilogue: running best / second best over this lane's 16 centroids of the tile; the register index r rides
         // in the 4 low mantissa bits, the tile index of the best is tracked once per tile.
         float m1[MF_SETS], m2[MF_SETS];
         int ktb[MF_SETS];
-        const float ninf = mf_opaque_neg_inf();
 #pragma unroll
         for (int s = 0; s < MF_SETS; ++s) { m1[s] = INFINITY; m2[s] = INFINITY; ktb[s] = 0; }
         constexpr int NMF = 3 * KS + 1;                             // MFMAs per tile
         constexpr int PER = (16 + NMF - 1) / NMF;                   // epilogue elements per MFMA slot
         struct afrag { mf_bf16x8 h[KS], l[KS], cn; };
-        const mf_bf16x8 ones = __builtin_bit_cast(mf_bf16x8, make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u));
         auto load_a = [&](afrag& A, int kt) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -271,12 +320,31 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
             const uint4 c = cn3[kt * 32 + col];
             A.cn = __builtin_bit_cast(mf_bf16x8, half ? make_uint4(0u, 0u, 0u, 0u) : c);
         };
+        // Candidates are folded in PAIRS: with t = second smallest of {m1, u1, u2} = med3(m1, u1, u2),
+        //     m2' = min(m2, t),   m1' = min3(m1, u1, u2)
+        // — 3 instructions per pair instead of 2 per candidate (the values are positive, see bcn: integer min = float min,
+        // and integer instructions need no canonicalisation of the bit-tagged operands).
+        auto tagged = [&](const mf_f32x16& a, int r) {
+            return __uint_as_float((__float_as_uint(a[r]) & 0xFFFFFFF0u) | (unsigned)r);
+        };
+        auto imin = [](float a, float b) {
+            const int x = (int)__float_as_uint(a), y = (int)__float_as_uint(b);
+            return __uint_as_float((unsigned)(x < y ? x : y));
+        };
         auto scan = [&](const mf_f32x16& a, int s, int r0, int cnt) {
+            const int r1 = (r0 + cnt < 16) ? r0 + cnt : 16;
 #pragma unroll
-            for (int r = r0; r < r0 + cnt && r < 16; ++r) {
-                const float u = __uint_as_float((__float_as_uint(a[r]) & 0xFFFFFFF0u) | (unsigned)r);
-                m2[s] = mf_med3(m1[s], m2[s], u);
-                m1[s] = mf_med3(m1[s], u, ninf);
+            for (int r = r0; r < r1; r += 2) {
+                const float u1 = tagged(a, r);
+                if (r + 1 < r1) {
+                    const float u2 = tagged(a, r + 1);
+                    const float t = mf_med3(m1[s], u1, u2);
+                    m2[s] = imin(m2[s], t);
+                    m1[s] = imin(imin(m1[s], u1), u2);
+                } else {
+                    m2[s] = mf_med3(m1[s], m2[s], u1);
+                    m1[s] = imin(m1[s], u1);
+                }
             }
         };
         // W = true: issue the MFMAs of tile (A, set sw) into aw;  R = true: run the epilogue of tile (kr, set sr) from ar
@@ -289,7 +357,7 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
                 if constexpr (w) {
                     if (j == 0) {
                         const mf_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        aw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.cn, ones, zero, 0, 0, 0);
+                        aw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.cn, bcn[SW], zero, 0, 0, 0);
                     } else {
                         const int ks = (j - 1) / 3, t = (j - 1) % 3;
                         aw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 2 ? A.l[ks] : A.h[ks],
@@ -303,7 +371,7 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
 #pragma unroll
                 for (int j = 0; j < NMF; ++j) {                     // issue order: 1 MFMA, then its share of the epilogue
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3 * PER, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, PER + 3 * (PER / 2) + 2 * (PER % 2), 0);
                 }
             }
         };
@@ -332,8 +400,6 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
             step(T_{}, T_{}, acc1, A1, S1{}, acc0, S0{}, kt + 1);
             step(F_{}, T_{}, acc0, A1, S0{}, acc1, S1{}, kt + 1);
         }
-        // rounding bound of the screen (file header): margin = 2 E
-        constexpr float MARGIN = 2.0f * (1.6e-5f + (float)(3 * KP + 2 * DSUB + 5) * 2.4e-7f);
 #pragma unroll
         for (int s = 0; s < MF_SETS; ++s) {
             const int r = (int)(__float_as_uint(m1[s]) & 15u);
@@ -362,12 +428,12 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
         }
         if (mi + 1 < mc) {
             if (NBUF == 2) {
-                store_c(mf_smem + ((mi + 1) & 1) * G::BUF_BYTES);    // the other buffer: last read before the previous barrier
+                stage_wait();
                 __syncthreads();
             } else {
                 __syncthreads();                                    // every wave is done with this buffer
-                fetch_c(m + 1);
-                store_c(mf_smem);
+                stage(m + 1, mf_smem);
+                stage_wait();
                 __syncthreads();
             }
         }
@@ -454,9 +520,11 @@ __global__ __launch_bounds__(256) void assign_redo_kernel(const float* __restric
 // 2^20-row chunk at M = 48), so no caller has to synchronise and re-run
 static unsigned mf_redo_cap(int64_t B, int M) { return (unsigned)(B * M); }
 
+#define MF_PREP_MAX_BYTES (RC_K * 96 * 4 + RC_K * 16 + 256)
 extern "C" size_t rc_pq_assign_nearest_fast_ws_bytes(int64_t B, int M) {
     if (B <= 0 || M <= 0) return 0;
-    return rc_align_up(256 + (size_t)mf_redo_cap(B, M) * sizeof(unsigned), 256);
+    // doubt list + the staged centroids (assign_prep_kernel; at most 25 KiB + 4 KiB per sub-quantiser, dsub <= 96)
+    return rc_align_up(256 + (size_t)mf_redo_cap(B, M) * sizeof(unsigned), 256) + (size_t)M * MF_PREP_MAX_BYTES;
 }
 
 // Asynchronous and complete: every doubtful pair (at most B*M of them) is re-judged exactly by assign_redo_kernel.
@@ -474,6 +542,7 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
     unsigned* redo_count = (unsigned*)ws;
     unsigned* redo = (unsigned*)((char*)ws + 256);
     const unsigned cap = mf_redo_cap(B, M);
+    unsigned char* cpre = (unsigned char*)ws + rc_align_up(256 + (size_t)cap * sizeof(unsigned), 256);
     RC_HIP_CHECK(h, hipMemsetAsync(redo_count, 0, 256, s));
     const int dsub = D / M;
     const int64_t nblk = (B + MF_ROWS_PER_BLOCK - 1) / MF_ROWS_PER_BLOCK;
@@ -488,8 +557,9 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
         case DS: {                                                                                                       \
             auto kern = assign_mfma_kernel<DS>;                                                                          \
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(assign_prep_kernel<DS>, dim3((unsigned)M), dim3(256), 0, s, C, cpre);                     \
             hipLaunchKernelGGL(kern, dim3((unsigned)nblk, nchunk), dim3(256), lds, s, x, ldx, C, B, M, codes_u8, codes_i64, \
-                               redo_count, redo, cap, MC);                                                                   \
+                               redo_count, redo, cap, MC, (const unsigned char*)cpre);                                       \
             hipLaunchKernelGGL(assign_redo_kernel<DS>, dim3((unsigned)(h->num_cus * 4)), dim3(256), 0, s, x, ldx, C, M,  \
                                redo_count, redo, cap, codes_u8, codes_i64);                                              \
         } break;
