@@ -494,9 +494,10 @@ def main():
                          "achieved": round(nb * bytes_per_vec / (ib["mfma"][1] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(nb * bytes_per_vec / (ib["mfma"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic("assign_mfma_kernel"), "algorithmic_bytes_per_launch": nb * bytes_per_vec,
-                         "note": "far from the HBM roof by construction: 256 candidate distances per (row, sub-quantiser) "
-                                 "cost 3 VALU ops each in the min/second-min epilogue (VALU ~80 % busy, PMC), the bf16 "
-                                 "MFMAs run underneath (DESIGN.md §3.5)"},
+                         "note": "far from the HBM roof by construction: 256 candidate distances per (row, sub-quantiser), "
+                                 "2.25 VALU instructions each in the pair-folded min/second-min epilogue, the bf16 MFMAs "
+                                 "underneath; after round 2 neither pipe is saturated (VALU ~64 %, matrix pipe ~37 %, waves "
+                                 "wait on LDS operand reads and the per-sub-quantiser barrier; DESIGN.md §3.4)"},
         }
         del xb
 
