@@ -84,11 +84,12 @@ int rc_pq_assign_nearest(rc_handle_t h, const float* x, int64_t ldx, const float
                          int D, int M, int K, uint8_t* codes_u8, int64_t* codes_i64,
                          rc_stream_t stream);
 
-/* Same codes, bit for bit, ~4.6x faster: the bf16 matrix cores (v_mfma_f32_32x32x16_bf16 on operands split into two
+/* Same codes, bit for bit, ~5.7x faster: the bf16 matrix cores (v_mfma_f32_32x32x16_bf16 on operands split into two
  * bf16 pieces, three products) screen with the GEMM form ||c||^2 - 2<c,x>; every (row, m) whose best/second-best gap is
  * inside the rounding bound of that form is recomputed with the reference's exact arithmetic and first-minimum rule
  * (csrc/pq_assign_mfma.hip).  x must be 16-byte aligned with ldx % 4 == 0 and B*M < 2^32.
- * ws: rc_pq_assign_nearest_fast_ws_bytes(B, M) bytes (one doubt-list slot per pair: the list cannot overflow).
+ * ws: rc_pq_assign_nearest_fast_ws_bytes(B, M) bytes (one doubt-list slot per pair: the list cannot overflow; plus the
+ * staged bf16 image of the centroids, written once per call by assign_prep_kernel and fetched by every block).
  * Asynchronous and complete — no follow-up call is needed.  rc_pq_assign_nearest_fast_overflow (synchronises) only
  * reports the number of doubtful pairs in *doubtful and returns 0. */
 size_t rc_pq_assign_nearest_fast_ws_bytes(int64_t B, int M);
