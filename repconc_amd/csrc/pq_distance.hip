@@ -10,57 +10,67 @@
 
 // d = sum_j (x_j - c_j)^2 in torch-CPU order.  XA / CA are anything indexable ([]), so callers
 // can keep one operand in VGPRs and let the other come from scalar (wave-uniform) loads.
+// The element-wise part (sub, square, the lane-wise accumulator adds) is written on pairs of floats: gfx950 executes a
+// <2 x float> add / mul as ONE packed instruction (v_pk_add_f32 / v_pk_mul_f32, IEEE per element), which takes the
+// 47 VALU instructions of a 16-wide distance down to 27; only the final 8-lane chain stays scalar.
+typedef float rc_f32x2 __attribute__((ext_vector_type(2)));
 template <int DSUB, typename XA, typename CA>
 __device__ __forceinline__ float sqdist_exact(const XA& x, const CA& c) {
+    static_assert(DSUB % 2 == 0, "pairs");
     constexpr int NV = DSUB / 8;    // 8-wide vectors in the row
     constexpr int TAIL = DSUB % 8;  // trailing scalars
     constexpr int FULL = NV / 4;    // rounds that feed all four accumulators
-    float sq[DSUB];
+    rc_f32x2 sq[DSUB / 2];          // sq[4 v + p] = lanes (2 p, 2 p + 1) of vector v
 #pragma unroll
-    for (int j = 0; j < DSUB; ++j) {
-        const float t = x[j] - c[j];
+    for (int j = 0; j < DSUB / 2; ++j) {
+        // x - c as x + (-c): the negation is exact and (with c loop-invariant in the callers) hoisted, the packed add has no
+        // packed subtract twin
+        const rc_f32x2 xv = {x[2 * j], x[2 * j + 1]}, ncv = {-c[2 * j], -c[2 * j + 1]};
+        const rc_f32x2 t = xv + ncv;
         sq[j] = t * t;
     }
-    float a[8];
+    rc_f32x2 a[4];
     if constexpr (FULL == 0) {
         // fewer than four vectors: they all land in accumulator 0, in order; the other
         // three accumulators stay +0 and adding them is exact.
 #pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            float s = sq[l];
+        for (int p = 0; p < 4; ++p) {
+            rc_f32x2 s = sq[p];
 #pragma unroll
-            for (int v = 1; v < NV; ++v) s = s + sq[8 * v + l];
-            a[l] = s;
+            for (int v = 1; v < NV; ++v) s = s + sq[4 * v + p];
+            a[p] = s;
         }
     } else {
-        float acc[4][8];
+        rc_f32x2 acc[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                float s = sq[8 * q + l];
+            for (int p = 0; p < 4; ++p) {
+                rc_f32x2 s = sq[4 * q + p];
 #pragma unroll
-                for (int i = 1; i < FULL; ++i) s = s + sq[8 * (4 * i + q) + l];
-                acc[q][l] = s;
+                for (int i = 1; i < FULL; ++i) s = s + sq[4 * (4 * i + q) + p];
+                acc[q][p] = s;
             }
 #pragma unroll
         for (int v = 4 * FULL; v < NV; ++v)
 #pragma unroll
-            for (int l = 0; l < 8; ++l) acc[0][l] = acc[0][l] + sq[8 * v + l];
+            for (int p = 0; p < 4; ++p) acc[0][p] = acc[0][p] + sq[4 * v + p];
 #pragma unroll
-        for (int l = 0; l < 8; ++l) a[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+        for (int p = 0; p < 4; ++p) a[p] = ((acc[0][p] + acc[1][p]) + acc[2][p]) + acc[3][p];
     }
     float r;
     if constexpr (TAIL == 0) {
-        r = a[0];  // (0 + lane0) is exact
+        r = a[0].x;  // (0 + lane0) is exact
+        r = r + a[0].y;
 #pragma unroll
-        for (int l = 1; l < 8; ++l) r = r + a[l];
+        for (int p = 1; p < 4; ++p) { r = r + a[p].x; r = r + a[p].y; }
     } else {
-        r = sq[NV * 8];
+        r = sq[NV * 4].x;
+        r = r + sq[NV * 4].y;
 #pragma unroll
-        for (int j = 1; j < TAIL; ++j) r = r + sq[NV * 8 + j];
+        for (int j = 1; j < TAIL / 2; ++j) { r = r + sq[NV * 4 + j].x; r = r + sq[NV * 4 + j].y; }
 #pragma unroll
-        for (int l = 0; l < 8; ++l) r = r + a[l];
+        for (int p = 0; p < 4; ++p) { r = r + a[p].x; r = r + a[p].y; }
     }
     return r;
 }
