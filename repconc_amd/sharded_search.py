@@ -45,3 +45,32 @@ def search_virtual_shards(shards: Sequence[PQIndex], q: torch.Tensor, k: int):
     """The same merge with the shards held by one process (single-GPU boxes, tests)."""
     parts = [sh.search(q, k) for sh in shards]
     return merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
+
+
+def replicated_search(index, q: torch.Tensor, k: int, *search_args, group=None):
+    """The reference's replica mode (`co.shard = False`, evaluate_repconc.py:131-134) in the one-process-per-GPU model,
+    and BASELINE configs[3] ("IVF nlist=5000 ADC search at 8 GPUs"): every rank holds the WHOLE index (flat `PQIndex` or
+    `IVFPQIndex`, anything with `search(q, k, *search_args)`), takes the contiguous slice [nq r / G, nq (r+1) / G) of the
+    query batch, searches it, and one all-gather of the padded (scores, ids) blocks gives every rank the full result in
+    query order — identical to the single-index search.  `q` is the same tensor on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return index.search(q, k, *search_args)
+    G, r = dist.get_world_size(group), dist.get_rank(group)
+    nq = q.shape[0]
+    bounds = [(nq * i) // G for i in range(G + 1)]
+    most = max(bounds[i + 1] - bounds[i] for i in range(G))
+    mine = q[bounds[r]:bounds[r + 1]]
+    if mine.shape[0]:
+        s, i = index.search(mine, k, *search_args)
+    else:
+        s = torch.empty((0, k), dtype=torch.float32, device=q.device)
+        i = torch.empty((0, k), dtype=torch.int64, device=q.device)
+    pad_s = torch.full((most, k), float("-inf"), dtype=torch.float32, device=s.device)
+    pad_i = torch.full((most, k), -1, dtype=torch.int64, device=s.device)
+    pad_s[: s.shape[0]], pad_i[: i.shape[0]] = s, i
+    all_s = torch.empty((G * most, k), dtype=torch.float32, device=s.device)
+    all_i = torch.empty((G * most, k), dtype=torch.int64, device=s.device)
+    dist.all_gather_into_tensor(all_s.view(-1), pad_s.view(-1), group=group)
+    dist.all_gather_into_tensor(all_i.view(-1), pad_i.view(-1), group=group)
+    keep = torch.cat([torch.arange(g * most, g * most + bounds[g + 1] - bounds[g], device=s.device) for g in range(G)])
+    return all_s[keep].contiguous(), all_i[keep].contiguous()

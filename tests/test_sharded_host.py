@@ -204,3 +204,49 @@ def test_gloo_rank_ordered_sum_and_rank0_broadcast_are_rank_identical():
     for r in range(world):
         assert np.array_equal(ret[r][0], want.numpy())          # the same bits on every rank, rank order
         assert np.array_equal(ret[r][1], ret[0][1])
+
+
+class _BruteIndex:
+    """Duck-typed index for the host-side test: exact inner-product top-k over a dense matrix, (score desc, id asc);
+    accepts the extra `nprobe` argument an IVF index takes."""
+
+    def __init__(self, base):
+        self.base = base
+
+    def search(self, q, k, nprobe=None):
+        s = q @ self.base.T
+        order = torch.argsort(s, dim=1, descending=True, stable=True)[:, :k]
+        return torch.gather(s, 1, order).contiguous(), order.contiguous()
+
+
+def _replica_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from repconc_amd.sharded_search import replicated_search
+    g = torch.Generator().manual_seed(11)                      # the same index and queries on every rank
+    index = _BruteIndex(torch.randn(300, 16, generator=g))
+    out = {}
+    for nq in (7, 2, 0):                                       # ragged split, fewer queries than ranks, none
+        q = torch.randn(nq, 16, generator=g)
+        s, i = replicated_search(index, q, 5, 8)
+        out[nq] = (s.numpy().copy(), i.numpy().copy())
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_gloo_replicated_search_splits_queries_and_gathers_in_order():
+    """sharded_search.replicated_search (replica mode of evaluate_repconc.py:131-134 with one process per GPU; also the
+    multi-GPU form of the IVF search): every rank ends with the single-index result, in query order."""
+    world = 3
+    ret = mp.Manager().dict()
+    mp.spawn(_replica_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(11)
+    index = _BruteIndex(torch.randn(300, 16, generator=g))
+    for nq in (7, 2, 0):
+        q = torch.randn(nq, 16, generator=g)
+        ws, wi = index.search(q, 5)
+        for r in range(world):
+            s, i = ret[r][nq]
+            assert s.shape == (nq, 5) and np.array_equal(i, wi.numpy())
+            np.testing.assert_allclose(s, ws.numpy(), rtol=1e-6, atol=1e-6)      # a one-row slice takes the GEMV path: last-ulp
