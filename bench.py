@@ -445,6 +445,14 @@ def main():
         same3 = bool(torch.equal(fs, s3) and float((ivf.ids[fi] == i3).float().mean()) > 0.999)   # ids may swap inside exact score ties
         rows128 = N_CORPUS * 128 // nlist
         t128 = nq_batch / sweep3["nprobe128"]
+        # the screen kernel alone (HIP events around its launch), nprobe = 128: against the measured LDS gather roof
+        lib.rc_profile_enable(h, 1)
+        ivf.search(qi, k, 128)
+        torch.cuda.synchronize()
+        lib.rc_profile_enable(h, 0)
+        lib.rc_profile_collect(h, _lib.PROF_ADC_SCAN, ctypes.byref(n_l), ctypes.byref(ms_l))
+        ivf_scan_ms = ms_l.value / max(n_l.value, 1)
+        ivf_gather = nq_batch * rows128 * M3 / (ivf_scan_ms * 1e-3) / 1e9 if n_l.value else 0.0   # 1 B per (row, m, query)
         out["ivf"] = {
             "metric": "ivf_adc_queries_per_sec", "unit": "queries/s", "k": k, "nlist": nlist, "M": M3,
             "index": f"{N_CORPUS} x {M3} B uniform codes in {nlist} uniformly filled cells (no residual coding)",
@@ -460,7 +468,14 @@ def main():
                          "unit": "GB/s", "frac": round(nq_batch * rows128 * M3 / t128 / 1e9 / HBM_PEAK_GBS, 4),
                          "note": "nprobe = 128: rows probed x M code bytes per query / whole-search time (task list, LUT, "
                                  "sample, byte tables, screen, rescoring, sort); up to 8 queries share every code read, so "
-                                 "like the flat ADC figure this is an equivalent rate, not HBM traffic"}}
+                                 "like the flat ADC figure this is an equivalent rate, not HBM traffic",
+                         "lds_gather": {"screen_kernel_ms": round(ivf_scan_ms, 3), "achieved": round(ivf_gather, 1),
+                                        "measured_gather_roof": round(512 / 2.2 * 256, 1), "unit": "GB/s",
+                                        "frac": round(ivf_gather / (512 / 2.2 * 256), 4),
+                                        "note": "the same gathers as the flat screen (one table byte per row, sub-quantiser "
+                                                "and query) against the roof of tools/ubench_lds_gather.hip: an IVF task "
+                                                "is one cell x <= 8 queries, ~7 us of gathers behind two table fills of "
+                                                "96 KiB each, so the screen is fill- and latency-bound, not gather-bound"}}}
         del ivf, flat3
         torch.cuda.empty_cache()
 
