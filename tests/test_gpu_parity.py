@@ -1279,6 +1279,12 @@ def test_evaluation_pipeline_with_the_reference_call_sequence(tmp_path):
     for row in (0, 100, 256):
         want = model(return_code=True, **col(corpus[corpus_ids[row]])).discrete_codes.to(torch.uint8)
         assert torch.equal(index.codes[row:row + 1], want)
+    # ... and against the ORACLE (not only the HIP path against itself): nearest codes of the model's own continuous
+    # embeddings by the numpy restatement of the reference's arithmetic
+    sample_rows = [0, 1, 57, 100, 255, 256]
+    cont = torch.cat([model(**col(corpus[corpus_ids[r]])).continuous_embeds for r in sample_rows]).detach().float().cpu().numpy()
+    want_codes = pq_oracle.quantize(cont, model.centroids.detach().cpu().numpy(), False).astype(np.uint8)
+    assert np.array_equal(index.codes[sample_rows].cpu().numpy(), want_codes)
     save_index_dir(index, corpus_ids, str(tmp_path / "corpus"))
     index2, ids2 = load_index_dir(str(tmp_path / "corpus"))
     assert np.array_equal(ids2, corpus_ids) and torch.equal(index2.codes, index.codes)
