@@ -1329,7 +1329,9 @@ static bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M 
 // three phases of 32 (64 KiB of tables, TWO 512-thread blocks per CU so that one block's refill hides behind the other's
 // gathers; 126 VGPRs, no spills, both blocks resident): 39 ms instead of 27 ms per 1200 queries flat, no change for the IVF
 // tasks — twice the refills per row and a third exposed code load per round cost more than the overlap returns.  Also without
-// effect on the 27 ms (or worse): requesting the next step's codes before the refill, and an XCD mapping of 8 groups x 4 tiles that
+// effect on the 27 ms (or worse): three 32-wide phases with the NEXT phase's table copied into a second LDS buffer by
+// global_load_lds_dwordx4 while the current one is gathered (one barrier per step, no refill on the critical path: 36 ms —
+// 64 gathers per wave between barriers do not amortise the pipeline ramp), requesting the next step's codes before the refill, and an XCD mapping of 8 groups x 4 tiles that
 // keeps the tables L2-resident.  What the two-phase screen pays over 2 x the one-phase time (20 ms) is the pipeline
 // drain and ramp-up of 16 waves around the two barriers of every 2048-row round.
 static int adc_cf_phase_m(int M) { return M == 96 ? 48 : M; }
