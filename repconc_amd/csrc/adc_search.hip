@@ -1331,7 +1331,8 @@ static bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M 
 // tasks — twice the refills per row and a third exposed code load per round cost more than the overlap returns.  Also without
 // effect on the 27 ms (or worse): three 32-wide phases with the NEXT phase's table copied into a second LDS buffer by
 // global_load_lds_dwordx4 while the current one is gathered (one barrier per step, no refill on the critical path: 36 ms —
-// 64 gathers per wave between barriers do not amortise the pipeline ramp), requesting the next step's codes before the refill, and an XCD mapping of 8 groups x 4 tiles that
+// 64 gathers per wave between barriers do not amortise the pipeline ramp), 8 waves per CU with 16 / 12 chunks each
+// (192 / 144 gathers per wave between barriers, 242 / 168 VGPRs: 29.4 / 32.7 ms), requesting the next step's codes before the refill, and an XCD mapping of 8 groups x 4 tiles that
 // keeps the tables L2-resident.  What the two-phase screen pays over 2 x the one-phase time (20 ms) is the pipeline
 // drain and ramp-up of 16 waves around the two barriers of every 2048-row round.
 static int adc_cf_phase_m(int M) { return M == 96 ? 48 : M; }
