@@ -1764,3 +1764,22 @@ def test_probe_selection_kernel_picks_the_ordered_probe_set():
     want = np.sort(np.lexsort((np.broadcast_to(np.arange(nlist), sc.shape), -sc), axis=1)[:, :nprobe], axis=1)
     assert np.array_equal(out.cpu().numpy(), want)
     assert lib.rc_ivf_select_probes(h, C.c_void_p(d_sc.data_ptr()), nq, nlist, nlist + 1, C.c_void_p(out.data_ptr()), s) == _lib.RC_EINVAL
+
+
+def test_deferred_search_on_empty_inputs():
+    """defer=True with nothing to do: no queries, or an empty index (scores -inf, ids -1) — the pending object resolves
+    without touching the device; PQIndex.search_async likewise."""
+    from repconc_amd import ops
+    from repconc_amd.index import PQIndex
+    C = _t(synth.gaussian(3, (48, 256, 16)))
+    codes = _t(synth.uniform_codes(4, 1000, 48))
+    p0 = ops.adc_search(codes, C, torch.empty((0, 768), device=DEV), 5, defer=True)
+    s0, i0 = p0.result()
+    assert s0.shape == (0, 5) and i0.shape == (0, 5)
+    p1 = ops.adc_search(codes[:0], C, _t(synth.gaussian(5, (3, 768))), 4, defer=True)
+    s1, i1 = p1.result()
+    assert torch.isinf(s1).all() and (s1 < 0).all() and (i1 == -1).all()
+    idx = PQIndex(768, 48)
+    idx.set_centroids(C)
+    s2, i2 = idx.search_async(synth.gaussian(6, (2, 768)), 3)()
+    assert s2.shape == (2, 3) and (i2 == -1).all()
