@@ -45,10 +45,17 @@ def coarse_kmeans(x: torch.Tensor, nlist: int, iters: int = 10, seed: int = 1234
 def coarse_assign(x: torch.Tensor, cent: torch.Tensor, chunk: int = 1 << 20) -> torch.Tensor:
     """L2-nearest coarse centroid of every row, argmin_l (||c_l||^2 - 2 <x, c_l>), first minimum: the fp32-MFMA
     GEMM + fused argmin of csrc/ivf_search.hip (rc_ivf_coarse_assign); the [n, nlist] scores are never materialised."""
+    ops._need_cuda(x, cent)
     xt = ops._rows_f32(x)
     cent = cent.float().contiguous()
     n, D = xt.shape
     nlist = cent.shape[0]
+    if D % 16 != 0:
+        # the MFMA kernel stages K in chunks of 16 (RC_ESHAPE otherwise); widths the PQ path cannot have anyway (toy
+        # fixtures): the same argmin through a library GEMM, chunked so the [chunk, nlist] scores stay small
+        c2 = (cent * cent).sum(1)
+        parts = [torch.argmin(c2[None, :] - 2.0 * (xt[i:i + (1 << 16)] @ cent.T), dim=1) for i in range(0, n, 1 << 16)]
+        return torch.cat(parts) if parts else torch.empty((0,), dtype=torch.int64, device=xt.device)
     lib, h, s, _ = ops._ctx(xt)
     wsb = lib.rc_ivf_coarse_assign_ws_bytes(nlist)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=xt.device)
@@ -72,6 +79,7 @@ class IVFPQIndex:
         self.image = None            # permuted copy of `codes` for the conflict-free screen (list-centric search)
         self.list_off = torch.zeros((nlist + 1,), dtype=torch.int64, device=self.device)
         self.ntotal = 0
+        self._sizes_desc = np.zeros(0, np.int64)      # cell sizes, descending (host copy; set_lists fills it)
 
     # ---- build
     def train(self, x, iters: int = 10, seed: int = 1234):

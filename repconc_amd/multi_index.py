@@ -19,6 +19,7 @@ A device may be listed more than once (virtual replicas / shards on a single-GPU
 from __future__ import annotations
 
 from concurrent.futures import ThreadPoolExecutor
+from types import SimpleNamespace
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -42,11 +43,50 @@ def _clone_to(index: PQIndex, device: int, rows: Optional[slice] = None, id_offs
     return out
 
 
+class _FanoutCentroids:
+    """`index.pq.centroids` of a multi-device index.  Every part keeps its own resident table, so an in-place write —
+    the reference's `faiss.copy_array_to_vector(c, index.pq.centroids)` idiom (finetune_jpq.py:211-213) — has to reach
+    ALL of them: `copy_` fans out through `set_centroids`; reads come from part 0 (the parts are kept identical)."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    @property
+    def _first(self) -> torch.Tensor:
+        return self._owner.parts[0].pq.centroids
+
+    shape = property(lambda self: self._first.shape)
+    dtype = property(lambda self: self._first.dtype)
+    device = property(lambda self: self._first.device)
+
+    def numel(self):
+        return self._first.numel()
+
+    def copy_(self, src, non_blocking: bool = False):
+        self._owner.set_centroids(src.reshape(self._first.shape))
+        return self
+
+    def detach(self):
+        return self._first.detach()
+
+    def reshape(self, *shape):
+        return self._first.reshape(*shape)
+
+    def cpu(self):
+        return self._first.cpu()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._first.cpu().numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+
 class _MultiIndex:
     def __init__(self, parts: List[PQIndex]):
         assert parts
         self.parts = parts
-        self.pq = parts[0].pq
+        p0 = parts[0].pq
+        self.pq = SimpleNamespace(d=p0.d, M=p0.M, nbits=p0.nbits, code_size=p0.code_size, ksub=p0.ksub, dsub=p0.dsub,
+                                  centroids=_FanoutCentroids(self))
         self.metric_type = parts[0].metric_type
         self.is_trained = parts[0].is_trained
         self.device = parts[0].device
@@ -62,11 +102,11 @@ class _MultiIndex:
         self.is_trained = True
 
     def _run(self, jobs):
-        """jobs: list of (part, queries on any device) -> list of (scores, ids) on the part's device."""
+        """jobs: list of (part, queries on any device, k) -> list of (scores, ids) on the part's device."""
         def one(job):
-            part, q = job
+            part, q, k = job
             with torch.cuda.device(part.device):
-                s, i = part.search(q.to(part.device, non_blocking=True), self._k)
+                s, i = part.search(q.to(part.device, non_blocking=True), k)
                 torch.cuda.current_stream(part.device).synchronize()
                 return s, i
         if len(jobs) == 1:
@@ -105,13 +145,13 @@ class ReplicatedPQIndex(_MultiIndex):
 
     def search(self, x, k: int):
         q, as_numpy = self._as_tensor(x)
-        self._k = int(k)
+        k = int(k)
         nq = q.shape[0]
         G = len(self.parts)
         bounds = [(nq * i) // G for i in range(G + 1)]
-        jobs = [(self.parts[i], q[bounds[i]:bounds[i + 1]]) for i in range(G) if bounds[i + 1] > bounds[i]]
+        jobs = [(self.parts[i], q[bounds[i]:bounds[i + 1]], k) for i in range(G) if bounds[i + 1] > bounds[i]]
         if not jobs:
-            jobs = [(self.parts[0], q)]
+            jobs = [(self.parts[0], q, k)]
         res = self._run(jobs)
         home = self.parts[0].device
         scores = torch.cat([r[0].to(home) for r in res], 0)
@@ -148,8 +188,7 @@ class ShardedPQIndex(_MultiIndex):
 
     def search(self, x, k: int):
         q, as_numpy = self._as_tensor(x)
-        self._k = int(k)
-        res = self._run([(p, q) for p in self.parts])
+        res = self._run([(p, q, int(k)) for p in self.parts])
         home = self.parts[0].device
         scores, ids = merge_topk(torch.stack([r[0].to(home) for r in res]), torch.stack([r[1].to(home) for r in res]), int(k))
         if as_numpy:
