@@ -77,8 +77,55 @@ def pmc_traffic(kernel):
         return None
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` typed as is (no launcher, WORLD_SIZE unset): start N ranks of this script, one per GPU,
+    over 127.0.0.1; rank 0 prints the JSON line.  Fewer than N GPUs visible: one {"skipped": ...} line, exit 0
+    (RC_BENCH_SHARE_GPU=1 puts every rank on cuda:0 instead — a walk through the N-rank code, flagged in the line).
+    A rank that dies takes the others down (exact PIDs) and its exit code becomes this process's."""
+    import socket
+    import subprocess
+    import torch
+    n_vis = torch.cuda.device_count()
+    share = os.environ.get("RC_BENCH_SHARE_GPU", "0") == "1"
+    if n_vis < args.gpus and not share:
+        print(json.dumps({"skipped": f"--gpus {args.gpus} requested but {n_vis} GPU(s) visible (RC_BENCH_SHARE_GPU=1 runs "
+                                     "all ranks on one GPU as a code walk)", "metric": "constrained_cluster_assignments_per_sec",
+                          "value": None, "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return 0
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        live = set(range(args.gpus))
+        while live:
+            for r in list(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 1
+            if rc:
+                break
+            time.sleep(0.2)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     # Only the JSON line may appear on stdout: libraries loaded below (RCCL prints a version banner) write to
     # fd 1 from C, so fd 1 is pointed at stderr for the duration and the result goes to the saved descriptor.
     sys.stdout.flush()
@@ -93,7 +140,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # RC_BENCH_SHARE_GPU=1 (development only, flagged in the line): every rank on cuda:0 with gloo collectives, to walk
     # the N > 1 branches of this file on a one-GPU box; RCCL refuses two ranks on one device, so the native solve's probe
@@ -150,21 +197,37 @@ def main():
         return assign_sinkhorn_sharded(x, C, EPS, ITERS, comm, dtype=torch.uint8)
 
     # ------------------------------------------------------------------ multi-rank self-check (untimed)
-    # On a small global batch: (1) the native RCCL solve (csrc/comm.hip) against the Python-staged torch.distributed
-    # solve, (2) the gathered sharded codes against the unsharded single-GPU solve of the same batch on rank 0.  If the
-    # native driver errors or disagrees on any rank, every rank switches to the staged driver and the line says so.
+    # On a small global batch: the Python-staged torch.distributed solve is the yardstick; the native C loop
+    # (csrc/comm.hip) is tried with each exchange transport in turn — ipc (peer stores into IPC-mapped buffers; works on
+    # a shared GPU too), then rccl — first in a child process with a timeout (a hang or crash in a transport this node has
+    # never run stays there), then in-process against the staged codes.  The first transport every rank passes is used;
+    # if none, every rank times the staged driver and the line says why.  (2) the gathered sharded codes against the
+    # unsharded single-GPU solve of the same batch on rank 0.
     dist_check = None
+    exchange = None
     if use_dist:
         gb = 1024 * world
         xs_full = np.random.default_rng(20230).standard_normal((gb, D), dtype=np.float32)
         xs_loc = torch.from_numpy(xs_full[rank * 1024:(rank + 1) * 1024]).to(dev)
         os.environ["RC_DIST_NATIVE"] = "0"
         c_staged, _ = assign_sinkhorn_sharded(xs_loc, C, EPS, ITERS, comm, dtype=torch.uint8)
-        native_ok, why = 1, ""
-        if args.dist_driver != "staged":
-            # first in a child process with a timeout: a hang or crash in the RCCL communicator set-up stays there
-            import subprocess
-            env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 17))
+
+        def all_ranks(ok):
+            t = torch.tensor([int(ok)], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        chosen, notes = None, {}
+        if args.dist_driver == "staged":
+            notes["staged"] = "--dist-driver staged"
+            candidates = []
+        elif os.environ.get("RC_COMM"):
+            candidates = [os.environ["RC_COMM"].lower()]
+        else:
+            candidates = ["ipc"] if share_gpu else ["ipc", "rccl"]     # RCCL refuses two ranks on one device
+        import subprocess
+        for ti, transport in enumerate(candidates):
+            env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 17 + ti), RC_COMM=transport)
             env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # the child makes its own TCP store on the new port
             child = subprocess.Popen([sys.executable, "-m", "repconc_amd.dist_probe"], cwd=ROOT, env=env,
                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -174,27 +237,27 @@ def main():
                 child.kill()
                 child.wait()
                 prc = -9
-            if prc != 0:
-                native_ok, why = 0, f"out-of-process probe failed (exit {prc})"
-        if args.dist_driver != "staged":
-            t = torch.tensor([native_ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)          # every rank must have passed the probe
-            if native_ok and not int(t.item()):
-                native_ok, why = 0, "out-of-process probe failed on another rank"
-        if args.dist_driver != "staged" and native_ok:
-            os.environ["RC_DIST_NATIVE"] = "1"
+            if not all_ranks(prc == 0):
+                notes[transport] = f"out-of-process probe failed (exit {prc} on this rank)"
+                continue
+            os.environ["RC_DIST_NATIVE"], os.environ["RC_COMM"] = "1", transport
+            ok, why = True, ""
             try:
                 c_native, _ = assign_sinkhorn_sharded(xs_loc, C, EPS, ITERS, comm, dtype=torch.uint8)
                 torch.cuda.synchronize()
                 if not torch.equal(c_native, c_staged):
-                    native_ok, why = 0, "codes differ from the staged driver"
-            except Exception as e:                           # rc_comm_init / RCCL failure: reported, not hidden
-                native_ok, why = 0, f"{type(e).__name__}: {e}"
-        if args.dist_driver == "staged":
-            native_ok, why = 0, "--dist-driver staged"
-        t = torch.tensor([native_ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        native_all = bool(int(t.item()))
+                    ok, why = False, "codes differ from the staged driver"
+            except Exception as e:                           # transport set-up failure: reported, not hidden
+                ok, why = False, f"{type(e).__name__}: {e}"
+            if all_ranks(ok):
+                chosen = transport
+                break
+            notes[transport] = why or "failed on another rank"
+            try:
+                ops.comm_destroy()
+            except Exception:
+                pass
+        native_all = chosen is not None
         os.environ["RC_DIST_NATIVE"] = "1" if native_all else "0"
         gathered = [torch.empty_like(c_staged) for _ in range(world)]
         dist.all_gather(gathered, c_staged)
@@ -202,9 +265,28 @@ def main():
         if rank == 0:
             ref_codes, _ = ops.assign_sinkhorn(torch.from_numpy(xs_full).to(dev), C, EPS, ITERS, torch.uint8)
             unsharded_equal = bool(torch.equal(torch.cat(gathered, 0), ref_codes))
-        dist_check = {"global_batch": gb, "driver": "native RCCL loop (csrc/comm.hip)" if native_all else
-                      "python-staged torch.distributed loop", "native_equals_staged": bool(native_ok) if args.dist_driver != "staged" else None,
-                      "native_note": why or None, "sharded_equals_unsharded": unsharded_equal}
+        dist_check = {"global_batch": gb,
+                      "driver": (f"native C loop (csrc/comm.hip), {chosen} transport" if native_all else
+                                 "python-staged torch.distributed loop"),
+                      "transport": chosen, "native_equals_staged": native_all if candidates else None,
+                      "transport_notes": notes or None, "sharded_equals_unsharded": unsharded_equal}
+        if native_all:
+            # cost of one exchange step of the solve: all-gather of a chain's [M/2, K] fp64 row sums, back to back
+            rows = torch.zeros((M // 2, K), dtype=torch.float64, device=dev)
+            for _ in range(20):
+                ops.comm_allgather(rows)
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                ops.comm_allgather(rows)
+            e1.record()
+            torch.cuda.synchronize()
+            exchange = {"transport": chosen, "bytes_per_rank": rows.numel() * 8,
+                        "us_per_allgather": round(max_over_ranks(e0.elapsed_time(e1)) * 1e3 / 200, 2),
+                        "what": "200 back-to-back rc_comm_allgather calls of one chain's row sums (push kernel + wait kernel "
+                                "+ copy-out); inside the solve the two chains overlap this with the other chain's sweep"}
+            barrier()
         del xs_loc, c_staged, gathered
 
     for i in range(args.warmup):
@@ -269,8 +351,9 @@ def main():
                                "49152x768 batches (180 = 8.84M corpus), M=48 K=256 eps=0.003 T=100",
                    "global_batch": B, "rows_per_gpu": bl, "D": D, "M": M, "K": K, "sk_iters": ITERS,
                    "parallelism": f"batch-sharded x{world}, all-gather of [M,K] f64 row sums per iteration"
-                                  + ((", RCCL driven from C, two chains of M/2 sub-quantisers on two streams "
-                                      "(all-gathers overlap sweeps)" if os.environ.get("RC_DIST_NATIVE", "1") != "0" else
+                                  + ((f", {os.environ.get('RC_COMM', 'ipc')} exchange driven from C, two chains of M/2 "
+                                      "sub-quantisers on two streams (all-gathers overlap sweeps)"
+                                      if os.environ.get("RC_DIST_NATIVE", "1") != "0" else
                                       ", python-staged torch.distributed loop (the native driver did not pass the probe)")
                                      if use_dist else "")},
         "sub_assignments_per_sec": round(value * M, 1),
@@ -279,8 +362,11 @@ def main():
     }
     if dist_check is not None:
         out["multi_gpu_check"] = dist_check
+    if exchange is not None:
+        out["exchange"] = exchange
     if share_gpu:
-        out["test_mode"] = "RC_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo - a walk through the N > 1 code, not a measurement"
+        out["test_mode"] = ("RC_BENCH_SHARE_GPU=1: all ranks on ONE GPU (gloo handshake, IPC exchange between the processes) - a "
+                            "walk through the N > 1 code, not a measurement")
 
     # ------------------------------------------------------------------ the 8-GPU recipe's per-rank shape on this GPU
     if not use_dist and B == B_GLOBAL and not args.no_per_rank:
@@ -651,6 +737,10 @@ def main():
                           "threads=1"}
 
     if use_dist:
+        try:
+            ops.comm_destroy()                               # barrier inside: no peer still stores into this rank's buffer
+        except Exception:
+            pass
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:

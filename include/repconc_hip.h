@@ -47,6 +47,8 @@ extern "C" {
 #define RC_FLAG_NONFINITE 1 /* a row/column sum became 0, inf or NaN — the reference's   */
                             /* "Sinkhorn Algorithm returns nan/inf values" warning,      */
                             /* models/repconc/modeling_repconc.py:64-65                  */
+#define RC_FLAG_COMM 4      /* IPC transport: a peer's signal did not arrive within RC_IPC_TIMEOUT_MS (default 30 s):  */
+                            /* the wait gave up instead of hanging the GPU; the codes of this call are garbage       */
 #define RC_FLAG_RANGE 2     /* |(L + f) N/ln2| left the range the sweep's integer split  */
                             /* covers (eps < ~3e-4 on centred distances: the reference's */
                             /* own exp(1/eps) overflows fp64 long before, at eps < 1.4e-3) */
@@ -172,6 +174,33 @@ int rc_comm_unique_ids(void* ids_host);
 int rc_comm_init(rc_handle_t h, const void* ids_host, int rank, int world);
 int rc_comm_destroy(rc_handle_t h);
 int rc_comm_world(rc_handle_t h);
+
+/* IPC transport (round 3; default of the Python boundary, RC_COMM=rccl selects RCCL): the same exchange steps — the
+ * dist.all_reduce calls of modeling_repconc.py:78-80,149-157 — as hand-written peer stores.  Every rank owns one receive
+ * buffer in device memory, exports it with hipIpcGetMemHandle and maps the other ranks' buffers (ranks may be processes
+ * on ONE GPU — what a one-GPU box can test — or one process per GPU of a node, where the stores travel over xGMI; the
+ * code is the same).  An all-gather is ONE kernel that stores this rank's slice into slot `rank` of every peer's buffer
+ * and bumps the peer's arrival counter (system-scope release), followed by a one-thread kernel that waits for the local
+ * counter and re-arms it: no library call, no communicator, capturable in a hipGraph like any kernel; buffers and
+ * counters alternate between two parities so consecutive exchanges need no further handshake.  The wait gives up after
+ * RC_IPC_TIMEOUT_MS (flags |= RC_FLAG_COMM) instead of hanging the device when a peer has died.
+ *
+ * rc_comm_ipc_export: allocate this rank's buffer, write its RC_IPC_BLOB_BYTES-byte descriptor (IPC handle, device
+ *   identity) to blob_host.  The caller gathers the descriptors of all ranks, rank order, through any channel
+ *   (torch.distributed, a file, a pipe) and hands them to
+ * rc_comm_ipc_connect: map the peers.  After it rc_pq_assign_sinkhorn_dist / rc_comm_allgather use the IPC transport.
+ * rc_comm_allgather: generic all-gather of `bytes` bytes per rank into dst [world][bytes] on `stream` (either
+ *   transport; per-shard k-means statistics run_warmup.py:102-113, row-sharded search results).  Every rank must call
+ *   it with the same `bytes`, in the same order relative to its other collectives.
+ * rc_comm_kind: 0 none, 1 RCCL, 2 IPC.  rc_comm_destroy releases either; the caller makes sure (barrier) that no peer
+ *   still stores into this rank's buffer. */
+#define RC_IPC_BLOB_BYTES 128
+#define RC_IPC_MAX_WORLD 16
+int rc_comm_ipc_export(rc_handle_t h, int rank, int world, void* blob_host);
+int rc_comm_ipc_connect(rc_handle_t h, const void* blobs_host);
+int rc_comm_allgather(rc_handle_t h, const void* src, void* dst, size_t bytes, int* flags, rc_stream_t stream);
+int rc_comm_kind(rc_handle_t h);
+int rc_comm_status(rc_handle_t h); /* IPC transport: RC_FLAG_COMM once a wait has timed out (synchronises the device) */
 int rc_solve_num_chains(int world, int M); /* 1 or 2: launches per sweep (measurement bookkeeping) */
 size_t rc_pq_assign_sinkhorn_dist_ws_bytes(int64_t B_local, int M, int K, int world);
 int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B_local,

@@ -16,6 +16,8 @@ RC_OK, RC_EINVAL, RC_ESHAPE, RC_EHIP, RC_EWORKSPACE, RC_ECOMM, RC_ESELECT = 0, -
 RC_CODE_U8, RC_CODE_I64 = 0, 1
 RC_FLAG_NONFINITE = 1
 RC_FLAG_RANGE = 2
+RC_FLAG_COMM = 4
+RC_IPC_BLOB_BYTES = 128
 PROF_SK_PASS, PROF_ADC_SCAN, PROF_ASSIGN_NEAREST, PROF_DIST_TABLE = 0, 1, 2, 3
 
 _vp, _i, _i64, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double
@@ -46,6 +48,11 @@ PROTOTYPES = {
     "rc_comm_init": (_i, [_vp, _vp, _i, _i]),
     "rc_comm_destroy": (_i, [_vp]),
     "rc_comm_world": (_i, [_vp]),
+    "rc_comm_ipc_export": (_i, [_vp, _i, _i, _vp]),
+    "rc_comm_ipc_connect": (_i, [_vp, _vp]),
+    "rc_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "rc_comm_kind": (_i, [_vp]),
+    "rc_comm_status": (_i, [_vp]),
     "rc_solve_num_chains": (_i, [_i, _i]),
     "rc_pq_assign_sinkhorn_dist_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rc_pq_assign_sinkhorn_dist": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -19,6 +19,7 @@
 #include <rccl/rccl.h>
 #include <string.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 namespace {
 struct nccl_api {
@@ -80,7 +81,7 @@ extern "C" int rc_comm_init(rc_handle_t h, const void* ids_host, int rank, int w
     nccl_api* n = nccl();
     if (!n) return RC_ECOMM;
     if (!h || !ids_host || world < 1 || rank < 0 || rank >= world) return RC_EINVAL;
-    if (h->comm[0]) return RC_EINVAL;   // already initialised
+    if (h->comm[0] || h->ipc.on || h->ipc.exported) return RC_EINVAL;   // already initialised
     RC_HIP_CHECK(h, hipSetDevice(h->device));
     for (int i = 0; i < 2; ++i) {
         ncclUniqueId id;
@@ -93,6 +94,8 @@ extern "C" int rc_comm_init(rc_handle_t h, const void* ids_host, int rank, int w
     h->comm_world = world;
     return RC_OK;
 }
+
+namespace { void ipc_release(rc_handle_t h); }
 
 extern "C" int rc_comm_destroy(rc_handle_t h) {
     if (!h) return RC_EINVAL;
@@ -109,11 +112,230 @@ extern "C" int rc_comm_destroy(rc_handle_t h) {
     if (h->side_stream) { (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
     if (h->ev_fork) { (void)hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
     if (h->ev_join) { (void)hipEventDestroy(h->ev_join); h->ev_join = nullptr; }
+    if (h->ipc.on || h->ipc.exported) { (void)hipDeviceSynchronize(); ipc_release(h); }
     h->comm_world = 0;
     return RC_OK;
 }
 
 extern "C" int rc_comm_world(rc_handle_t h) { return h ? h->comm_world : 0; }
+
+
+// ---- IPC transport ------------------------------------------------------------------------------------------------
+// The exchange steps of the solve as hand-written peer stores (include/repconc_hip.h, rc_comm_ipc_*).  Receive buffer of
+// a rank:  data [channel 0..2][parity 0..1][world x IPC_SLOT bytes]  |  counters [channel][parity] (one u64 per 64 B)  |
+// status word.  Channels 0 / 1 belong to the two Sinkhorn chains (one stream each), channel 2 to everything else on the
+// caller's stream (distance-range all-reduce, rc_comm_allgather).  Exchange number n of a channel uses parity n & 1:
+//   push   one kernel, grid (IPC_PUSH_BLOCKS, world): block (b, p) stores its share of this rank's slice into peer p's
+//          region at offset rank * bytes (so a region holds the dense [world][bytes] all-gather result) and, after a
+//          system-scope fence, adds 1 to peer p's counter of (channel, parity);
+//   wait   one thread: spins (s_sleep) until the local counter shows IPC_PUSH_BLOCKS * world arrivals, re-arms it to 0.
+// Why two parities are enough: a rank's push n + 2 (same parity as n) is stream-ordered after its wait n + 1, which
+// needs every peer's push n + 1, which that peer issued after ITS wait n (counter re-armed) and after the kernels that
+// read region n (stream order) — so neither the region nor the counter of exchange n can still be in use.
+// No CU is held while waiting beyond one wave, so ranks that share a GPU (the one-GPU test boxes) cannot starve each
+// other; a peer that died is noticed after RC_IPC_TIMEOUT_MS (flags |= RC_FLAG_COMM) instead of hanging the queue.
+namespace {
+constexpr size_t IPC_SLOT = 256 * 1024;     // most bytes one rank contributes per exchange ([96, 256] fp64 row sums = 192 KiB)
+constexpr int IPC_CHANNELS = 3;
+constexpr int IPC_PUSH_BLOCKS = 4;
+constexpr unsigned IPC_MAGIC = 0x52434950u;  // "RCIP"
+
+struct ipc_blob {                            // RC_IPC_BLOB_BYTES on the wire
+    hipIpcMemHandle_t handle;                // 64 bytes
+    unsigned magic;
+    int rank, world, pid;
+    int pci_domain, pci_bus, pci_device;
+    char pad[RC_IPC_BLOB_BYTES - 64 - 7 * 4];
+};
+static_assert(sizeof(ipc_blob) == RC_IPC_BLOB_BYTES, "blob layout");
+
+size_t ipc_data_bytes(int world) { return (size_t)IPC_CHANNELS * 2 * world * IPC_SLOT; }
+size_t ipc_total_bytes(int world) { return ipc_data_bytes(world) + 4096; }
+size_t ipc_region_off(int world, int ch, int par) { return ((size_t)ch * 2 + par) * world * IPC_SLOT; }
+size_t ipc_counter_off(int world, int ch, int par) { return ipc_data_bytes(world) + ((size_t)ch * 2 + par) * 64; }
+size_t ipc_status_off(int world) { return ipc_data_bytes(world) + 2048; }
+
+struct ipc_peers { char* p[RC_IPC_MAX_WORLD]; };
+
+__global__ __launch_bounds__(256) void ipc_push_kernel(const char* __restrict__ src, size_t bytes, ipc_peers P,
+                                                       size_t region_off, size_t slot_off, size_t counter_off) {
+    char* dst = P.p[blockIdx.y] + region_off + slot_off;
+    const size_t n16 = bytes / 16;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d4[i] = s4[i];
+        if (blockIdx.x == 0)
+            for (size_t i = n16 * 16 + threadIdx.x; i < bytes; i += blockDim.x) dst[i] = src[i];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    }
+    __threadfence_system();          // this thread's stores are visible system-wide before the barrier ...
+    __syncthreads();                 // ... so after it every store of the block is
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(P.p[blockIdx.y] + counter_off), 1ull, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void ipc_wait_kernel(unsigned long long* __restrict__ counter, unsigned long long want, int* __restrict__ flags,
+                                int* __restrict__ status, long long timeout_ticks) {
+    const long long t0 = wall_clock64();                     // constant 100 MHz
+    bool ok = true;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > timeout_ticks) { ok = false; break; }
+    }
+    __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!ok) {
+        if (flags) atomicOr(flags, RC_FLAG_COMM);
+        atomicOr(status, RC_FLAG_COMM);
+    }
+}
+
+// distance range over ranks: gathered [world][2M] (max then min per rank) -> minmax [2M]
+__global__ void ipc_minmax_kernel(const float* __restrict__ gathered, int world, int M, float* __restrict__ minmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * M) return;
+    float v = gathered[i];
+    for (int r = 1; r < world; ++r) {
+        const float o = gathered[(size_t)r * 2 * M + i];
+        // NaN ranges propagate like torch's all_reduce(MAX / MIN) would not guarantee; keep the first NaN seen
+        v = (i < M) ? ((o > v || o != o) ? o : v) : ((o < v || o != o) ? o : v);
+    }
+    minmax[i] = v;
+}
+
+long long ipc_timeout_ticks() { return (long long)rc_env_int("RC_IPC_TIMEOUT_MS", 30000) * 100000ll; }
+
+// exchange number `n` of channel `ch`: every rank contributes `bytes` from `src`; returns this rank's dense
+// [world][bytes] region in *region.  Kernels only (capturable).
+int ipc_exchange(rc_handle_t h, int ch, unsigned long long n, const void* src, size_t bytes, const char** region, int* flags,
+                 hipStream_t s) {
+    const int world = h->comm_world, rank = h->comm_rank, par = (int)(n & 1);
+    if (bytes > IPC_SLOT) return RC_EINVAL;
+    ipc_peers P;
+    for (int r = 0; r < RC_IPC_MAX_WORLD; ++r) P.p[r] = r < world ? h->ipc.peer[r] : nullptr;
+    const size_t roff = ipc_region_off(world, ch, par), coff = ipc_counter_off(world, ch, par);
+    if (bytes)
+        hipLaunchKernelGGL(ipc_push_kernel, dim3(IPC_PUSH_BLOCKS, world), dim3(256), 0, s, (const char*)src, bytes, P, roff,
+                           (size_t)rank * bytes, coff);
+    else   // nothing to send still signals (keeps the counters of all ranks in step)
+        hipLaunchKernelGGL(ipc_push_kernel, dim3(IPC_PUSH_BLOCKS, world), dim3(256), 0, s, (const char*)h->ipc.mine, (size_t)0, P,
+                           roff, (size_t)0, coff);
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)(h->ipc.mine + coff),
+                       (unsigned long long)IPC_PUSH_BLOCKS * world, flags, (int*)(h->ipc.mine + ipc_status_off(world)),
+                       ipc_timeout_ticks());
+    RC_LAUNCH_CHECK(h);
+    *region = h->ipc.mine + roff;
+    return RC_OK;
+}
+
+void ipc_release(rc_handle_t h) {
+    if (h->ipc.on)
+        for (int r = 0; r < h->comm_world && r < RC_IPC_MAX_WORLD; ++r)
+            if (r != h->comm_rank && h->ipc.peer[r]) (void)hipIpcCloseMemHandle(h->ipc.peer[r]);
+    if (h->ipc.mine) (void)hipFree(h->ipc.mine);
+    memset(&h->ipc, 0, sizeof(h->ipc));
+}
+}  // namespace
+
+extern "C" int rc_comm_ipc_export(rc_handle_t h, int rank, int world, void* blob_host) {
+    if (!h || !blob_host || world < 1 || world > RC_IPC_MAX_WORLD || rank < 0 || rank >= world) return RC_EINVAL;
+    if (h->comm[0] || h->ipc.on || h->ipc.exported) return RC_EINVAL;   // one transport per handle; rc_comm_destroy first
+    rc_device_guard device_guard_(h);
+    RC_HIP_CHECK(h, hipSetDevice(h->device));
+    // fine-grained device memory: peer stores and the system-scope counters stay coherent while kernels of several
+    // agents touch it (RC_IPC_ALLOC=plain|uncached for experiments)
+    const char* kind = getenv("RC_IPC_ALLOC");
+    void* buf = nullptr;
+    const size_t total = ipc_total_bytes(world);
+    if (kind && !strcmp(kind, "plain")) RC_HIP_CHECK(h, hipMalloc(&buf, total));
+    else RC_HIP_CHECK(h, hipExtMallocWithFlags(&buf, total, (kind && !strcmp(kind, "uncached")) ? hipDeviceMallocUncached
+                                                                                               : hipDeviceMallocFinegrained));
+    RC_HIP_CHECK(h, hipMemset(buf, 0, total));
+    RC_HIP_CHECK(h, hipDeviceSynchronize());
+    ipc_blob b;
+    memset(&b, 0, sizeof b);
+    hipError_t e = hipIpcGetMemHandle(&b.handle, buf);
+    if (e != hipSuccess) { (void)hipFree(buf); h->last_hip_error = (int)e; return RC_EHIP; }
+    hipDeviceProp_t prop;
+    RC_HIP_CHECK(h, hipGetDeviceProperties(&prop, h->device));
+    b.magic = IPC_MAGIC; b.rank = rank; b.world = world; b.pid = (int)getpid();
+    b.pci_domain = prop.pciDomainID; b.pci_bus = prop.pciBusID; b.pci_device = prop.pciDeviceID;
+    memcpy(blob_host, &b, sizeof b);
+    h->ipc.mine = (char*)buf;
+    h->ipc.exported = 1;
+    h->comm_rank = rank;
+    h->comm_world = world;
+    return RC_OK;
+}
+
+extern "C" int rc_comm_ipc_connect(rc_handle_t h, const void* blobs_host) {
+    if (!h || !blobs_host || !h->ipc.exported || h->ipc.on) return RC_EINVAL;
+    rc_device_guard device_guard_(h);
+    const int world = h->comm_world, rank = h->comm_rank;
+    const ipc_blob* B = (const ipc_blob*)blobs_host;
+    for (int r = 0; r < world; ++r)
+        if (B[r].magic != IPC_MAGIC || B[r].rank != r || B[r].world != world) return RC_EINVAL;
+    h->ipc.shared_device = 0;
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) { h->ipc.peer[r] = h->ipc.mine; continue; }
+        if (B[r].pci_domain == B[rank].pci_domain && B[r].pci_bus == B[rank].pci_bus && B[r].pci_device == B[rank].pci_device)
+            h->ipc.shared_device = 1;
+        void* q = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&q, B[r].handle, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            for (int k = 0; k < r; ++k)
+                if (k != rank && h->ipc.peer[k]) { (void)hipIpcCloseMemHandle(h->ipc.peer[k]); h->ipc.peer[k] = nullptr; }
+            h->last_hip_error = (int)e;
+            return RC_ECOMM;
+        }
+        h->ipc.peer[r] = (char*)q;
+    }
+    h->ipc.on = 1;
+    return RC_OK;
+}
+
+extern "C" int rc_comm_kind(rc_handle_t h) { return !h ? 0 : h->ipc.on ? 2 : h->comm[0] ? 1 : 0; }
+
+// flags word of the IPC transport (RC_FLAG_COMM after a timed-out wait); synchronises the device
+extern "C" int rc_comm_status(rc_handle_t h) {
+    if (!h || !h->ipc.on) return 0;
+    rc_device_guard device_guard_(h);
+    int v = 0;
+    RC_HIP_CHECK(h, hipMemcpy(&v, h->ipc.mine + ipc_status_off(h->comm_world), sizeof v, hipMemcpyDeviceToHost));
+    return v;
+}
+
+extern "C" int rc_comm_allgather(rc_handle_t h, const void* src, void* dst, size_t bytes, int* flags, rc_stream_t stream) {
+    if (!h) return RC_EINVAL;
+    if (bytes == 0) return RC_OK;                 // every rank passes the same size: nothing to exchange anywhere
+    if (!dst || !src) return RC_EINVAL;
+    rc_device_guard device_guard_(h);
+    hipStream_t s = (hipStream_t)stream;
+    if (h->ipc.on) {
+        const int world = h->comm_world;
+        for (size_t off = 0; off < bytes; off += IPC_SLOT) {
+            const size_t chunk = bytes - off < IPC_SLOT ? bytes - off : IPC_SLOT;
+            const char* region = nullptr;
+            int rc = ipc_exchange(h, 2, h->ipc.seq[2]++, (const char*)src + off, chunk, &region, flags, s);
+            if (rc != RC_OK) return rc;
+            // region [world][chunk] -> dst [world][bytes] at column offset off
+            RC_HIP_CHECK(h, hipMemcpy2DAsync((char*)dst + off, bytes, region, chunk, chunk, (size_t)world,
+                                             hipMemcpyDeviceToDevice, s));
+        }
+        return RC_OK;
+    }
+    if (h->comm[0]) {
+        nccl_api* n = nccl();
+        if (!n) return RC_ECOMM;
+        RC_NCCL_CHECK(h, n->AllGather(src, dst, bytes, ncclChar, (ncclComm_t)h->comm[0], s));
+        return RC_OK;
+    }
+    if (bytes) RC_HIP_CHECK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    return RC_OK;
+}
 
 static int ensure_side_stream(rc_handle_t h) {
     if (h->side_stream) return RC_OK;
@@ -185,18 +407,23 @@ __global__ void solve_merge_flags_kernel(const int* __restrict__ own, int* __res
 // One iteration (sweep t of every chain + its all-gather).  Shared by the eager loop and the capture.
 struct solve_ctx {
     rc_handle_t h; nccl_api* n; const dist_ws* L; char* w; float* d; float* minmax; int64_t B; int M, G; double eps;
-    int* flags; hipStream_t st[2]; bool fuse_centre, coll;
+    int* flags; hipStream_t st[2]; bool fuse_centre, coll, ipc;
+    unsigned long long ipc_base[2];      // exchange number of sweep 0 on channel 0 / 1 (IPC transport)
 };
+// where the gathered [G, mc, K] row sums of sweep t of chain ch live: the workspace ping-pong, or (IPC transport) this
+// rank's receive region of that exchange
+const double* gathered_rows(const solve_ctx& c, int ch, int t) {
+    if (c.ipc) return (const double*)(c.h->ipc.mine + ipc_region_off(c.G, ch, (int)((c.ipc_base[ch] + (unsigned long long)t) & 1)));
+    return (const double*)(c.w + c.L->ch[ch].gathered) + (size_t)(t & 1) * c.G * c.L->mc[ch] * RC_K;
+}
 int solve_iteration(const solve_ctx& c, int t) {
     const dist_ws& L = *c.L;
     for (int ch = 0; ch < L.nch; ++ch) {
         const chain_ws& cw = L.ch[ch];
         const int mc = L.mc[ch];
         float* dc = c.d + (size_t)L.m0[ch] * c.B * RC_K;
-        double* gath = (double*)(c.w + cw.gathered);
-        const size_t gsz = (size_t)c.G * mc * RC_K;
-        const double* prev = gath + (size_t)((t + 1) & 1) * gsz;   // gathered row sums of sweep t-1
-        double* out = gath + (size_t)(t & 1) * gsz;
+        const double* prev = t > 0 ? gathered_rows(c, ch, t - 1) : nullptr;   // gathered row sums of sweep t-1
+        double* out = c.ipc ? nullptr : const_cast<double*>(gathered_rows(c, ch, t));
         // one rank: the sweep writes its row sums straight into the "gathered" slot
         double* rows = c.coll ? (double*)(c.w + cw.rows) : out;
         int rc = RC_OK;
@@ -212,8 +439,13 @@ int solve_iteration(const solve_ctx& c, int t) {
                              (rc_stream_t)c.st[ch]);
         }
         if (rc != RC_OK) return rc;
-        if (c.coll)
+        if (c.ipc) {
+            const char* region = nullptr;
+            if ((rc = ipc_exchange(c.h, ch, c.ipc_base[ch] + (unsigned long long)t, rows, (size_t)mc * RC_K * sizeof(double),
+                                   &region, c.flags, c.st[ch])) != RC_OK) return rc;
+        } else if (c.coll) {
             RC_NCCL_CHECK(c.h, c.n->AllGather(rows, out, (size_t)mc * RC_K, ncclDouble, (ncclComm_t)c.h->comm[ch], c.st[ch]));
+        }
     }
     return RC_OK;
 }
@@ -235,9 +467,10 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
                     hipStream_t s0) {
     const int G = world;
     // RC_DIST_FORCE_COLL=1 (tests on a one-GPU box): a one-rank communicator still issues every RCCL call of the loop
-    const bool coll = G > 1 || (h->comm[0] && rc_env_int("RC_DIST_FORCE_COLL", 0) != 0);
-    nccl_api* n = coll ? nccl() : nullptr;
-    if (coll && (!n || !h->comm[0])) return RC_ECOMM;
+    const bool ipc = h->ipc.on != 0;
+    const bool coll = G > 1 || ((h->comm[0] || ipc) && rc_env_int("RC_DIST_FORCE_COLL", 0) != 0);
+    nccl_api* n = (coll && !ipc) ? nccl() : nullptr;
+    if (coll && !ipc && (!n || !h->comm[0])) return RC_ECOMM;
     if (G == 1 && B == 1) {      // a global batch of one row: exact K-way tie, the reference returns code 0
         if (codes_u8) RC_HIP_CHECK(h, hipMemsetAsync(codes_u8, 0, (size_t)M, s0));
         if (codes_i64) RC_HIP_CHECK(h, hipMemsetAsync(codes_i64, 0, (size_t)M * sizeof(int64_t), s0));
@@ -261,7 +494,12 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
         for (int c = 0; c < L.nch; ++c)
             RC_HIP_CHECK(h, hipMemsetAsync(w + L.ch[c].rows, 0, (size_t)L.mc[c] * RC_K * sizeof(double), s0));
     }
-    if (coll) {   // modeling_repconc.py:79-80
+    if (coll && ipc) {   // modeling_repconc.py:79-80 as one all-gather of the [2M] ranges + a local max / min
+        const char* region = nullptr;
+        if ((rc = ipc_exchange(h, 2, h->ipc.seq[2]++, minmax, (size_t)2 * M * sizeof(float), &region, own_flags, s0)) != RC_OK) return rc;
+        hipLaunchKernelGGL(ipc_minmax_kernel, dim3((2 * M + 63) / 64), dim3(64), 0, s0, (const float*)region, G, M, minmax);
+        RC_LAUNCH_CHECK(h);
+    } else if (coll) {   // modeling_repconc.py:79-80
         RC_NCCL_CHECK(h, n->AllReduce(minmax, minmax, (size_t)M, ncclFloat, ncclMax, (ncclComm_t)h->comm[0], s0));
         RC_NCCL_CHECK(h, n->AllReduce(minmax + M, minmax + M, (size_t)M, ncclFloat, ncclMin, (ncclComm_t)h->comm[0], s0));
     }
@@ -269,7 +507,13 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
     const bool fuse_centre = rc_env_int("RC_FUSE_CENTRE", 1) != 0;
     if (B > 0 && !fuse_centre && (rc = rc_pq_centre(h, d, minmax, B, M, RC_K, (rc_stream_t)s0)) != RC_OK) return rc;
 
-    solve_ctx cx = {h, n, &L, w, d, minmax, B, M, G, eps, own_flags, {s0, s0}, fuse_centre, coll};
+    const bool use_ipc = coll && ipc;
+    solve_ctx cx = {h, n, &L, w, d, minmax, B, M, G, eps, own_flags, {s0, s0}, fuse_centre, coll, use_ipc,
+                    {h->ipc.seq[0], h->ipc.seq[1]}};
+    if (use_ipc) {   // this solve's exchanges are numbered base .. base + iters - 1 on each channel it uses
+        h->ipc.seq[0] += (unsigned long long)iters;
+        if (L.nch == 2) h->ipc.seq[1] += (unsigned long long)iters;
+    }
     if (L.nch == 2) {
         if ((rc = ensure_side_stream(h)) != RC_OK) return rc;
         cx.st[1] = h->side_stream;
@@ -292,7 +536,8 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
     };
     // sweeps t = 0 .. iters-1, the two chains enqueued alternately so both streams stay fed
     const int variant = rc_env_int("RC_SK_V1", 0) | (rc_env_int("RC_SK_FKLDS", 1) << 1) | (rc_env_int("RC_SK_NB", 0) << 2) |
-                        (rc_env_int("RC_SK_CPB", 0) << 14) | ((int)coll << 24);
+                        (rc_env_int("RC_SK_CPB", 0) << 14) | ((int)coll << 24) | ((int)use_ipc << 25) |
+                        ((int)(cx.ipc_base[0] & 1) << 26) | ((int)(cx.ipc_base[1] & 1) << 27);
     // per-launch event marks (profile mode 1) need the eager loop; the bracket mode (2) times the whole run of sweeps
     const bool want_graph = rc_env_int("RC_GRAPH", 1) != 0 && h->profile_on != 1 && !h->graph_broken && iters > 4;
     const bool bracket = h->profile_on == 2 && L.nch == 1 && B > 0;     // one chain: launches are back to back on s0
@@ -354,7 +599,7 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
         for (int c = 0; c < L.nch; ++c) {
             const chain_ws& cw = L.ch[c];
             const int mc = L.mc[c];
-            const double* gath = (const double*)(w + cw.gathered) + (size_t)((iters - 1) & 1) * G * mc * RC_K;
+            const double* gath = gathered_rows(cx, c, iters - 1);
             if ((rc = rc_sk_argmax_strided(h, d + (size_t)L.m0[c] * B * RC_K, gath, G, (const double*)(w + cw.f2), B, mc, eps,
                                            iters, M, L.m0[c], codes_u8, codes_i64, own_flags, cx.st[c])) != RC_OK) return rc;
         }
@@ -376,7 +621,7 @@ extern "C" int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t
                                           int M, int K, double eps, int iters, uint8_t* codes_u8, int64_t* codes_i64,
                                           int* flags, void* ws, size_t ws_bytes, rc_stream_t stream) {
     rc_device_guard device_guard_(h);
-    if (!h || !h->comm[0] || !C || !flags || B < 0 || (B > 0 && !x) || M <= 0 || iters < 1 || !(eps > 0.0) ||
+    if (!h || !(h->comm[0] || h->ipc.on) || !C || !flags || B < 0 || (B > 0 && !x) || M <= 0 || iters < 1 || !(eps > 0.0) ||
         (B > 0 && !codes_u8 && !codes_i64))
         return RC_EINVAL;
     if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;

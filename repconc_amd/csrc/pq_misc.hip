@@ -1,6 +1,7 @@
 // Handle management plus the small byte/gather kernels of the path: decode (+ its gradient),
 // centroid normalisation, code histogram, k-means sufficient statistics and centroid update.
 #include "rc_common.h"
+#include <string.h>
 
 #include <math.h>
 
@@ -46,6 +47,7 @@ extern "C" int rc_create(rc_handle_t* out, int device) {
     h->scratch_bytes = 0;
     h->graph_broken = 0;
     h->capturing = 0;
+    memset(&h->ipc, 0, sizeof(h->ipc));
     *out = h;
     return RC_OK;
 }

@@ -33,6 +33,15 @@ struct rc_handle_s {
     };
     solve_graph graphs[4];
     unsigned long long graph_stamp;
+    // IPC transport (comm.hip, rc_comm_ipc_*): peer-mapped receive buffers instead of RCCL communicators
+    struct ipc_state {
+        int on;                                       // rc_comm_ipc_connect succeeded
+        int exported;                                 // rc_comm_ipc_export done, waiting for connect
+        int shared_device;                            // some peer lives on my device (one-GPU test boxes)
+        char* mine;                                   // my receive buffer
+        char* peer[RC_IPC_MAX_WORLD];                 // peer[r] = rank r's buffer as mapped here (peer[rank] = mine)
+        unsigned long long seq[3];                    // exchanges done per channel (0/1: Sinkhorn chains, 2: everything else)
+    } ipc;
     void* scratch;                                    // handle-owned device scratch (rc_scratch), grown on demand
     size_t scratch_bytes;
     int graph_broken;                                 // capture failed once on this handle: stay eager

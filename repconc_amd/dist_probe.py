@@ -1,4 +1,4 @@
-"""Out-of-process probe of the native multi-rank solve (csrc/comm.hip over RCCL).
+"""Out-of-process probe of the native multi-rank solve (csrc/comm.hip; exchange transport from RC_COMM = ipc | rccl).
 
 `python -m repconc_amd.dist_probe` is started by every rank of a job (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
 MASTER_PORT from the environment, its own rendezvous port), runs the native constrained assignment and the
@@ -23,9 +23,15 @@ def main() -> int:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29550")
+    share = os.environ.get("RC_BENCH_SHARE_GPU", "0") == "1"          # every rank on cuda:0 (one-GPU boxes): gloo handshake
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    if share:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     rng = np.random.default_rng(4242)
     M, K, D, rows = 48, 256, 768, 512
     x = rng.standard_normal((rows * world, D), dtype=np.float32)
@@ -38,8 +44,11 @@ def main() -> int:
     native, _ = assign_sinkhorn_sharded(xl, C, 0.003, 100, comm, dtype=torch.uint8)       # captures the iteration graph
     replay, _ = assign_sinkhorn_sharded(xl, C, 0.003, 100, comm, dtype=torch.uint8)       # replays it (same workspace block)
     torch.cuda.synchronize()
-    ok = torch.tensor([int(torch.equal(staged, native) and torch.equal(staged, replay))], dtype=torch.int32, device=dev)
+    ok = torch.tensor([int(torch.equal(staged, native) and torch.equal(staged, replay))], dtype=torch.int32,
+                      device=torch.device("cpu") if share else dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    from . import ops
+    ops.comm_destroy()
     dist.destroy_process_group()
     return 0 if int(ok.item()) == 1 else 1
 

@@ -230,34 +230,103 @@ def assign_sinkhorn(x: torch.Tensor, centroids: torch.Tensor, eps: float, iters:
 
 # --------------------------------------------------------------------------- N ranks, native loop
 _comm_ready = {}
+_dist_ws = {}          # device index -> persistent workspace of assign_sinkhorn_dist
 
 
-def comm_init(group=None):
-    """Create the RCCL communicators of this process's handle (once).  The 256-byte unique ids are produced on rank 0
-    and broadcast through torch.distributed (any backend); everything after that is RCCL called from C."""
+def comm_transport() -> str:
+    """RC_COMM=ipc|rccl (default ipc): how the ranks of a node exchange the Sinkhorn row sums and k-means statistics.
+    ipc = hand-written peer stores into IPC-mapped receive buffers (csrc/comm.hip; works between processes on ONE GPU
+    too), rccl = two RCCL communicators (needs one GPU per rank)."""
+    import os
+    v = os.environ.get("RC_COMM", "ipc").lower()
+    if v not in ("ipc", "rccl"):
+        raise ValueError("RC_COMM must be ipc or rccl")
+    return v
+
+
+def comm_init(group=None, transport: Optional[str] = None):
+    """Set up the exchange layer of this process's handle (once per process group).  Only the set-up handshake goes
+    through torch.distributed (any backend): the IPC descriptors (128 bytes per rank, all-gathered) or the RCCL unique
+    ids (256 bytes, broadcast from rank 0); everything after that happens inside librepconc_hip.so."""
     import torch.distributed as dist
     dev = torch.cuda.current_device()
-    key = id(group) if group is not None else 0
+    transport = transport or comm_transport()
+    key = (id(group) if group is not None else 0, transport)
     if _comm_ready.get(dev) == key:
         return
     lib, h = _lib.load(), _lib.handle(dev)
-    if dev in _comm_ready:                                  # another process group: new communicators
-        _lib.check(lib.rc_comm_destroy(h), "rc_comm_destroy", h)
-        del _comm_ready[dev]
+    if dev in _comm_ready:                                  # another process group / transport: start over
+        comm_destroy(group_barrier=False)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    ids = torch.zeros(256, dtype=torch.uint8)
-    if rank == 0:
-        buf = (C.c_char * 256)()
-        _lib.check(lib.rc_comm_unique_ids(C.cast(buf, C.c_void_p)), "rc_comm_unique_ids")
-        ids = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-    if world > 1:
-        backend = dist.get_backend(group)
-        t = ids.to(torch.device("cuda", dev)) if backend == "nccl" else ids
-        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ids = t.cpu()
-    raw = (C.c_char * 256).from_buffer_copy(bytes(ids.numpy().tobytes()))
-    _lib.check(lib.rc_comm_init(h, C.cast(raw, C.c_void_p), rank, world), "rc_comm_init", h)
+    if transport == "ipc":
+        blob = (C.c_char * _lib.RC_IPC_BLOB_BYTES)()
+        _lib.check(lib.rc_comm_ipc_export(h, rank, world, C.cast(blob, C.c_void_p)), "rc_comm_ipc_export", h)
+        blobs = [None] * world
+        dist.all_gather_object(blobs, bytes(blob.raw), group=group)
+        raw = (C.c_char * (_lib.RC_IPC_BLOB_BYTES * world)).from_buffer_copy(b"".join(blobs))
+        _lib.check(lib.rc_comm_ipc_connect(h, C.cast(raw, C.c_void_p)), "rc_comm_ipc_connect", h)
+        dist.barrier(group=group)                           # every rank has mapped every buffer before the first store
+    else:
+        ids = torch.zeros(256, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 256)()
+            _lib.check(lib.rc_comm_unique_ids(C.cast(buf, C.c_void_p)), "rc_comm_unique_ids")
+            ids = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world > 1:
+            backend = dist.get_backend(group)
+            t = ids.to(torch.device("cuda", dev)) if backend == "nccl" else ids
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ids = t.cpu()
+        raw = (C.c_char * 256).from_buffer_copy(bytes(ids.numpy().tobytes()))
+        _lib.check(lib.rc_comm_init(h, C.cast(raw, C.c_void_p), rank, world), "rc_comm_init", h)
     _comm_ready[dev] = key
+
+
+def comm_destroy(group=None, group_barrier: bool = True):
+    """Release the exchange layer of the current device's handle.  With the IPC transport no peer may still be storing
+    into this rank's buffer: `group_barrier` synchronises the device and the process group first."""
+    dev = torch.cuda.current_device()
+    if dev not in _comm_ready:
+        return
+    if group_barrier:
+        import torch.distributed as dist
+        torch.cuda.synchronize(dev)
+        if dist.is_initialized():
+            dist.barrier(group=group)
+    lib, h = _lib.load(), _lib.handle(dev)
+    _lib.check(lib.rc_comm_destroy(h), "rc_comm_destroy", h)
+    del _comm_ready[dev]
+
+
+def comm_allgather(t: torch.Tensor, flags: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[world, *t.shape] stack of every rank's `t` (same shape and dtype on all ranks) through the handle's exchange
+    layer (rc_comm_allgather; comm_init() first), on the current stream."""
+    _need_cuda(t)
+    t = t.contiguous()
+    lib, h, s, _ = _ctx(t)
+    world = lib.rc_comm_world(h)
+    if world < 1:
+        raise _lib.RepconcHipError("comm_allgather: call ops.comm_init() first")
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    _lib.check(lib.rc_comm_allgather(h, _p(t), _p(out), t.numel() * t.element_size(), _p(flags), s), "rc_comm_allgather", h)
+    return out
+
+
+def all_gather(t: torch.Tensor, group=None) -> torch.Tensor:
+    """[world, *t.shape] stack of every rank's `t`: through the handle's own exchange layer when comm_init() has been
+    called for this process group on t's device (IPC peer stores or RCCL, from C), otherwise through torch.distributed.
+    The ONE all-gather the multi-rank code paths (k-means statistics run_warmup.py:102-113, row-sharded / replicated
+    search results evaluate_repconc.py:121-135) are written against."""
+    import torch.distributed as dist
+    if t.is_cuda:
+        dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+        ready = _comm_ready.get(dev)
+        if ready is not None and ready[0] == (id(group) if group is not None else 0):
+            return comm_allgather(t)
+    G = dist.get_world_size(group)
+    out = torch.empty((G,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=group)
+    return out
 
 
 def assign_sinkhorn_dist(x: torch.Tensor, centroids: torch.Tensor, eps: float, iters: int, dtype=torch.int64):
@@ -274,7 +343,14 @@ def assign_sinkhorn_dist(x: torch.Tensor, centroids: torch.Tensor, eps: float, i
     flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
     # a rank without rows (ragged last batch) still takes part in every collective of the solve
     wsb = lib.rc_pq_assign_sinkhorn_dist_ws_bytes(B, M, K, world)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    # The iteration graph (csrc/comm.hip) is cached per workspace ADDRESS: keep one block per device and reuse it while
+    # it is large enough, instead of asking the caching allocator for a (possibly different) block on every call.  The
+    # block is only touched by this function, on the caller's stream, so consecutive solves are ordered by the stream.
+    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    ws = _dist_ws.get(dev)
+    if ws is None or ws.numel() < wsb:
+        _dist_ws.pop(dev, None)
+        ws = _dist_ws[dev] = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
     u8 = codes if dtype == torch.uint8 else None
     i64 = codes if dtype == torch.int64 else None
     _lib.check(lib.rc_pq_assign_sinkhorn_dist(h, _p(x), x.stride(0), _p(c), B, D, M, K, float(eps), int(iters),

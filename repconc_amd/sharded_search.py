@@ -33,12 +33,8 @@ def sharded_search(index: PQIndex, q: torch.Tensor, k: int, group=None):
     scores, ids = index.search(q, k)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return scores, ids
-    G = dist.get_world_size(group)
-    all_s = torch.empty((G,) + tuple(scores.shape), dtype=scores.dtype, device=scores.device)
-    all_i = torch.empty((G,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
-    dist.all_gather_into_tensor(all_s.view(-1), scores.contiguous().view(-1), group=group)
-    dist.all_gather_into_tensor(all_i.view(-1), ids.contiguous().view(-1), group=group)
-    return merge_topk(all_s, all_i, k)
+    from . import ops
+    return merge_topk(ops.all_gather(scores, group), ops.all_gather(ids, group), k)
 
 
 def search_virtual_shards(shards: Sequence[PQIndex], q: torch.Tensor, k: int):
@@ -68,9 +64,8 @@ def replicated_search(index, q: torch.Tensor, k: int, *search_args, group=None):
     pad_s = torch.full((most, k), float("-inf"), dtype=torch.float32, device=s.device)
     pad_i = torch.full((most, k), -1, dtype=torch.int64, device=s.device)
     pad_s[: s.shape[0]], pad_i[: i.shape[0]] = s, i
-    all_s = torch.empty((G * most, k), dtype=torch.float32, device=s.device)
-    all_i = torch.empty((G * most, k), dtype=torch.int64, device=s.device)
-    dist.all_gather_into_tensor(all_s.view(-1), pad_s.view(-1), group=group)
-    dist.all_gather_into_tensor(all_i.view(-1), pad_i.view(-1), group=group)
+    from . import ops
+    all_s = ops.all_gather(pad_s, group).view(G * most, k)
+    all_i = ops.all_gather(pad_i, group).view(G * most, k)
     keep = torch.cat([torch.arange(g * most, g * most + bounds[g + 1] - bounds[g], device=s.device) for g in range(G)])
     return all_s[keep].contiguous(), all_i[keep].contiguous()

@@ -25,3 +25,25 @@ def test_bench_has_the_contract_flags():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):
         assert f'"{flag}"' in src
+
+
+def test_bench_spawns_its_own_ranks_when_typed_without_a_launcher():
+    """`python bench.py --gpus N` with WORLD_SIZE unset (how the driver types it) must not die with 'launch with
+    torch.distributed.run': it re-executes itself once per rank; with too few GPUs it prints ONE {"skipped": ...} JSON
+    line and exits 0 (checked here on the GPU-less box)."""
+    import json
+    import subprocess
+    import sys
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "def spawn_ranks(" in src and '"WORLD_SIZE" not in os.environ' in src
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RC_BENCH_SHARE_GPU")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert "skipped" in line and line["n_gpus"] == 2 and line["value"] is None

@@ -1,0 +1,81 @@
+"""The N-rank product path with N PROCESSES on the GPU box (one GPU is enough): rc_pq_assign_sinkhorn_dist and the other
+multi-rank gathers on the IPC transport of csrc/comm.hip (rc_comm_ipc_export / _connect / rc_comm_allgather).
+
+Reference behaviour: the dist.is_initialized() branch of RepCONC.quantize (models/repconc/modeling_repconc.py:78-80,
+149-157) — every rank's codes equal the codes of the unsharded batch, here the reference-generated golden fixtures.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_case
+from mp_util import rank_logs, run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+def _cuts(name, world):
+    g, _, _ = load_case(name)
+    B = int(g["B"])
+    if name == "m48_b1000_ragged":                       # two ranks hold 500 rows each, the others are EMPTY ranks
+        return B, [0, 500] + [1000] * (world - 1) if world > 1 else [0, B]
+    return B, [(B * r) // world for r in range(world + 1)]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("name", ["m48_b1024_sample", "m8_b2048_sample", "m48_b1000_ragged", "m96_b512_blend"])
+def test_native_solve_on_ipc_ranks_equals_golden(name, world, tmp_path):
+    """Native C loop (two chains on two streams, exchanges as peer stores + one-thread waits) with `world` processes:
+    eager, graph capture, graph replay, eager again — every pass of every rank equals the golden codes of its rows;
+    empty ranks take part in every exchange; a 7-iteration solve (odd: flips the exchange parity) is repeatable."""
+    B, cuts = _cuts(name, world)
+    codes = run_ranks(world, ["solve", name] + cuts, str(tmp_path), timeout=420)
+    assert codes == [0] * world, rank_logs(str(tmp_path), world)
+    g, _, _ = load_case(name)
+    for i in range(4):
+        got = np.concatenate([np.load(tmp_path / f"codes{i}_rank{r}.npy") for r in range(world)], 0)
+        assert np.array_equal(got, g["codes_constrained"]), (name, world, i)
+
+
+def test_seven_iteration_solve_on_ipc_ranks_equals_single_process(tmp_path):
+    import torch
+    from repconc_amd import ops
+    name, world = "m48_b1024_sample", 2
+    B, cuts = _cuts(name, world)
+    assert run_ranks(world, ["solve", name] + cuts, str(tmp_path), timeout=420) == [0] * world, rank_logs(str(tmp_path), world)
+    _, x, C = load_case(name)
+    want, _ = ops.assign_sinkhorn(torch.from_numpy(x).cuda(), torch.from_numpy(C).cuda(), 0.003, 7, torch.uint8)
+    got = np.concatenate([np.load(tmp_path / f"codes7_rank{r}.npy") for r in range(world)], 0)
+    assert np.array_equal(got, want.cpu().numpy())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ipc_allgather_sizes(world, tmp_path):
+    """rc_comm_allgather: 7 bytes, one exchange slot, several slots (chunked), nothing, 4 MiB — three times each."""
+    assert run_ranks(world, ["allgather"], str(tmp_path), timeout=240) == [0] * world, rank_logs(str(tmp_path), world)
+
+
+def test_ipc_wait_gives_up_on_a_missing_peer(tmp_path):
+    """A peer that never pushes: the wait kernel leaves after RC_IPC_TIMEOUT_MS and raises RC_FLAG_COMM (flags word and
+    rc_comm_status) instead of hanging the queue."""
+    assert run_ranks(2, ["timeout"], str(tmp_path), timeout=240) == [0, 0], rank_logs(str(tmp_path), 2)
+
+
+def test_corpus_sharded_warmup_on_ipc_ranks_is_rank_identical(tmp_path):
+    """BASELINE configs[2] ("corpus sharded ... centroid all-gather"): OPQ + PQ training with the corpus rows split over
+    two processes — per-shard Lloyd statistics and Procrustes matrices gathered through rc_comm_allgather, summed in rank
+    order: both ranks end with bit-identical rotations and centroids; the shards are contiguous."""
+    world = 2
+    assert run_ranks(world, ["warmup"], str(tmp_path), timeout=420) == [0] * world, rank_logs(str(tmp_path), world)
+    r0, r1 = np.load(tmp_path / "rotation_rank0.npy"), np.load(tmp_path / "rotation_rank1.npy")
+    c0, c1 = np.load(tmp_path / "centroids_rank0.npy"), np.load(tmp_path / "centroids_rank1.npy")
+    assert np.array_equal(r0.view(np.uint32), r1.view(np.uint32)) and np.array_equal(c0.view(np.uint32), c1.view(np.uint32))
+    assert np.abs(r0 @ r0.T - np.eye(768)).max() < 1e-4 and np.isfinite(c0).all() and np.abs(c0).max() > 0
+    s0, s1 = np.load(tmp_path / "shard_rank0.npy"), np.load(tmp_path / "shard_rank1.npy")
+    assert list(s0) == [0, 3000] and list(s1) == [3000, 3000]
+
+
+def test_sharded_and_replicated_search_gathers_on_ipc_ranks(tmp_path):
+    """evaluate_repconc.py:121-135 in the one-process-per-rank model: row-sharded search (local top-k, gather, merge) and
+    replica search (query slices, gather) with the result gathers on the IPC layer equal the whole-index search."""
+    world = 3
+    assert run_ranks(world, ["search"], str(tmp_path), timeout=300) == [0] * world, rank_logs(str(tmp_path), world)
