@@ -271,6 +271,21 @@ size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, int k);
 int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
                       const float* C, int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,
                       float* scores, int64_t* ids, int* status, void* ws, size_t ws_bytes, rc_stream_t stream);
+/* Search that cannot fail (evaluate_repconc.py:180-185: Faiss's IndexPQ.search returns for ANY index content).
+ * rc_adc_search_q = rc_adc_search_img + qstatus: NULL, or nq ints zeroed by the caller that receive the status bits PER
+ *   QUERY, so a caller repeats (other sel_slack) or re-routes only the queries concerned — one degenerate query does not
+ *   tax the others of its batch.
+ * rc_adc_search_exact: exact fp32 score of every row, the min(k, N) best by an 8-pass radix select over the 64-bit keys
+ *   (ordered(score) << 32 | ~row), sorted (score desc, id asc).  No sample, no threshold, no status: terminates with the
+ *   same answer as the fast path for any codes (all rows identical, k = N, ...).  Slower (N x 4 bytes of scores per query,
+ *   ~10 passes): the route for the queries the fast path gives up on.  ws: rc_adc_search_exact_ws_bytes(N, M, K, nq, k). */
+int rc_adc_search_q(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
+                    const float* C, int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,
+                    float* scores, int64_t* ids, int* status, int* qstatus, void* ws, size_t ws_bytes, rc_stream_t stream);
+size_t rc_adc_search_exact_ws_bytes(int64_t N, int M, int K, int nq, int k);
+int rc_adc_search_exact(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, const float* C, int D,
+                        const float* q, int nq, int k, int64_t id_offset, float* scores, int64_t* ids, void* ws,
+                        size_t ws_bytes, rc_stream_t stream);
 /* the look-up tables alone (test hook): lut [nq,M,K] fp32 */
 int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K,
                float* lut, rc_stream_t stream);

@@ -69,6 +69,9 @@ PROTOTYPES = {
     "rc_adc_scan_image": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp]),
     "rc_adc_search_img_ws_bytes": (_sz, [_i64, _i, _i, _i, _i]),
     "rc_adc_search_img": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rc_adc_search_q": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rc_adc_search_exact_ws_bytes": (_sz, [_i64, _i, _i, _i, _i]),
+    "rc_adc_search_exact": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "rc_ivf_coarse_assign_ws_bytes": (_sz, [_i]),
     "rc_ivf_coarse_assign": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp]),
     "rc_ivf_search_lists_ws_bytes": (_sz, [_i, _i, _i64]),

@@ -285,7 +285,8 @@ __global__ __launch_bounds__(1024) void adc_threshold_kernel(const float* __rest
 __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __restrict__ cand,
                                                           const unsigned* __restrict__ cand_count, int64_t N, int k,
                                                           int64_t id_offset, float* __restrict__ scores,
-                                                          int64_t* __restrict__ ids, int* __restrict__ status) {
+                                                          int64_t* __restrict__ ids, int* __restrict__ status,
+                                                          int* __restrict__ qstatus) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int qi = blockIdx.x, tid = threadIdx.x;
     const unsigned raw = cand_count[qi];
@@ -298,7 +299,10 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __
         int st = 0;
         if ((int64_t)cnt < want) st |= 1;
         if (raw > ADC_CAND_CAP) st |= 2;
-        if (st) atomicOr(status, st);
+        if (st) {
+            atomicOr(status, st);
+            if (qstatus) atomicOr(qstatus + qi, st);          // which query: the caller repeats only those
+        }
     }
     // Long lists (the threshold of step 3 lets ~5 k rows through for k = 1000) are first cut down to the k best scores
     // (+ every tie at the k-th score): radix select of the k-th largest 32-bit score key, then compaction into LDS.  The
@@ -1276,14 +1280,18 @@ __global__ __launch_bounds__(ADC_RESCORE_THREADS) void adc_rescore_kernel(const 
                                                           unsigned* __restrict__ cand_count,
                                                           unsigned long long* __restrict__ cand,
                                                           int* __restrict__ status,
-                                                          const int64_t* __restrict__ rowmap) {
+                                                          const int64_t* __restrict__ rowmap,
+                                                          int* __restrict__ qstatus = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tab = reinterpret_cast<float*>(smem);  // [M][256]
     const int qi = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < M * RC_K; i += ADC_RESCORE_THREADS) tab[i] = lut[(size_t)qi * M * RC_K + i];
     const unsigned raw = id_count[qi];
     const unsigned cnt = raw > ADC_ID_CAP ? ADC_ID_CAP : raw;
-    if (tid == 0 && raw > ADC_ID_CAP) atomicOr(status, 2);
+    if (tid == 0 && raw > ADC_ID_CAP) {
+        atomicOr(status, 2);
+        if (qstatus) atomicOr(qstatus + qi, 2);
+    }
     const float tau = thr[qi];
     __syncthreads();
     for (unsigned i0 = 0; i0 < cnt; i0 += ADC_RESCORE_THREADS) {
@@ -1427,7 +1435,7 @@ struct adc_bufs {
 
 template <int M, int QT>
 static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* image, int64_t N, int nq, int64_t S,
-                            const adc_bufs& b, int r, int k, int* status, hipStream_t s) {
+                            const adc_bufs& b, int r, int k, int* status, int* qstatus, hipStream_t s) {
     const size_t lds = (size_t)M * RC_K * QT * sizeof(float);
     const unsigned qg = (unsigned)((nq + QT - 1) / QT);
     auto ksample = adc_scan_kernel<M, QT, ADC_SAMPLE>;
@@ -1514,13 +1522,13 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
     const size_t rl = (size_t)M * RC_K * sizeof(float);
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
     hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(ADC_RESCORE_THREADS), rl, s, codes, b.lut, b.thr, b.idcnt, b.ids, b.cnt, b.cand,
-                       status, (const int64_t*)nullptr);
+                       status, (const int64_t*)nullptr, qstatus);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
 
 #define ADC_CASE(MM, QQ) \
-    case MM: rc = adc_launch_scans<MM, QQ>(h, codes, image, N, nq, L.S, bufs, r, k, status, s); break;
+    case MM: rc = adc_launch_scans<MM, QQ>(h, codes, image, N, nq, L.S, bufs, r, k, status, qstatus, s); break;
 
 extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq, int D, int M, int K, float* lut,
                           rc_stream_t stream) {
@@ -1547,12 +1555,12 @@ extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq,
 
 // sort + emit stage, shared with the IVF path (ivf_search.hip)
 int rc_adc_launch_select(rc_handle_t h, unsigned long long* cand, const unsigned* cnt, int nq, int64_t N, int k,
-                         int64_t id_offset, float* scores, int64_t* ids, int* status, hipStream_t s) {
+                         int64_t id_offset, float* scores, int64_t* ids, int* status, hipStream_t s, int* qstatus = nullptr) {
     const size_t ss = (size_t)ADC_SELECT_SMALL * sizeof(unsigned long long);
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)adc_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ss));
     hipLaunchKernelGGL(adc_select_kernel, dim3((unsigned)nq), dim3(1024), ss, s, cand, cnt, N, k, id_offset, scores, ids,
-                       status);
+                       status, qstatus);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
@@ -1567,10 +1575,25 @@ extern "C" int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int
 
 // The search proper.  scan_image: the index's permuted code image (rc_adc_scan_image) or NULL — then, where the
 // conflict-free screen applies, the image is rebuilt in the workspace on every call (one extra pass over the codes).
+extern "C" int rc_adc_search_q(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
+                               const float* C, int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,
+                               float* scores, int64_t* ids, int* status, int* qstatus, void* ws, size_t ws_bytes,
+                               rc_stream_t stream);
+
 extern "C" int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
                                  const float* C, int D, const float* q, int nq, int k, int64_t id_offset,
                                  double sel_slack, float* scores, int64_t* ids, int* status, void* ws, size_t ws_bytes,
                                  rc_stream_t stream) {
+    return rc_adc_search_q(h, codes, scan_image, N, M, K, C, D, q, nq, k, id_offset, sel_slack, scores, ids, status, nullptr,
+                           ws, ws_bytes, stream);
+}
+
+// qstatus: NULL, or nq ints (zeroed by the caller) that receive the status bits PER QUERY (bit0 too few candidates, bit1 a
+// list overflowed), so that a caller repeats or re-routes only the queries concerned (rc_adc_search_exact never fails).
+extern "C" int rc_adc_search_q(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
+                               const float* C, int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,
+                               float* scores, int64_t* ids, int* status, int* qstatus, void* ws, size_t ws_bytes,
+                               rc_stream_t stream) {
     rc_device_guard device_guard_(h);
     if (!h || !codes || !C || !q || !scores || !ids || !status || N <= 0 || nq < 0 || k <= 0 || M <= 0 || D <= 0)
         return RC_EINVAL;
@@ -1620,7 +1643,173 @@ extern "C" int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint
     }
     if (rc != RC_OK) return rc;
     (void)adc_qt_for;
-    return rc_adc_launch_select(h, cand, cnt, nq, N, k, id_offset, scores, ids, status, s);
+    return rc_adc_launch_select(h, cand, cnt, nq, N, k, id_offset, scores, ids, status, s, qstatus);
+}
+
+// ------------------------------------------------------------------------------------------ exact search (never fails)
+// evaluate_repconc.py:180-185 relies on Faiss's IndexPQ.search, which returns for ANY index content.  The fast path above
+// places a candidate threshold from a sample and can, on degenerate data (thousands of rows with identical codes, all rows
+// tied), keep too few or too many candidates however the slack is set.  This path has no such failure mode: exact fp32
+// scores of every row (adc_scan_kernel<SAMPLE> with the sample = the whole index), then the k-th largest 64-bit key
+// (ordered(score) << 32 | ~row: distinct for distinct rows, so "the k best in (score desc, id asc) order" is a unique set)
+// by an 8-pass byte-wise radix select over all rows, then a compaction of the keys >= that key (exactly min(k, N) of them)
+// and the ordinary sort + emit.  Cost: N x 4 bytes of scores per query and ~10 passes over them — for the handful of
+// queries the fast path hands over, not for whole batches.
+#define ADC_EXACT_QX 8             // queries per round (scores [QX][N] fp32 in the workspace)
+__device__ __forceinline__ unsigned long long adc_exact_key(float s, int64_t i) {
+    return ((unsigned long long)adc_order_key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+}
+// grid (slices, queries of the round): histogram of byte `pass` (0 = most significant) over the keys whose higher bytes
+// equal prefix[q]
+__global__ __launch_bounds__(256) void adc_exact_hist_kernel(const float* __restrict__ sc, int64_t N,
+                                                             const unsigned long long* __restrict__ prefix, int pass,
+                                                             unsigned* __restrict__ hist) {
+    __shared__ unsigned h[256];
+    const int qx = blockIdx.y, tid = threadIdx.x;
+    h[tid] = 0u;
+    __syncthreads();
+    const unsigned long long pf = prefix[qx];
+    const int shift = 56 - 8 * pass;
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    const float* row = sc + (size_t)qx * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < N; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long key = adc_exact_key(row[i], i);
+        if ((key & himask) == pf) atomicAdd(&h[(unsigned)(key >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    if (h[tid]) atomicAdd(hist + (size_t)qx * 256 + tid, h[tid]);
+}
+// one block of 256 threads per query: the bin that holds the rank-th largest key; prefix and rank move on, hist is zeroed
+__global__ __launch_bounds__(256) void adc_exact_pick_kernel(unsigned* __restrict__ hist, unsigned long long* __restrict__ prefix,
+                                                             unsigned* __restrict__ rank, int pass) {
+    __shared__ unsigned s_scan[4];
+    __shared__ unsigned sel_prefix, sel_rank;
+    const int qx = blockIdx.x, tid = threadIdx.x;
+    unsigned* hq = hist + (size_t)qx * 256;
+    const unsigned need = rank[qx];
+    if (tid == 0) { sel_prefix = 0u; sel_rank = need; }
+    __syncthreads();
+    adc_pick_bin(hq, need, 0u, 0, s_scan, &sel_prefix, &sel_rank);     // bin index lands in sel_prefix (shift 0, prefix 0)
+    if (tid == 0) {
+        prefix[qx] |= (unsigned long long)(sel_prefix & 0xFFu) << (56 - 8 * pass);
+        rank[qx] = sel_rank;
+    }
+    hq[tid] = 0u;
+}
+__global__ __launch_bounds__(256) void adc_exact_init_kernel(unsigned* __restrict__ hist, unsigned long long* __restrict__ prefix,
+                                                             unsigned* __restrict__ rank, unsigned* __restrict__ cnt, unsigned want) {
+    const int qx = blockIdx.x, tid = threadIdx.x;
+    hist[(size_t)qx * 256 + tid] = 0u;
+    if (tid == 0) { prefix[qx] = 0ull; rank[qx] = want; cnt[qx] = 0u; }
+}
+// keys >= the selected key (= the min(k, N) best rows) go to the candidate list
+__global__ __launch_bounds__(256) void adc_exact_collect_kernel(const float* __restrict__ sc, int64_t N,
+                                                                const unsigned long long* __restrict__ prefix,
+                                                                unsigned* __restrict__ cand_count,
+                                                                unsigned long long* __restrict__ cand) {
+    const int qx = blockIdx.y, tid = threadIdx.x;
+    const unsigned long long kth = prefix[qx];
+    const float* row = sc + (size_t)qx * N;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < N; i0 += (int64_t)gridDim.x * 256) {      // wave-uniform trip count
+        const int64_t i = i0 + tid;
+        const unsigned long long key = i < N ? adc_exact_key(row[i], i) : 0ull;
+        const bool pass = i < N && key >= kth;
+        const unsigned long long mask = __ballot(pass);
+        if (mask) {
+            const int lane = tid & 63;
+            unsigned base = 0;
+            if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(cand_count + qx, (unsigned)__popcll(mask));
+            base = __shfl(base, (int)__builtin_ctzll(mask));
+            const unsigned slot = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+            if (pass && slot < ADC_CAND_CAP) cand[(size_t)qx * ADC_CAND_CAP + slot] = key;
+        }
+    }
+}
+
+struct adc_exact_layout { size_t lut, sc, hist, prefix, rank, cnt, cand, status, total; };
+static adc_exact_layout adc_exact_ws(int64_t N, int M, int nq) {
+    adc_exact_layout L;
+    size_t o = 0;
+    const int qx = nq < ADC_EXACT_QX ? nq : ADC_EXACT_QX;
+    L.lut = o;    o += rc_align_up((size_t)nq * M * RC_K * sizeof(float), 256);
+    L.sc = o;     o += rc_align_up((size_t)qx * (size_t)N * sizeof(float), 256);
+    L.hist = o;   o += rc_align_up((size_t)qx * 256 * sizeof(unsigned), 256);
+    L.prefix = o; o += rc_align_up((size_t)qx * sizeof(unsigned long long), 256);
+    L.rank = o;   o += rc_align_up((size_t)qx * sizeof(unsigned), 256);
+    L.cnt = o;    o += rc_align_up((size_t)qx * sizeof(unsigned), 256);
+    L.cand = o;   o += rc_align_up((size_t)qx * ADC_CAND_CAP * sizeof(unsigned long long), 256);
+    L.status = o; o += 256;
+    L.total = o;
+    return L;
+}
+extern "C" size_t rc_adc_search_exact_ws_bytes(int64_t N, int M, int K, int nq, int k) {
+    if (N <= 0 || M <= 0 || K != RC_K || nq <= 0 || k <= 0) return 0;
+    return adc_exact_ws(N, M, nq).total;
+}
+
+template <int M, int QT>
+static int adc_exact_scores(rc_handle_t h, const uint8_t* codes, int64_t N, const float* lut, int nq, float* sc, hipStream_t s) {
+    const size_t lds = (size_t)M * RC_K * QT * sizeof(float);
+    auto kern = adc_scan_kernel<M, QT, ADC_SAMPLE>;
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((nq + QT - 1) / QT), (unsigned)((N + ADC_TILE_DOCS - 1) / ADC_TILE_DOCS)),
+                       dim3(ADC_THREADS), lds, s, codes, N, lut, nq, N, sc, (const float*)nullptr, (unsigned*)nullptr,
+                       (unsigned long long*)nullptr);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+extern "C" int rc_adc_search_exact(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, const float* C, int D,
+                                   const float* q, int nq, int k, int64_t id_offset, float* scores, int64_t* ids, void* ws,
+                                   size_t ws_bytes, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !codes || !C || !q || !scores || !ids || N <= 0 || nq < 0 || k <= 0 || M <= 0 || D <= 0) return RC_EINVAL;
+    if (K != RC_K || D % M != 0 || N > 0xFFFFFFFFll || k > ADC_CAND_CAP / 2) return RC_ESHAPE;
+    if (nq == 0) return RC_OK;
+    const adc_exact_layout L = adc_exact_ws(N, M, nq);
+    if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
+    char* w = (char*)ws;
+    hipStream_t s = (hipStream_t)stream;
+    float* lut = (float*)(w + L.lut);
+    float* sc = (float*)(w + L.sc);
+    unsigned* hist = (unsigned*)(w + L.hist);
+    unsigned long long* prefix = (unsigned long long*)(w + L.prefix);
+    unsigned* rank = (unsigned*)(w + L.rank);
+    unsigned* cnt = (unsigned*)(w + L.cnt);
+    unsigned long long* cand = (unsigned long long*)(w + L.cand);
+    int* status = (int*)(w + L.status);
+    int rc = rc_adc_lut(h, C, q, nq, D, M, K, lut, stream);
+    if (rc != RC_OK) return rc;
+    const unsigned want = (unsigned)((int64_t)k < N ? (int64_t)k : N);
+    unsigned slices = (unsigned)((N + 256 * 64 - 1) / (256 * 64));
+    if (slices > 2048) slices = 2048;
+    for (int q0 = 0; q0 < nq; q0 += ADC_EXACT_QX) {
+        const int nx = nq - q0 < ADC_EXACT_QX ? nq - q0 : ADC_EXACT_QX;
+        const float* lq = lut + (size_t)q0 * M * RC_K;
+        switch (M) {
+#define ADC_EXACT_CASE(MM, QQ) case MM: rc = adc_exact_scores<MM, QQ>(h, codes, N, lq, nx, sc, s); break;
+            ADC_EXACT_CASE(8, 4) ADC_EXACT_CASE(12, 4) ADC_EXACT_CASE(16, 4) ADC_EXACT_CASE(24, 4) ADC_EXACT_CASE(32, 4)
+            ADC_EXACT_CASE(48, 2) ADC_EXACT_CASE(64, 2) ADC_EXACT_CASE(96, 1)
+#undef ADC_EXACT_CASE
+            default: return RC_ESHAPE;
+        }
+        if (rc != RC_OK) return rc;
+        hipLaunchKernelGGL(adc_exact_init_kernel, dim3((unsigned)nx), dim3(256), 0, s, hist, prefix, rank, cnt, want);
+        RC_LAUNCH_CHECK(h);
+        for (int pass = 0; pass < 8; ++pass) {
+            hipLaunchKernelGGL(adc_exact_hist_kernel, dim3(slices, (unsigned)nx), dim3(256), 0, s, (const float*)sc, N,
+                               (const unsigned long long*)prefix, pass, hist);
+            RC_LAUNCH_CHECK(h);
+            hipLaunchKernelGGL(adc_exact_pick_kernel, dim3((unsigned)nx), dim3(256), 0, s, hist, prefix, rank, pass);
+            RC_LAUNCH_CHECK(h);
+        }
+        hipLaunchKernelGGL(adc_exact_collect_kernel, dim3(slices, (unsigned)nx), dim3(256), 0, s, (const float*)sc, N,
+                           (const unsigned long long*)prefix, cnt, cand);
+        RC_LAUNCH_CHECK(h);
+        rc = rc_adc_launch_select(h, cand, cnt, nx, N, k, id_offset, scores + (size_t)q0 * k, ids + (size_t)q0 * k, status, s);
+        if (rc != RC_OK) return rc;
+    }
+    return RC_OK;
 }
 
 // =============================================================================================== IVF, list-centric
@@ -1796,7 +1985,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
         const size_t rl = (size_t)M * RC_K * sizeof(float);
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
         hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(ADC_RESCORE_THREADS), rl, s, codes, lut, (const float*)thr, (const unsigned*)idcnt,
-                           (const unsigned*)ids, cnt, cand, status, rowmap);
+                           (const unsigned*)ids, cnt, cand, status, rowmap, (int*)nullptr);
         RC_LAUNCH_CHECK(h);
     }
     hipLaunchKernelGGL(ivf_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const unsigned*)cnt, rows, nq, k, status);

@@ -169,17 +169,59 @@ extern "C" int rc_index_search(rc_index_t idx, const float* q, int nq, int k, fl
         RC_IDX_HIP(idx, hipMalloc(&idx->ws, need));
         idx->ws_bytes = need;
     }
+    // Like Faiss's IndexPQ.search (evaluate_repconc.py:180-185) this returns for any index content: the sampled-threshold
+    // search is tried twice on the whole batch; queries whose status bits are still set then go through the exact path
+    // (rc_adc_search_exact: no sample, no threshold), alone — the other queries' results stand.
+    int* qstatus = nullptr;
+    RC_IDX_HIP(idx, hipMalloc((void**)&qstatus, (size_t)nq * sizeof(int)));
+    struct guard { void* p[4]; ~guard() { for (void* q_ : p) if (q_) (void)hipFree(q_); } } g = {{qstatus, nullptr, nullptr, nullptr}};
     double slack = 6.0;
     int st = 0;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
         RC_IDX_HIP(idx, hipMemsetAsync(idx->status, 0, sizeof(int), s));
-        const int rc = rc_adc_search_img(idx->h, idx->codes, idx->image, idx->n, idx->M, idx->K, idx->C, idx->D, q, nq, k, 0,
-                                         slack, scores, ids, idx->status, idx->ws, idx->ws_bytes, stream);
+        RC_IDX_HIP(idx, hipMemsetAsync(qstatus, 0, (size_t)nq * sizeof(int), s));
+        const int rc = rc_adc_search_q(idx->h, idx->codes, idx->image, idx->n, idx->M, idx->K, idx->C, idx->D, q, nq, k, 0,
+                                       slack, scores, ids, idx->status, qstatus, idx->ws, idx->ws_bytes, stream);
         if (rc != RC_OK) return rc;
         RC_IDX_HIP(idx, hipMemcpyAsync(&st, idx->status, sizeof(int), hipMemcpyDeviceToHost, s));
         RC_IDX_HIP(idx, hipStreamSynchronize(s));
         if (st == 0) return RC_OK;
         slack = (st & 1) ? slack * 3.0 + 2.0 : (slack / 3.0);     // too few candidates -> widen; overflow -> tighten
     }
-    return RC_ESELECT;
+    int* hq = (int*)malloc((size_t)nq * sizeof(int));
+    if (!hq) return RC_EINVAL;
+    hipError_t e = hipMemcpy(hq, qstatus, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+    int nbad = 0;
+    for (int i = 0; e == hipSuccess && i < nq; ++i)
+        if (hq[i]) hq[nbad++] = i;                               // compacted in place: indices of the failing queries
+    if (e != hipSuccess) { free(hq); idx->h->last_hip_error = (int)e; return RC_EHIP; }
+    float* bq = nullptr; float* bs = nullptr; int64_t* bi = nullptr;
+    const size_t need_x = rc_adc_search_exact_ws_bytes(idx->n, idx->M, idx->K, nbad, k);
+    if (e == hipSuccess) e = hipMalloc((void**)&bq, (size_t)nbad * idx->D * sizeof(float));
+    g.p[1] = bq;
+    if (e == hipSuccess) e = hipMalloc((void**)&bs, (size_t)nbad * k * sizeof(float));
+    g.p[2] = bs;
+    if (e == hipSuccess) e = hipMalloc((void**)&bi, (size_t)nbad * k * sizeof(int64_t));
+    g.p[3] = bi;
+    if (e == hipSuccess && need_x > idx->ws_bytes) {
+        (void)hipFree(idx->ws);
+        idx->ws = nullptr; idx->ws_bytes = 0;
+        e = hipMalloc(&idx->ws, need_x);
+        if (e == hipSuccess) idx->ws_bytes = need_x;
+    }
+    for (int j = 0; e == hipSuccess && j < nbad; ++j)
+        e = hipMemcpyAsync(bq + (size_t)j * idx->D, q + (size_t)hq[j] * idx->D, (size_t)idx->D * sizeof(float), hipMemcpyDeviceToDevice, s);
+    int rc = RC_OK;
+    if (e == hipSuccess)
+        rc = rc_adc_search_exact(idx->h, idx->codes, idx->n, idx->M, idx->K, idx->C, idx->D, bq, nbad, k, 0, bs, bi, idx->ws,
+                                 idx->ws_bytes, stream);
+    for (int j = 0; e == hipSuccess && rc == RC_OK && j < nbad; ++j) {
+        e = hipMemcpyAsync(scores + (size_t)hq[j] * k, bs + (size_t)j * k, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(ids + (size_t)hq[j] * k, bi + (size_t)j * k, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToDevice, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    free(hq);
+    if (e != hipSuccess) { idx->h->last_hip_error = (int)e; return RC_EHIP; }
+    return rc;
 }

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void ivf_filter_kernel(const float* __restrict
 
 // adc_search.hip: sort the candidate keys and emit the top-k
 int rc_adc_launch_select(rc_handle_t h, unsigned long long* cand, const unsigned* cnt, int nq, int64_t N, int k,
-                         int64_t id_offset, float* scores, int64_t* ids, int* status, hipStream_t s);
+                         int64_t id_offset, float* scores, int64_t* ids, int* status, hipStream_t s, int* qstatus = nullptr);
 
 extern "C" size_t rc_ivf_search_ws_bytes(int nq, int64_t stride) {
     if (nq <= 0 || stride <= 0) return 0;

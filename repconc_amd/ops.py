@@ -495,39 +495,96 @@ def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Op
 
 class PendingSearch:
     """A search that has been enqueued but whose status word has not been read yet (`adc_search(..., defer=True)`).
-    `result()` synchronises, reads the status and — in the rare case that the sampled threshold admitted too few or too
-    many candidates — repeats the search with an adjusted slack, exactly as the immediate form does; then returns
-    (scores, ids).  Lets a caller enqueue every query batch before the first host synchronisation."""
+    `result()` synchronises and reads the status.  In the rare case that the sampled threshold admitted too few or too
+    many candidates for SOME queries, only those queries are repeated with an adjusted slack (the others' results stand),
+    and queries that still fail after `max_retries` repetitions are answered by the exact path (`adc_search_exact`),
+    which terminates for any index content — like Faiss's `index.search` (evaluate_repconc.py:180-185) this never raises
+    on degenerate data (thousands of identical codes, all rows tied).  Lets a caller enqueue every query batch before the
+    first host synchronisation."""
 
-    def __init__(self, run, scores, ids, status, slack, max_retries):
-        self._run, self._scores, self._ids, self._status = run, scores, ids, status
+    def __init__(self, rerun, scores, ids, status, qstatus, slack, max_retries, stream=None):
+        self._rerun, self._scores, self._ids, self._status, self._qstatus = rerun, scores, ids, status, qstatus
         self._slack, self._left, self._done = slack, max_retries, status is None
+        self._stream = stream
+        self.stats = {"retried_queries": 0, "exact_queries": 0}
 
     def result(self):
-        while not self._done:
-            st = int(self._status.item())
-            if st == 0:
-                self._done = True
-                break
-            if self._left <= 0:
-                raise _lib.RepconcHipError(f"ADC candidate selection did not converge (status {st}); "
-                                           "the index probably holds thousands of identical codes")
-            # bit0: too few candidates (threshold too high) -> widen; bit1: overflow -> tighten
-            self._slack = max(self._slack, 0.0) * 3.0 + 2.0 if (st & 1) else max(self._slack / 3.0, 0.0)
-            self._left -= 1
-            self._run(self._slack)
-        self._run = None
+        if self._done:
+            return self._scores, self._ids
+        # retries run on the stream the search was enqueued on, whatever stream is current when result() is called
+        with torch.cuda.stream(self._stream) if self._stream is not None else _nullcontext():
+            if int(self._status.item()) != 0:
+                bad = torch.nonzero(self._qstatus).flatten()
+                bits = self._qstatus[bad]
+                slack_few, slack_many = self._slack, self._slack
+                while bad.numel() and self._left > 0:
+                    self._left -= 1
+                    self.stats["retried_queries"] += int(bad.numel())
+                    slack_few = max(slack_few, 0.0) * 3.0 + 2.0          # bit0: too few candidates -> wider
+                    slack_many = max(slack_many / 3.0, 0.0)              # bit1 only: a list overflowed -> tighter
+                    still, still_bits = [], []
+                    for sel, slack in (((bits & 1) != 0, slack_few), ((bits & 1) == 0, slack_many)):
+                        idx = bad[sel]
+                        if idx.numel() == 0:
+                            continue
+                        s, i, qs = self._rerun(idx, slack, False)
+                        ok = qs == 0
+                        self._scores[idx[ok]] = s[ok]
+                        self._ids[idx[ok]] = i[ok]
+                        still.append(idx[~ok])
+                        still_bits.append(qs[~ok])
+                    bad, bits = torch.cat(still), torch.cat(still_bits)
+                if bad.numel():
+                    self.stats["exact_queries"] = int(bad.numel())
+                    s, i, _ = self._rerun(bad, 0.0, True)
+                    self._scores[bad] = s
+                    self._ids[bad] = i
+        self._done = True
+        self._rerun = None
         return self._scores, self._ids
 
 
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def adc_search_exact(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k: int, id_offset: int = 0):
+    """The same answer as `adc_search` by the path that cannot fail (rc_adc_search_exact): exact scores of every row and
+    a radix select of the min(k, N) best keys.  For the queries the sampled-threshold path gives up on, and a slow but
+    independent cross-check in the tests."""
+    _need_cuda(codes, centroids, q)
+    if codes.dtype != torch.uint8 or not codes.is_contiguous():
+        raise ValueError("index codes must be contiguous uint8 [N, M]")
+    c, q = _centroids(centroids), _rows_f32(q).contiguous()
+    N, M = codes.shape
+    nq, D = q.shape
+    lib, h, s, _ = _ctx(q)
+    scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+    if nq == 0 or N == 0:
+        scores.fill_(float("-inf"))
+        ids.fill_(-1)
+        return scores, ids
+    wsb = lib.rc_adc_search_exact_ws_bytes(N, M, K, nq, k)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.rc_adc_search_exact(h, _p(codes), N, M, K, _p(c), D, _p(q), nq, int(k), int(id_offset), _p(scores), _p(ids),
+                                       _p(ws), wsb, s), "rc_adc_search_exact", h)
+    return scores, ids
+
+
 def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k: int, id_offset: int = 0,
-               sel_slack: float = 6.0, max_retries: int = 3, scan_image: Optional[torch.Tensor] = None,
+               sel_slack: float = 6.0, max_retries: int = 2, scan_image: Optional[torch.Tensor] = None,
                defer: bool = False):
     """Top-k inner-product ADC search of `q` [nq,D] against uint8 `codes` [N,M].
     Returns (scores [nq,k] fp32, ids [nq,k] int64), sorted (score desc, id asc).
     evaluate_repconc.py:180-185 / finetune_jpq.py:176.
     scan_image: the index's permuted code image (adc_scan_image_), kept by PQIndex; None = rebuilt per call.
-    defer: return a `PendingSearch` instead (no host synchronisation here; `.result()` gives the pair)."""
+    defer: return a `PendingSearch` instead (no host synchronisation here; `.result()` gives the pair).
+    Never raises on degenerate index content: see `PendingSearch`."""
     _need_cuda(codes, centroids, q, scan_image)
     if codes.dtype != torch.uint8 or not codes.is_contiguous():
         raise ValueError("index codes must be contiguous uint8 [N, M]")
@@ -540,25 +597,40 @@ def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k:
     nq, D = q.shape
     if D != M * c.shape[2]:
         raise ValueError("query width does not match the centroid table")
-    lib, h, s, _ = _ctx(q)
+    lib, h, s, dev = _ctx(q)
     scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
     if nq == 0 or N == 0:
         if nq and N == 0:
             scores.fill_(float("-inf"))
             ids.fill_(-1)
-        return PendingSearch(None, scores, ids, None, 0.0, 0) if defer else (scores, ids)
-    wsb = (lib.rc_adc_search_img_ws_bytes if scan_image is not None else lib.rc_adc_search_ws_bytes)(N, M, K, nq, k)
-    status = torch.zeros((1,), dtype=torch.int32, device=q.device)
+        return PendingSearch(None, scores, ids, None, None, 0.0, 0) if defer else (scores, ids)
+    ws_fn = lib.rc_adc_search_img_ws_bytes if scan_image is not None else lib.rc_adc_search_ws_bytes
 
-    def run(slack):
+    def launch(qq, slack, out_s, out_i):
         # the workspace is released when this returns: the caching allocator hands it out again in stream order only
+        n = qq.shape[0]
+        wsb = ws_fn(N, M, K, n, k)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
-        status.zero_()
-        _lib.check(lib.rc_adc_search_img(h, _p(codes), _p(scan_image), N, M, K, _p(c), D, _p(q), nq, int(k),
-                                         int(id_offset), float(slack), _p(scores), _p(ids), _p(status), _p(ws), wsb, s),
-                   "rc_adc_search_img", h)
+        status = torch.zeros((1,), dtype=torch.int32, device=q.device)
+        qstatus = torch.zeros((n,), dtype=torch.int32, device=q.device)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.rc_adc_search_q(h, _p(codes), _p(scan_image), N, M, K, _p(c), D, _p(qq), n, int(k), int(id_offset),
+                                       float(slack), _p(out_s), _p(out_i), _p(status), _p(qstatus), _p(ws), wsb, st),
+                   "rc_adc_search_q", h)
+        return status, qstatus
 
-    run(float(sel_slack))
-    pending = PendingSearch(run, scores, ids, status, float(sel_slack), max_retries)
+    def rerun(idx, slack, exact):
+        qq = q[idx].contiguous()
+        if exact:
+            s_, i_ = adc_search_exact(codes, c, qq, k, id_offset)
+            return s_, i_, None
+        s_ = torch.empty((qq.shape[0], k), dtype=torch.float32, device=q.device)
+        i_ = torch.empty((qq.shape[0], k), dtype=torch.int64, device=q.device)
+        _, qs = launch(qq, slack, s_, i_)
+        return s_, i_, qs
+
+    status, qstatus = launch(q, float(sel_slack), scores, ids)
+    pending = PendingSearch(rerun, scores, ids, status, qstatus, float(sel_slack), max_retries,
+                            stream=torch.cuda.current_stream(dev))
     return pending if defer else pending.result()

@@ -1,0 +1,148 @@
+"""Search that cannot fail (evaluate_repconc.py:180-185: Faiss's index.search returns for any index content).
+
+The fast path places a candidate threshold from a sample of the rows; degenerate indexes (every row identical, a few distinct
+codes, k = N, thousands of copies of one passage) defeat any slack.  Then: per-query status bits, only the queries concerned
+are repeated, and what still fails goes through rc_adc_search_exact — never a RepconcHipError, and the answer is the
+oracle's (score desc, id asc) top-k."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _case(M, N, nq, seed):
+    C = synth.gaussian(seed + 1, (M, 256, 768 // M))
+    codes = synth.uniform_codes(seed + 2, N, M)
+    q = synth.gaussian(seed + 3, (nq, 768))
+    return C, codes, q
+
+
+def _same(scores, ids, ws, wi):
+    assert np.array_equal(ids.cpu().numpy(), wi)
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("M,N,nq,k", [(48, 70000, 5, 100), (96, 30000, 3, 1000), (8, 3000, 4, 3000), (24, 300000, 9, 10),
+                                      (48, 500, 2, 1000), (64, 20001, 3, 1)])
+def test_exact_path_equals_the_oracle(M, N, nq, k):
+    from repconc_amd import ops
+    C, codes, q = _case(M, N, nq, seed=7 * M + N)
+    s, i = ops.adc_search_exact(_t(codes), _t(C), _t(q), k)
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    _same(s, i, ws, wi)
+
+
+@pytest.mark.parametrize("N,k", [(50000, 1000), (50000, 10), (300000, 200)])
+def test_index_of_identical_rows(N, k):
+    """Every row has the same code: every score ties, every list overflows whatever the slack.  The answer is rows
+    0 .. k-1 (ties by id) with that one score."""
+    from repconc_amd import ops
+    C, codes, q = _case(48, 1, 4, seed=1)
+    codes = np.repeat(codes, N, 0)
+    pend = ops.adc_search(_t(codes), _t(C), _t(q), k, defer=True)
+    s, i = pend.result()
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    _same(s, i, ws, wi)
+    assert np.array_equal(wi, np.tile(np.arange(k), (4, 1)))
+    assert pend.stats["exact_queries"] == 4
+
+
+@pytest.mark.parametrize("N", [60000, 400000])
+def test_index_with_three_distinct_codes(N):
+    """One of 3 codes per row (N >= 2^18 goes through the 8-bit screen)."""
+    from repconc_amd import ops
+    from repconc_amd.index import PQIndex
+    C, base, q = _case(48, 3, 6, seed=2)
+    codes = base[np.random.default_rng(5).integers(0, 3, N)]
+    idx = PQIndex(768, 48)
+    idx.set_centroids(_t(C))
+    idx.add_codes(_t(codes))
+    s, i = idx.search(_t(q), 500)
+    ws, wi = c_oracle.adc_search(codes, C, q, 500)
+    _same(s, i, ws, wi)
+
+
+def test_k_equals_n():
+    from repconc_amd import ops
+    for M, N in ((48, 2000), (16, 8000)):
+        C, codes, q = _case(M, N, 3, seed=N)
+        s, i = ops.adc_search(_t(codes), _t(C), _t(q), N)
+        ws, wi = c_oracle.adc_search(codes, C, q, N)
+        _same(s, i, ws, wi)
+
+
+def test_one_degenerate_query_does_not_tax_the_others():
+    """300 k random rows + 20 000 copies of one row.  For the queries whose top-k reaches the copies' score the candidate
+    list overflows: only THOSE queries are repeated / answered exactly, every query gets the oracle's answer."""
+    from repconc_amd import ops
+    M, N, nq, k = 48, 300000, 24, 1000
+    C, codes, q = _case(M, N, nq, seed=11)
+    dup = codes[123].copy()
+    codes = np.concatenate([codes, np.repeat(dup[None], 20000, 0)], 0)
+    # half of the queries point at the duplicated passage: its 20 001 copies fill their top-k
+    from oracle import pq_oracle
+    recon = pq_oracle.decode(dup[None].astype(np.int64), C)[0]
+    q[: nq // 2] = (q[: nq // 2] * 0.1 + recon * 3.0).astype(np.float32)
+    pend = ops.adc_search(_t(codes), _t(C), _t(q), k, defer=True)
+    s, i = pend.result()
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    _same(s, i, ws, wi)
+    assert 1 <= pend.stats["exact_queries"] <= nq // 2
+    assert pend.stats["retried_queries"] <= 2 * (nq // 2)
+
+
+def test_c_index_never_returns_eselect():
+    """rc_index_search on an index of identical rows: RC_OK and the oracle's answer (was RC_ESELECT)."""
+    from repconc_amd import _lib
+    lib, h = _lib.load(), _lib.handle(0)
+    M, N, nq, k = 48, 40000, 3, 100
+    C, codes, q = _case(M, 1, nq, seed=3)
+    codes = np.repeat(codes, N, 0)
+    # one ordinary query batch on an ordinary index through the same handle afterwards: workspace regrowth is harmless
+    idx = ctypes.c_void_p()
+    assert lib.rc_index_create(h, 768, M, 256, ctypes.byref(idx)) == 0
+    try:
+        dq, dC, dcodes = _t(q), _t(C), _t(codes)
+        sc = torch.empty((nq, k), dtype=torch.float32, device=DEV)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=DEV)
+        assert lib.rc_index_set_centroids(idx, dC.data_ptr(), None) == 0
+        assert lib.rc_index_add_codes(idx, dcodes.data_ptr(), N, None) == 0
+        assert lib.rc_index_search(idx, dq.data_ptr(), nq, k, sc.data_ptr(), ids.data_ptr(), None) == 0
+        ws, wi = c_oracle.adc_search(codes, C, q, k)
+        _same(sc, ids, ws, wi)
+    finally:
+        assert lib.rc_index_destroy(idx) == 0
+
+
+@pytest.mark.parametrize("mode", ["replicated", "sharded"])
+def test_in_place_centroid_write_reaches_every_part_of_a_multi_index(mode):
+    """finetune_jpq.py:211-213 writes the centroids IN PLACE through `faiss.copy_array_to_vector(c, index.pq.centroids)`.
+    On a replicated / sharded index every part has its own resident table: the write must reach all of them (it used to
+    update part 0 only, and the parts then scored with different codebooks)."""
+    from repconc_amd import faiss_compat as faiss
+    from repconc_amd.index import PQIndex
+    from repconc_amd.models.repconc.evaluate_repconc import load_index_to_gpu
+    C, codes, q = _case(48, 30000, 9, seed=21)
+    idx = PQIndex(768, 48)
+    idx.set_centroids(_t(C))
+    idx.add_codes(_t(codes))
+    ndev = torch.cuda.device_count()
+    multi = load_index_to_gpu(idx, None, shard=(mode == "sharded"), devices=list(range(ndev)) if ndev >= 2 else [0, 0, 0])
+    C2 = (C * np.float32(0.5) + np.float32(0.125)).astype(np.float32)
+    faiss.copy_array_to_vector(C2.ravel(), multi.pq.centroids)
+    for part in multi.parts:
+        assert np.array_equal(part.pq.centroids.cpu().numpy(), C2)
+    s, i = multi.search(_t(q), 50)
+    ws, wi = c_oracle.adc_search(codes, C2, q, 50)
+    _same(s, i, ws, wi)
+    assert np.array_equal(faiss.vector_to_array(multi.pq.centroids), C2.ravel())
