@@ -38,7 +38,8 @@ def copy_array_to_vector(array, vector: torch.Tensor) -> None:
 
 def vector_to_array(vector) -> np.ndarray:
     """Flat numpy copy of `index.pq.centroids` (float32) or `index.codes` (uint8, row-major [ntotal * M])."""
-    t = vector.detach() if isinstance(vector, torch.Tensor) else torch.as_tensor(vector)
+    # tensors, and the fan-out view a multi-device index exposes as pq.centroids (multi_index._FanoutCentroids)
+    t = vector.detach() if hasattr(vector, "detach") else torch.as_tensor(vector)
     return t.reshape(-1).cpu().numpy().copy()
 
 

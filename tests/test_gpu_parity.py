@@ -243,6 +243,65 @@ def test_adc_golden_fixture_and_duplicates():
     assert np.array_equal(i2.cpu().numpy(), wi + 1000)
 
 
+@pytest.mark.parametrize("M,N", [(24, 100000), (64, 100000), (96, 120000)])
+def test_adc_fixtures_from_the_reference_decode_other_widths(M, N):
+    """oracle/gen_golden.py --extra: exact <q, decode(codes)> on the REFERENCE's decode, k = 1000, M in {24, 64, 96}.  The
+    HIP search equals the C oracle bit for bit and the reference-derived scores to fp32 summation error."""
+    from repconc_amd import ops
+    g = np.load(os.path.join(GOLDEN, f"adc_m{M}_n{N}.npz"))
+    nq, k, seed = int(g["nq"]), int(g["k"]), int(g["seed"])
+    C = synth.gaussian(seed, (M, 256, 768 // M))
+    codes = synth.uniform_codes(seed + 1, N, M)
+    q = synth.gaussian(seed + 2, (nq, 768))
+    scores, ids = ops.adc_search(_t(codes), _t(C), _t(q), k)
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    assert np.array_equal(ids.cpu().numpy(), wi) and np.array_equal(scores.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    np.testing.assert_allclose(scores.cpu().numpy(), g["top_scores"], rtol=0, atol=1e-3)
+    assert (ids.cpu().numpy() == g["top_ids"].astype(np.int64)).mean() > 0.98
+
+
+def test_forward_fixture_m96_from_the_reference():
+    """The reference's forward() at M = 96: module output codes on the reference's continuous embeddings, nearest and
+    constrained, and decode CRC."""
+    from types import SimpleNamespace
+    from repconc_amd.models.repconc import RepCONC
+    g = np.load(os.path.join(GOLDEN, "forward_m96_b512.npz"))
+    seed = int(g["seed"])
+    table = torch.from_numpy(synth.clustered_embeddings(seed, 512))
+    C = synth.sample_centroids(seed + 1, table.numpy(), 96)
+    cfg = SimpleNamespace(MCQ_M=96, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_IP")
+    model = RepCONC(cfg, _TableEncoder(table), False, EPS, ITERS).to(DEV)
+    rot = torch.linalg.qr(torch.from_numpy(synth.gaussian(int(g["rotation_seed"]), (768, 768))))[0].contiguous()
+    with torch.no_grad():
+        model.centroids.copy_(_t(C))
+        model.rotation.copy_(rot.to(DEV))
+    ids = torch.arange(512, device=DEV)[:, None].repeat(1, 4)
+    out = model(ids, torch.ones_like(ids), return_code=True, return_quantized_embedding=True)
+    np.testing.assert_allclose(out.continuous_embeds.cpu().numpy(), g["ip_continuous"], rtol=1e-4, atol=1e-4)
+    cont = _t(g["ip_continuous"])
+    assert np.array_equal(model.quantize(cont).cpu().numpy().astype(np.uint8), g["ip_codes"])
+    model.use_constraint = True
+    assert np.array_equal(model.quantize(cont).cpu().numpy().astype(np.uint8), g["ip_codes_constrained"])
+    assert zlib.crc32(model.decode(_t(g["ip_codes"]).long()).detach().cpu().numpy().tobytes()) == int(g["ip_quantized_crc"])
+
+
+def test_config0_exact_shape_10000_m8_against_the_oracle():
+    """BASELINE configs[0] at its exact shape: x [10 000, 768] seed 20220, M = 8, centroids = rows of x at
+    rng(20221).permutation(N)[:256], ONE batch of 10 000 rows, eps 0.003, 100 iterations — constrained and nearest codes
+    against the C oracle."""
+    from repconc_amd import ops
+    N, M = 10000, 8
+    x = np.random.default_rng(20220).standard_normal((N, 768), dtype=np.float32)
+    C = np.ascontiguousarray(x[np.random.default_rng(20221).permutation(N)[:256]].reshape(256, M, 768 // M).transpose(1, 0, 2))
+    got, flags = ops.assign_sinkhorn(_t(x), _t(C), EPS, ITERS, torch.uint8)
+    want, _ = c_oracle.quantize(x, C, True, EPS, ITERS)
+    assert int(flags.item()) == 0 and np.array_equal(got.cpu().numpy(), want)
+    near = ops.assign_nearest(_t(x), _t(C), torch.uint8)
+    assert np.array_equal(near.cpu().numpy(), c_oracle.quantize(x, C, False)[0])
+    hist = np.bincount(got.cpu().numpy()[:, 0], minlength=256)
+    assert 30 <= hist.min() and hist.max() <= 48              # SURVEY Appendix A: 35 .. 43 around the ideal 39.06
+
+
 def test_adc_large_index_properties():
     """BASELINE-size index (8.84M x 48): top-k must be sorted, contain planted winners, and agree
     with an exact rescoring of the returned ids."""

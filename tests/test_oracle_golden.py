@@ -107,6 +107,46 @@ def test_adc_identity_against_reference_decode():
     assert np.array_equal(ci, ids) and np.array_equal(cs.view(np.uint32), scores.view(np.uint32))
 
 
+@pytest.mark.parametrize("M,N", [(24, 100000), (64, 100000), (96, 120000)])
+def test_adc_fixtures_from_the_reference_decode_other_widths(M, N):
+    """Round-3 fixtures (oracle/gen_golden.py --extra): exact fp64 <q, decode(codes)> on the reference's decode, k = 1000,
+    N >= 1e5, M in {24, 64, 96}.  The C restatement's LUT sums agree to fp32 summation error; ids differ only where two
+    scores are closer than that."""
+    import os
+    from conftest import GOLDEN
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, f"adc_m{M}_n{N}.npz"))
+    nq, k, seed = int(g["nq"]), int(g["k"]), int(g["seed"])
+    C = synth.gaussian(seed, (M, 256, 768 // M))
+    codes = synth.uniform_codes(seed + 1, N, M)
+    q = synth.gaussian(seed + 2, (nq, 768))
+    cs, ci = c_oracle.adc_search(codes, C, q, k)
+    np.testing.assert_allclose(cs, g["top_scores"], rtol=0, atol=1e-3)
+    same = ci == g["top_ids"].astype(np.int64)
+    assert same.mean() > 0.98
+    for qi, r in zip(*np.nonzero(~same)):
+        assert abs(float(cs[qi, r]) - float(g["top_scores_f64"][qi, r])) < 1e-3
+    for r in range(nq):
+        assert len(set(ci[r].tolist()) & set(g["top_ids"][r].tolist())) >= k - 3
+
+
+def test_forward_fixture_m96_codes_from_the_reference():
+    """forward() of the reference at M = 96 (dsub 8): on the reference's own continuous embeddings both C / numpy
+    restatements give the reference's codes, nearest and constrained."""
+    import os
+    from conftest import GOLDEN
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, "forward_m96_b512.npz"))
+    seed = int(g["seed"])
+    table = synth.clustered_embeddings(seed, 512)
+    C = synth.sample_centroids(seed + 1, table, 96)
+    near, _ = c_oracle.quantize(g["ip_continuous"], C, False)
+    assert np.array_equal(near, g["ip_codes"])
+    con, _ = c_oracle.quantize(g["ip_continuous"], C, True, 0.003, 100)
+    assert np.array_equal(con, g["ip_codes_constrained"])
+    assert zlib.crc32(np.ascontiguousarray(pq_oracle.decode(g["ip_codes"].astype(np.int64), C)).tobytes()) == int(g["ip_quantized_crc"])
+
+
 def test_mrr_at_k():
     ranked = np.array([[5, 3, 9], [1, 2, 3], [7, 8, 9]])
     assert pq_oracle.mrr_at_k(ranked, [{3}, {1}, {4}], 10) == round((0.5 + 1.0 + 0.0) / 3, 5)
