@@ -306,25 +306,47 @@ def lloyd(x, centroids, n_iter: int):
     return C
 
 
-def reseed_empty(C, cnt):
-    """Faiss 1.7.x `split_clusters` as SURVEY.md Appendix B restates it: an empty cluster takes a copy of the most
-    populated cluster's centroid, the copy scaled by (1 +- 1/1024) with alternating sign over the components and the
-    donor by the opposite factor; the donor's count is split in two.  (Simplification kept on both sides of the parity
-    test: the donor is the argmax, not Faiss's size-proportional random draw.)"""
-    eps = 1.0 / 1024
+def reseed_empty(C, cnt, n=None):
+    """Faiss 1.7.x `split_clusters` (Clustering.cpp; restated from the published source), applied to
+    every sub-quantiser as Faiss's per-sub-quantiser `Clustering` objects do: with a generator re-seeded to 1234
+    (std::mt19937; numpy's legacy RandomState produces the same stream) walk the clusters cyclically from 0 and accept
+    cluster cj as the donor with probability (size_cj - 1) / (n - k) — a size-proportional draw, not the arg-max; the empty
+    cluster takes a copy of the donor's centroid, the copy scaled by (1 +- 1/1024) with alternating sign over the components
+    and the donor by the opposite factor; the donor's (float) size is halved.  `n`: number of training points (default: the
+    sum of the counts).  Returns the number of splits."""
+    eps = F32(1.0 / 1024)
     M, K, dsub = C.shape
-    cnt = cnt.copy()
-    sign = np.where(np.arange(dsub) % 2 == 0, 1.0, -1.0).astype(F32) * F32(eps)
-    n = 0
-    for m, k in zip(*np.nonzero(cnt == 0)):
-        j = int(np.argmax(cnt[m]))
-        C[m, k] = C[m, j] * (F32(1) + sign)
-        C[m, j] = C[m, j] * (F32(1) - sign)
-        half = cnt[m, j] // 2
-        cnt[m, k] = half
-        cnt[m, j] -= half
-        n += 1
-    return n
+    nsplit = 0
+    for m in range(M):
+        h = cnt[m].astype(F32)
+        if not (h == 0).any():
+            continue
+        nn = int(cnt[m].sum()) if n is None else int(n)
+        denom = np.float64(F32(nn - K))
+        rs = np.random.RandomState(1234)
+        raw = rs._bit_generator.random_raw
+        for ci in range(K):
+            if h[ci] != 0:
+                continue
+            cj, draws = 0, 0
+            if denom <= 0 or h.max() <= 1:                   # Faiss would spin forever: take the biggest cluster
+                cj = int(np.argmax(h))
+            else:
+                while True:
+                    p = F32((np.float64(h[cj]) - 1.0) / denom)
+                    r = F32(raw()) / F32(4294967295.0)
+                    draws += 1
+                    if r < p or draws > 10_000_000:
+                        break
+                    cj = (cj + 1) % K
+            C[m, ci] = C[m, cj]
+            even = np.arange(dsub) % 2 == 0
+            C[m, ci] = np.where(even, C[m, ci] * (F32(1) + eps), C[m, ci] * (F32(1) - eps)).astype(F32)
+            C[m, cj] = np.where(even, C[m, cj] * (F32(1) - eps), C[m, cj] * (F32(1) + eps)).astype(F32)
+            h[ci] = h[cj] / F32(2)
+            h[cj] = h[cj] - h[ci]
+            nsplit += 1
+    return nsplit
 
 
 def train_pq(x, M, n_iter, centroids=None, seed=1234, quantize_fn=None):

@@ -99,23 +99,50 @@ def broadcast_from_rank0_(t: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def _reseed_empty(C: torch.Tensor, counts: torch.Tensor):
-    """Faiss's empty-cluster rule: give an empty centroid a copy of the biggest cluster's centroid, perturbed by
-    +-1/1024 (and the donor by the opposite sign)."""
-    eps = 1.0 / 1024
-    M, K, dsub = C.shape
-    empty = (counts == 0).nonzero().cpu().tolist()
-    if not empty:
+    """Empty clusters after an update, by Faiss's published rule (`split_clusters`, Clustering.cpp of 1.7.x — what
+    `index.train` at train/run_warmup.py:113 runs): per sub-quantiser a std::mt19937 seeded with 1234 (numpy's legacy
+    RandomState is the same generator) drives a cyclic walk over the clusters that accepts cluster j as the donor with
+    probability (size_j - 1) / (n - 256); the empty cluster gets the donor's centroid scaled by (1 +- 1/1024), alternating
+    over the components, the donor the opposite factors, and the donor's size is halved for the following draws.
+    Empty clusters are rare: the walk runs on the host on the [M, 256] counts and touches only the rows concerned; every
+    rank holds the same counts, hence makes the same splits."""
+    if not bool((counts == 0).any()):
         return 0
-    cnt = counts.clone()
-    sign = torch.where(torch.arange(dsub, device=C.device) % 2 == 0, 1.0, -1.0) * eps
-    for m, k in empty:
-        j = int(torch.argmax(cnt[m]))
-        C[m, k] = C[m, j] * (1 + sign)
-        C[m, j] = C[m, j] * (1 - sign)
-        half = cnt[m, j] // 2
-        cnt[m, k] = half
-        cnt[m, j] -= half
-    return len(empty)
+    M, K, dsub = C.shape
+    f32 = np.float32
+    eps = f32(1.0 / 1024)
+    cnt = counts.cpu().numpy()
+    Ch = C.detach().cpu().numpy().copy()
+    even = np.arange(dsub) % 2 == 0
+    nsplit = 0
+    for m in range(M):
+        h = cnt[m].astype(f32)
+        if not (h == 0).any():
+            continue
+        denom = np.float64(f32(int(cnt[m].sum()) - K))
+        draw = np.random.RandomState(1234)._bit_generator.random_raw
+        for ci in range(K):
+            if h[ci] != 0:
+                continue
+            cj, draws = 0, 0
+            if denom <= 0 or h.max() <= 1:                   # nothing to split by size: the biggest cluster
+                cj = int(np.argmax(h))
+            else:
+                while True:
+                    p = f32((np.float64(h[cj]) - 1.0) / denom)
+                    r = f32(draw()) / f32(4294967295.0)
+                    draws += 1
+                    if r < p or draws > 10_000_000:
+                        break
+                    cj = (cj + 1) % K
+            src = Ch[m, cj].copy()
+            Ch[m, ci] = np.where(even, src * (f32(1) + eps), src * (f32(1) - eps)).astype(f32)
+            Ch[m, cj] = np.where(even, src * (f32(1) - eps), src * (f32(1) + eps)).astype(f32)
+            h[ci] = h[cj] / f32(2)
+            h[cj] = h[cj] - h[ci]
+            nsplit += 1
+    C.copy_(torch.from_numpy(Ch).to(C.device))
+    return nsplit
 
 
 def procrustes_rotation(P: torch.Tensor, tol: float = 1e-13, max_iter: int = 160) -> torch.Tensor:

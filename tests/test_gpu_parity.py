@@ -1842,3 +1842,27 @@ def test_deferred_search_on_empty_inputs():
     idx.set_centroids(C)
     s2, i2 = idx.search_async(synth.gaussian(6, (2, 768)), 3)()
     assert s2.shape == (2, 3) and (i2 == -1).all()
+
+
+def test_empty_cluster_rule_is_the_published_faiss_rule_on_both_sides():
+    """train/run_warmup.py:113 runs Faiss's Clustering, whose `split_clusters` re-seeds empty clusters with a seeded,
+    size-proportional donor draw.  The product's `_reseed_empty` and the oracle's restatement make the same splits
+    (several empties per sub-quantiser, a donor that is split twice, sub-quantisers without empties untouched)."""
+    from repconc_amd.train.run_warmup import _reseed_empty
+    rng = np.random.default_rng(17)
+    M, K, dsub = 6, 256, 16
+    C = rng.standard_normal((M, K, dsub)).astype(np.float32)
+    cnt = rng.integers(1, 40, (M, K)).astype(np.int64)
+    cnt[0, [3, 77, 200]] = 0
+    cnt[2, 5] = 0
+    cnt[2, 6] = 4000                       # dominant cluster: the likely donor
+    cnt[4, :] = 1
+    cnt[4, 9] = 0                          # nothing to split by size: falls back to the biggest cluster
+    cnt[5, [0, 1, 2, 3, 4, 5, 6, 7]] = 0
+    want = C.copy()
+    n_want = pq_oracle.reseed_empty(want, cnt)
+    Ct, ct = _t(C).clone(), _t(cnt)
+    n_got = _reseed_empty(Ct, ct)
+    assert n_got == n_want == 3 + 1 + 1 + 8
+    assert np.array_equal(Ct.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(want[[1, 3]], C[[1, 3]])

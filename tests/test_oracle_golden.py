@@ -178,10 +178,21 @@ def test_warmup_procedure_oracle_lowers_the_error_and_keeps_the_rotation_orthogo
     R, hist = pq_oracle.train_opq(x, M, R0, 4, 3, 2, quantize_fn=cq)
     assert np.abs(R @ R.T - np.eye(D)).max() < 1e-5
     assert hist[-1] < hist[0]
-    # empty clusters are re-seeded from the biggest one
+    # empty clusters: Faiss's split_clusters — a seeded, size-proportional donor (not the arg-max), +-1/1024 perturbation
     C = C3.copy()
     cnt = np.full((M, 256), 16, np.int64)
     cnt[2, 7] = 0
     cnt[2, 9] = 100
     assert pq_oracle.reseed_empty(C, cnt) == 1
-    assert np.allclose(C[2, 7] + C[2, 9], 2 * C3[2, 9], rtol=1e-6) and not np.array_equal(C[2, 7], C[2, 9])
+    changed = [k for k in range(256) if not np.array_equal(C[2, k], C3[2, k])]
+    assert len(changed) == 2 and 7 in changed
+    donor = [k for k in changed if k != 7][0]
+    assert np.allclose(C[2, 7] + C[2, donor], 2 * C3[2, donor], rtol=1e-6) and not np.array_equal(C[2, 7], C[2, donor])
+    # the walk is the published one: std::mt19937(1234), accept cluster j with probability (size_j - 1) / (n - k)
+    rs = np.random.RandomState(1234)
+    n, j = int(cnt[2].sum()), 0
+    while not (np.float32(rs._bit_generator.random_raw()) / np.float32(4294967295.0)
+               < np.float32((float(cnt[2, j]) - 1.0) / float(np.float32(n - 256)))):
+        j = (j + 1) % 256
+    assert j == donor
+    assert np.array_equal(C[[0, 1, 3]], C3[[0, 1, 3]])
