@@ -331,7 +331,10 @@ def main():
                                "one extra profiled step after the timed region (the timed region replays the hipGraph)",
                 "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic("sk_sweep_kernel"), "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic": pmc_traffic("sk_sweep_kernel"),
+                "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc passes of an earlier profiled run of this "
+                                  "command), NOT measured by this run",
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(sweep_ms, 4), "launches_timed": n_l.value,
                 "sub_quantisers_per_launch": M // n_chains}
 
@@ -449,18 +452,20 @@ def main():
                          "bound": "lds-gather", "achieved": round(lds_ach, 1), "peak": round(lds_peak, 1), "unit": "GB/s",
                          "frac": round(lds_ach / lds_peak, 4), "lds_bytes_per_launch": lds_bytes,
                          "avg_launch_ms": round(scan_ms, 3), "launches_timed": n_l.value,
-                         "measured_gather_roof": {"ns_per_gather_instruction_per_cu": 2.2, "GBs": round(512 / 2.2 * 256, 1),
-                                                  "frac": round(lds_ach / (512 / 2.2 * 256), 4),
-                                                  "note": "tools/ubench_lds_gather.hip (profiles/r02c_ubench_lds_gather.txt): a "
-                                                          "random-code ds_read_b64 gather with the screen's two-instruction address, "
-                                                          "zero bank conflicts, 16 waves per CU, sustains 2.2-2.4 ns per "
-                                                          "wave-instruction per CU with or without the MFMAs - the nominal 256 B/clk is "
-                                                          "for sequential reads"},
+                         "measured_gather_roof": {
+                             "lds_alone_cycles_per_gather_per_cu": 2.03, "with_screen_address_and_mfma_cycles": 4.0,
+                             "note": "tools/ubench_lds_gather.hip, round 3 (profiles/r03a_ubench_lds_gather.txt; whole-launch "
+                                     "timing at a measured 2.3-2.4 GHz - the round-2 table timed wave 0 only and was wrong): "
+                                     "random conflict-free ds_read_b64 gathers with precomputed addresses run at 2.03 "
+                                     "cycles per wave-instruction per CU = 252 B/clk = the nominal roof used in `frac`; with "
+                                     "the screen's two address instructions per gather and its MFMAs the same loop needs "
+                                     "4.0 cycles (VALU + matrix-pipe issue, not the LDS array): the screen is issue-bound"},
                          "hbm_equivalent": {"algorithmic_bytes_per_launch": adc_alg, "achieved_GBs": round(adc_ach, 1),
                                             "note": "N*M code bytes per query (SURVEY 8d) / kernel time: 8 queries share every "
                                                     "code read and tiles are re-read from L2, so this exceeds the HBM peak and is "
                                                     "not a roofline"},
-                         "traffic": pmc_traffic("adc_screen_cf_kernel")},
+                         "traffic": pmc_traffic("adc_screen_cf_kernel"),
+                         "traffic_source": "profiles/pmc_summary.json, not this run"},
         }
 
     if not args.no_adc:
@@ -550,18 +555,14 @@ def main():
                                            "frac": round(2.0 * (1 << 18) * nlist * D / cdt / 1e12 / 157.3, 4)}},
             "roofline": {"kernel": "adc_screen_cf_kernel<96,2,8,IVF> (list-centric: one block per (cell, <= 8 probing queries), "
                                    "conflict-free 8-bit screen + exact rescoring); nprobe < 6 takes the per-query scan",
-                         "bound": "hbm", "achieved": round(nq_batch * rows128 * M3 / t128 / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(nq_batch * rows128 * M3 / t128 / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "nprobe = 128: rows probed x M code bytes per query / whole-search time (task list, LUT, "
-                                 "sample, byte tables, screen, rescoring, sort); up to 8 queries share every code read, so "
-                                 "like the flat ADC figure this is an equivalent rate, not HBM traffic",
-                         "lds_gather": {"screen_kernel_ms": round(ivf_scan_ms, 3), "achieved": round(ivf_gather, 1),
-                                        "measured_gather_roof": round(512 / 2.2 * 256, 1), "unit": "GB/s",
-                                        "frac": round(ivf_gather / (512 / 2.2 * 256), 4),
-                                        "note": "the same gathers as the flat screen (one table byte per row, sub-quantiser "
-                                                "and query) against the roof of tools/ubench_lds_gather.hip: an IVF task "
-                                                "is one cell x <= 8 queries, ~7 us of gathers behind two table fills of "
-                                                "96 KiB each, so the screen is fill- and latency-bound, not gather-bound"}}}
+                         "bound": "lds-gather", "achieved": round(ivf_gather, 1), "peak": round(256 * 256 * 2.4, 1),
+                         "unit": "GB/s", "frac": round(ivf_gather / (256 * 256 * 2.4), 4),
+                         "screen_kernel_ms": round(ivf_scan_ms, 3), "nprobe": 128,
+                         "note": "nprobe = 128, the screen kernel alone (HIP events): one table byte per (probed row, "
+                                 "sub-quantiser, query) - an 8-byte entry per task of 8 queries - against the nominal "
+                                 "conflict-free ds_read_b64 rate (256 CUs x 256 B/clk x 2.4 GHz).  A task is one cell x <= 8 queries: ~7 us of gathers "
+                                 "behind two table fills of 96 KiB each - fill- and latency-bound, not gather-bound",
+                         "whole_search_equivalent_code_GBs": round(nq_batch * rows128 * M3 / t128 / 1e9, 1)}}
         del ivf, flat3
         torch.cuda.empty_cache()
 
@@ -594,7 +595,9 @@ def main():
             "roofline": {"kernel": "assign_mfma_kernel<16> + assign_redo_kernel<16>", "bound": "hbm",
                          "achieved": round(nb * bytes_per_vec / (ib["mfma"][1] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(nb * bytes_per_vec / (ib["mfma"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("assign_mfma_kernel"), "algorithmic_bytes_per_launch": nb * bytes_per_vec,
+                         "traffic": pmc_traffic("assign_mfma_kernel"),
+                         "traffic_source": "profiles/pmc_summary.json, not this run",
+                         "algorithmic_bytes_per_launch": nb * bytes_per_vec,
                          "note": "far from the HBM roof by construction: 256 candidate distances per (row, sub-quantiser), "
                                  "2.25 VALU instructions each in the pair-folded min/second-min epilogue, the bf16 MFMAs "
                                  "underneath; after round 2 neither pipe is saturated (VALU ~64 %, matrix pipe ~37 %, waves "
@@ -634,6 +637,43 @@ def main():
         procrustes_rotation(Pm)
         torch.cuda.synchronize()
         t_polar = time.perf_counter() - t0
+
+        # what one OPQ round is made of (HIP-event time of each part, device-side only) next to the round as it runs
+        def ev_ms(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        codes_w = ops.assign_nearest(xr, Cw, torch.uint8)
+        xrec_w = ops.decode_raw(codes_w, Cw)
+        Pw = (xt.T @ xrec_w).double()
+
+        def lloyd():
+            cw = ops.assign_nearest(xr, Cw, torch.uint8)
+            sw, nw = ops.kmeans_stats(xr, cw)
+            ops.kmeans_update_(sw, nw, Cw.clone())
+        parts = {
+            "rotate_gemm_ms": ev_ms(lambda: (xt @ Rw).contiguous()),
+            "lloyd_iteration_ms": ev_ms(lloyd),
+            "assign_nearest_ms": ev_ms(lambda: ops.assign_nearest(xr, Cw, torch.uint8)),
+            "decode_ms": ev_ms(lambda: ops.decode_raw(codes_w, Cw)),
+            "xT_xrec_gemm_fp64cast_ms": ev_ms(lambda: (xt.T @ xrec_w).double()),
+            "procrustes_ms": ev_ms(lambda: procrustes_rotation(Pw), reps=3),
+        }
+        parts = {kk: round(v, 3) for kk, v in parts.items()}
+        device_sum = (parts["rotate_gemm_ms"] + 5 * parts["lloyd_iteration_ms"] + parts["assign_nearest_ms"] + parts["decode_ms"]
+                      + parts["xT_xrec_gemm_fp64cast_ms"] + parts["procrustes_ms"])
+        parts["device_sum_per_round_ms"] = round(device_sum, 3)      # 4 Lloyd iterations + train_pq's final assignment + mse
+        parts["measured_per_round_ms"] = round(t_opq / 50 * 1e3, 3)
+        parts["note"] = ("a round = rotate, 4 Lloyd iterations (assignment, statistics, update, empty-cluster rule: no host "
+                         "synchronisation), error, assignment, decode, x^T x_rec, Procrustes (Newton-Schulz; its convergence "
+                         "reads are the round's only host synchronisations); round 0 runs 40 Lloyd iterations")
+        del codes_w, xrec_w, Pw
         out["opq_pq_warmup"] = {
             "metric": "opq_pq_training_seconds", "value": round(t_opq + t_pq2, 3), "unit": "s", "higher_is_better": False,
             "train_rows": MAX_TRAIN_POINTS, "M": M,
@@ -643,6 +683,7 @@ def main():
             "mse_pq_without_rotation": round(mse_pq, 5), "mse_after_opq": round(mse_opq, 5),
             "mse_opq_rounds_first_last": [round(hist[0], 5), round(hist[-1], 5)],
             "rotation_orthogonality_error": float((Rw @ Rw.T - torch.eye(D, device=dev)).abs().max()),
+            "opq_round_breakdown": parts,
             "note": "the whole training of run_warmup.py:92-113 at Faiss-default sizes (65 536 training rows; 50 OPQ rounds "
                     "with 40 + 49 x 4 Lloyd iterations, then 25 Lloyd iterations on the rotated rows), nothing projected: "
                     "assignment / statistics / update are the HIP kernels, the 768-wide GEMMs are library calls, the "
@@ -694,19 +735,34 @@ def main():
                 "sample": f"{Bs} rows, exact fp32 nearest codes, oracle/pq_oracle.c ({nall:.2f} s); one thread: "
                           f"{512 / n1:.0f} vectors/s (512 rows, {n1:.2f} s)"}
             out["index_build"]["speedup_vs_cpu_baseline"] = round(out["index_build"]["value"] / (Bs / nall), 1)
-        xg, cg = torch.from_numpy(xs).to(dev), torch.from_numpy(near_c).to(dev)
-        ops.kmeans_stats(xg, cg)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
+        # GPU side at the sizes the path runs it on: the 65 536 training rows of the warm-up (run_warmup.py:92-113) and a
+        # 2^20-row corpus chunk (corpus-sharded k-means, BASELINE configs[2]); the CPU port beside it on the 16 384-row sample
+        ks_sizes = {}
+        gk = torch.Generator(device=dev).manual_seed(20228)
+        for rows in (1 << 16, 1 << 20):
+            xg = torch.randn((rows, D), device=dev, generator=gk)
+            cg = torch.randint(0, 256, (rows, M), dtype=torch.uint8, device=dev, generator=gk)
             ops.kmeans_stats(xg, cg)
-        torch.cuda.synchronize()
-        kg = (time.perf_counter() - t0) / 10
-        out["kmeans_stats"] = {"metric": "kmeans_sufficient_statistics_vectors_per_sec", "value": round(Bs / kg, 1),
-                               "unit": "vectors/s", "rows": Bs, "ms": round(kg * 1e3, 3),
-                               "roofline": {"bound": "hbm", "achieved": round(Bs * (D * 4 + M) / kg / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                            "unit": "GB/s", "frac": round(Bs * (D * 4 + M) / kg / 1e9 / HBM_PEAK_GBS, 4),
-                                            "note": "4 D + M bytes per vector (SURVEY 8d); small batch, launch-bound"},
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.kmeans_stats(xg, cg)
+            e1.record()
+            torch.cuda.synchronize()
+            kg = e0.elapsed_time(e1) / 10 * 1e-3
+            ks_sizes[rows] = {"rows": rows, "ms": round(kg * 1e3, 4), "value": round(rows / kg, 1), "unit": "vectors/s",
+                              "roofline": {"kernel": "kmeans_stats_fx_kernel (exact fixed-point split, 64-bit integer atomics)",
+                                           "bound": "hbm", "achieved": round(rows * (D * 4 + M) / kg / 1e9, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(rows * (D * 4 + M) / kg / 1e9 / HBM_PEAK_GBS, 4),
+                                           "algorithmic_bytes_per_launch": rows * (D * 4 + M)}}
+            del xg, cg
+        big = ks_sizes[1 << 20]
+        out["kmeans_stats"] = {"metric": "kmeans_sufficient_statistics_vectors_per_sec", "value": big["value"],
+                               "unit": "vectors/s", "rows": big["rows"], "ms": big["ms"], "roofline": big["roofline"],
+                               "warmup_size_65536": ks_sizes[1 << 16],
+                               "note": "4 D + M bytes per vector (SURVEY 8d), HIP events around 10 launches",
                                "cpu_baseline": {"value": round(Bs / ks, 1), "unit": "vectors/s", "cores": 1, "kind": "port",
                                                 "sample": f"{Bs} rows, numpy restatement oracle/pq_oracle.py ({ks:.2f} s)"}}
         if not args.no_adc:
@@ -715,9 +771,15 @@ def main():
             sl = index_codes.cpu().numpy()
             qc = q_all[:nq_c].cpu().numpy()
             t0 = time.perf_counter()
-            c_oracle.adc_search(sl, cent, qc, k)
+            cpu_s, cpu_i = c_oracle.adc_search(sl, cent, qc, k)
             adt_c = time.perf_counter() - t0
             qps_c = nq_c / adt_c
+            # the same queries on the GPU: ids and score bits of the CPU restatement over the WHOLE 8.84 M-row index
+            gpu_s, gpu_i = ops.adc_search(index_codes, C, q_all[:nq_c], k)
+            out["adc"]["gpu_ids_identical"] = bool(np.array_equal(gpu_i.cpu().numpy(), cpu_i))
+            out["adc"]["gpu_score_bits_identical"] = bool(np.array_equal(gpu_s.cpu().numpy().view(np.uint32), cpu_s.view(np.uint32)))
+            out["adc"]["checked_against_cpu_port"] = f"{nq_c} queries x top-{k} over the whole index"
+            del gpu_s, gpu_i
             out["adc"]["cpu_baseline"] = {
                 "value": round(qps_c, 2), "unit": "queries/s", "cores": cores, "kind": "port",
                 "sample": f"{nq_c} queries over the whole {N_CORPUS}-row index ({adt_c:.1f} s); oracle/pq_oracle.c "

@@ -237,6 +237,13 @@ int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const uint8_t* c
                     int D, int M, int K, double* sums, int64_t* counts, rc_stream_t stream);
 int rc_kmeans_update(rc_handle_t h, const double* sums, const int64_t* counts, float* C, int M,
                      int K, int dsub, rc_stream_t stream);
+/* Empty clusters after an update, by Faiss's published rule (Clustering.cpp `split_clusters`, run by `index.train`,
+ * train/run_warmup.py:113): per sub-quantiser a std::mt19937(1234) walk picks a donor with probability proportional to
+ * its size, the empty centroid becomes the donor's scaled by (1 +- 1/1024), the donor the opposite.  On the device (no host
+ * synchronisation inside a Lloyd iteration).  counts: [M,K] int64 of the update just made; nsplit: optional device int,
+ * incremented by the number of splits. */
+int rc_kmeans_split_empty(rc_handle_t h, float* C, const int64_t* counts, int M, int K, int dsub, int* nsplit,
+                          rc_stream_t stream);
 
 /* ------------------------------------------------------------------ a-9 … a-11
  * PQ asymmetric-distance (inner product) top-k over raw codes — what `index.search` of the

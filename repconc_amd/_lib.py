@@ -62,6 +62,7 @@ PROTOTYPES = {
     "rc_code_hist": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
     "rc_kmeans_stats": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "rc_kmeans_update": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "rc_kmeans_split_empty": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "rc_adc_search_ws_bytes": (_sz, [_i64, _i, _i, _i, _i]),
     "rc_adc_search": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_adc_scan_image_bytes": (_sz, [_i64, _i]),

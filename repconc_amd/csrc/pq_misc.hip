@@ -604,3 +604,96 @@ extern "C" int rc_kmeans_update(rc_handle_t h, const double* sums, const int64_t
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
+
+// ------------------------------------------------------------------------------------------ empty clusters
+// Faiss 1.7.x Clustering.cpp `split_clusters` (what `index.train`, train/run_warmup.py:113, does after every centroid
+// update), restated from the published source: per clustering (= per sub-quantiser) a std::mt19937 seeded with 1234
+// drives a cyclic walk cj = 0, 1, ... that accepts cluster cj as the donor of an empty cluster ci with probability
+// (size_cj - 1) / (n - k); centroid ci <- centroid cj, then ci *= 1 +- 1/1024 and cj *= 1 -+ 1/1024 alternating over the
+// components; the donor's (float) size is halved for the following draws.  On the device so that a Lloyd iteration has no
+// host synchronisation: one block per sub-quantiser, all threads look for an empty cluster, thread 0 makes the
+// (sequential, rare) walk with its own MT19937 in LDS.
+namespace {
+struct mt19937_lds {
+    unsigned* mt;
+    int idx;
+    __device__ void seed(unsigned s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned)i;
+        idx = 624;
+    }
+    __device__ unsigned next() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; ++i) {
+                const unsigned y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        unsigned y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+};
+}  // namespace
+
+__global__ __launch_bounds__(RC_K) void kmeans_split_empty_kernel(float* __restrict__ C, const long long* __restrict__ counts,
+                                                                  int dsub, int* __restrict__ nsplit) {
+    __shared__ unsigned s_mt[624];
+    __shared__ float s_h[RC_K];
+    __shared__ int s_any;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const long long c = counts[(size_t)m * RC_K + tid];
+    s_h[tid] = (float)c;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    if (c == 0) s_any = 1;
+    __syncthreads();
+    if (!s_any || tid != 0) return;
+    long long n = 0;
+    float hmax = 0.f;
+    for (int k = 0; k < RC_K; ++k) { n += counts[(size_t)m * RC_K + k]; hmax = fmaxf(hmax, s_h[k]); }
+    const double denom = (double)(float)(n - RC_K);
+    mt19937_lds rng{s_mt, 624};
+    rng.seed(1234u);
+    float* Cm = C + (size_t)m * RC_K * dsub;
+    const float up = 1.0f + 1.0f / 1024.0f, dn = 1.0f - 1.0f / 1024.0f;
+    int splits = 0;
+    for (int ci = 0; ci < RC_K; ++ci) {
+        if (s_h[ci] != 0.f) continue;
+        int cj = 0;
+        if (!(denom > 0.0) || hmax <= 1.f) {                    // Faiss would never accept: take the biggest cluster
+            for (int k = 1; k < RC_K; ++k) cj = s_h[k] > s_h[cj] ? k : cj;
+        } else {
+            for (int draws = 0; draws < 10000000; ++draws) {
+                const float p = (float)(((double)s_h[cj] - 1.0) / denom);
+                const float r = (float)rng.next() / 4294967296.0f;     // float(mt()) / float(mt.max()): float(2^32 - 1) = 2^32
+                if (r < p) break;
+                cj = (cj + 1) % RC_K;
+            }
+        }
+        for (int j = 0; j < dsub; ++j) {
+            const float v = Cm[(size_t)cj * dsub + j];
+            Cm[(size_t)ci * dsub + j] = v * ((j & 1) ? dn : up);
+            Cm[(size_t)cj * dsub + j] = v * ((j & 1) ? up : dn);
+        }
+        s_h[ci] = s_h[cj] / 2.0f;
+        s_h[cj] = s_h[cj] - s_h[ci];
+        ++splits;
+    }
+    if (nsplit && splits) atomicAdd(nsplit, splits);
+}
+
+extern "C" int rc_kmeans_split_empty(rc_handle_t h, float* C, const int64_t* counts, int M, int K, int dsub, int* nsplit,
+                                     rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !C || !counts || M <= 0 || dsub <= 0) return RC_EINVAL;
+    if (K != RC_K) return RC_ESHAPE;
+    hipLaunchKernelGGL(kmeans_split_empty_kernel, dim3((unsigned)M), dim3(RC_K), 0, (hipStream_t)stream, C,
+                       reinterpret_cast<const long long*>(counts), dsub, nsplit);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}

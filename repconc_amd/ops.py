@@ -455,6 +455,17 @@ def kmeans_update_(sums: torch.Tensor, counts: torch.Tensor, centroids: torch.Te
     return centroids
 
 
+def kmeans_split_empty_(centroids: torch.Tensor, counts: torch.Tensor, nsplit: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Faiss's empty-cluster rule (`split_clusters`) applied in place on the device; see include/repconc_hip.h."""
+    _need_cuda(centroids, counts, nsplit)
+    if centroids.dtype != torch.float32 or not centroids.is_contiguous() or counts.dtype != torch.int64 or not counts.is_contiguous():
+        raise ValueError("centroids must be contiguous fp32 [M,256,dsub], counts contiguous int64 [M,256]")
+    M, Kc, dsub = centroids.shape
+    lib, h, s, _ = _ctx(centroids)
+    _lib.check(lib.rc_kmeans_split_empty(h, _p(centroids), _p(counts), M, Kc, dsub, _p(nsplit), s), "rc_kmeans_split_empty", h)
+    return centroids
+
+
 # --------------------------------------------------------------------------- ADC search
 def adc_lut(centroids: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
     _need_cuda(centroids, q)

@@ -100,49 +100,12 @@ def broadcast_from_rank0_(t: torch.Tensor, group=None) -> torch.Tensor:
 
 def _reseed_empty(C: torch.Tensor, counts: torch.Tensor):
     """Empty clusters after an update, by Faiss's published rule (`split_clusters`, Clustering.cpp of 1.7.x — what
-    `index.train` at train/run_warmup.py:113 runs): per sub-quantiser a std::mt19937 seeded with 1234 (numpy's legacy
-    RandomState is the same generator) drives a cyclic walk over the clusters that accepts cluster j as the donor with
-    probability (size_j - 1) / (n - 256); the empty cluster gets the donor's centroid scaled by (1 +- 1/1024), alternating
-    over the components, the donor the opposite factors, and the donor's size is halved for the following draws.
-    Empty clusters are rare: the walk runs on the host on the [M, 256] counts and touches only the rows concerned; every
-    rank holds the same counts, hence makes the same splits."""
-    if not bool((counts == 0).any()):
-        return 0
-    M, K, dsub = C.shape
-    f32 = np.float32
-    eps = f32(1.0 / 1024)
-    cnt = counts.cpu().numpy()
-    Ch = C.detach().cpu().numpy().copy()
-    even = np.arange(dsub) % 2 == 0
-    nsplit = 0
-    for m in range(M):
-        h = cnt[m].astype(f32)
-        if not (h == 0).any():
-            continue
-        denom = np.float64(f32(int(cnt[m].sum()) - K))
-        draw = np.random.RandomState(1234)._bit_generator.random_raw
-        for ci in range(K):
-            if h[ci] != 0:
-                continue
-            cj, draws = 0, 0
-            if denom <= 0 or h.max() <= 1:                   # nothing to split by size: the biggest cluster
-                cj = int(np.argmax(h))
-            else:
-                while True:
-                    p = f32((np.float64(h[cj]) - 1.0) / denom)
-                    r = f32(draw()) / f32(4294967295.0)
-                    draws += 1
-                    if r < p or draws > 10_000_000:
-                        break
-                    cj = (cj + 1) % K
-            src = Ch[m, cj].copy()
-            Ch[m, ci] = np.where(even, src * (f32(1) + eps), src * (f32(1) - eps)).astype(f32)
-            Ch[m, cj] = np.where(even, src * (f32(1) - eps), src * (f32(1) + eps)).astype(f32)
-            h[ci] = h[cj] / f32(2)
-            h[cj] = h[cj] - h[ci]
-            nsplit += 1
-    C.copy_(torch.from_numpy(Ch).to(C.device))
-    return nsplit
+    `index.train` at train/run_warmup.py:113 runs): per sub-quantiser a std::mt19937 seeded with 1234 drives a cyclic walk
+    over the clusters that accepts cluster j as the donor with probability (size_j - 1) / (n - 256); the empty cluster gets
+    the donor's centroid scaled by (1 +- 1/1024), alternating over the components, the donor the opposite factors, and the
+    donor's size is halved for the following draws.  One kernel on the device (rc_kmeans_split_empty): a Lloyd iteration has
+    no host synchronisation; every rank holds the same counts, hence makes the same splits."""
+    ops.kmeans_split_empty_(C, counts.contiguous())
 
 
 def procrustes_rotation(P: torch.Tensor, tol: float = 1e-13, max_iter: int = 160) -> torch.Tensor:
@@ -163,27 +126,36 @@ def procrustes_rotation(P: torch.Tensor, tol: float = 1e-13, max_iter: int = 160
         v = P.T @ (P @ v)
         v = v / torch.linalg.vector_norm(v).clamp_min(1e-300)
     scale = 1.05 * torch.linalg.vector_norm(P @ v)
-    ok = bool(torch.isfinite(scale)) and float(scale) > 0.0
-    if ok:
-        X = P / scale
-        eye = torch.eye(n, dtype=P.dtype, device=P.device)
-        ok = False
-        for it in range(max_iter):
-            G = X.T @ X
-            if it % 8 == 7 and float((G - eye).abs().max()) < tol ** 0.5:   # quadratic: the next step brings it below tol
+    # No read of `scale` here: a zero / non-finite scale makes X non-finite, which the convergence reads below report.
+    X = P / scale
+    eye = torch.eye(n, dtype=P.dtype, device=P.device)
+    ok = False
+    first_check = 47                                            # OPQ's matrices need 45 - 60 steps: no reads before that
+    for it in range(max_iter):
+        G = X.T @ X
+        if it >= first_check and (it - first_check) % 8 == 0:
+            err = float((G - eye).abs().max())                  # one host synchronisation
+            if not (err == err) or err == float("inf"):
+                break                                           # singular / non-finite input: SVD below
+            if err < tol ** 0.5:                                # quadratic: two more steps bring it far below tol
+                X = 1.5 * X - 0.5 * (X @ G)
+                G = X.T @ X
                 X = 1.5 * X - 0.5 * (X @ G)
                 ok = True
                 break
-            X = 1.5 * X - 0.5 * (X @ G)
-        ok = ok and float((X.T @ X - eye).abs().max()) < 1e-9
+        X = 1.5 * X - 0.5 * (X @ G)
+    if ok:
+        ok = float((X.T @ X - eye).abs().max()) < 1e-9
         if ok:
             return X
     U, _, Vh = torch.linalg.svd(P)
     return U @ Vh
 
 
-def train_pq(x: torch.Tensor, M: int, n_iter: int, centroids: Optional[torch.Tensor] = None, seed: int = SEED):
-    """Lloyd k-means of the M sub-quantisers on x [n, D] (device).  Returns (centroids [M,256,dsub], mse)."""
+def train_pq(x: torch.Tensor, M: int, n_iter: int, centroids: Optional[torch.Tensor] = None, seed: int = SEED,
+             mse_on_device: bool = False):
+    """Lloyd k-means of the M sub-quantisers on x [n, D] (device).  Returns (centroids [M,256,dsub], mse); with
+    `mse_on_device` the mse stays a 0-dim device tensor and the whole call enqueues without a host synchronisation."""
     n, D = x.shape
     dsub = D // M
     if centroids is None:                                   # random-sample initialisation
@@ -201,7 +173,8 @@ def train_pq(x: torch.Tensor, M: int, n_iter: int, centroids: Optional[torch.Ten
     err = torch.stack([((ops.decode_raw(codes, C) - x) ** 2).sum().double(),
                        torch.tensor(float(n), dtype=torch.float64, device=x.device)])
     rank_ordered_sum_(err)                                  # MSE over the rows of every rank
-    return C, float(err[0] / err[1])
+    mse = err[0] / err[1]
+    return C, (mse if mse_on_device else float(mse))
 
 
 def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, n_pq: int = 4, seed: int = SEED,
@@ -215,18 +188,24 @@ def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, 
         R0 = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]        # same seed on every rank
     R = R0.float().to(x.device).contiguous()
     C = None
+    mses = []
     for it in range(n_outer):
         xr = (x @ R).contiguous()
-        C, mse = train_pq(xr, M, n_pq_first if it == 0 else n_pq, centroids=C, seed=seed)
-        if history is not None:
-            history.append(mse)
+        # the round's only host synchronisations are the convergence reads of the Procrustes iteration: the Lloyd
+        # iterations (assignment, statistics, update, empty-cluster rule) and the error enqueue without one
+        C, mse = train_pq(xr, M, n_pq_first if it == 0 else n_pq, centroids=C, seed=seed, mse_on_device=True)
+        mses.append(mse)
         codes = ops.assign_nearest(xr, C, torch.uint8)
         xrec = ops.decode_raw(codes, C)
         P = (x.T @ xrec).double()
         rank_ordered_sum_(P)                                    # Procrustes matrix over the rows of every rank
         R = procrustes_rotation(P).float().contiguous()        # fp64: keeps R orthogonal to ~1e-7 after the cast
+    mses = [float(v) for v in torch.stack(mses).cpu()] if mses else []
+    if history is not None:
+        history.extend(mses)
+    for it, v in enumerate(mses):
         if it % 10 == 0 or it == n_outer - 1:
-            logger.info("OPQ iteration %d: reconstruction mse %.5f", it, mse)
+            logger.info("OPQ iteration %d: reconstruction mse %.5f", it, v)
     return R
 
 

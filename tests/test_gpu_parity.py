@@ -1862,7 +1862,11 @@ def test_empty_cluster_rule_is_the_published_faiss_rule_on_both_sides():
     want = C.copy()
     n_want = pq_oracle.reseed_empty(want, cnt)
     Ct, ct = _t(C).clone(), _t(cnt)
-    n_got = _reseed_empty(Ct, ct)
-    assert n_got == n_want == 3 + 1 + 1 + 8
+    _reseed_empty(Ct, ct)                                   # one kernel, MT19937 on the device
+    assert n_want == 3 + 1 + 1 + 8
+    from repconc_amd import ops
+    ns = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.kmeans_split_empty_(_t(C).clone(), ct, ns)
+    assert int(ns.item()) == n_want
     assert np.array_equal(Ct.cpu().numpy().view(np.uint32), want.view(np.uint32))
     assert np.array_equal(want[[1, 3]], C[[1, 3]])
