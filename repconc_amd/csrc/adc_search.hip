@@ -967,6 +967,7 @@ __global__ __launch_bounds__(RC_K) void adc_qbyte_write_kernel(const float* __re
 }
 
 typedef int adc_i32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned adc_u32x2v __attribute__((ext_vector_type(2)));
 
 // grid (groups of 8 queries, row tiles of adc_cf_tile_rows(M) rows), XCD-remapped like the other screens.
 // A wave owns R chunks of 16 rows per round; lanes (r = l & 15, g = l >> 4).
@@ -983,12 +984,29 @@ struct adc_ivf_tasks {
     const int* ntasks;           // device-side task count when the list is padded (rc_ivf_search_probes), else NULL
 };
 
-template <int M, int NP, int R, bool IVF = false, int THREADS = ADC_THREADS>
+// Two-pass form of a two-phase screen (M = 96; round 3).  The one-launch form keeps a round's accumulators in registers
+// across the table swap and pays two block-wide barriers + two synchronous 128 KiB refills per 2048-row round: 27 ms per
+// 1200 queries against 2 x 10 ms of gathers.  PART = 1 / 2 run ONE phase each over the whole index with the tables resident
+// (no barrier, no refill — the M = 48 kernel's schedule): pass 1 writes every (row, query) partial sum as an int16
+// (|sum of 48 biased bytes| <= 6144) to HBM, pass 2 adds it to its own sum before the threshold test.  The partial sums are
+// a pure stream (written once, read once, non-temporal): 2 x 2 bytes per (row, query) = 42 GB per 1200-query batch over
+// ~20 ms, ~2 TB/s of an otherwise idle HBM.  Layout: [group][chunk of 16 rows][lane quarter g][column r < 8][4 rows] int16,
+// i.e. the accumulator registers as they are: 512 contiguous bytes per wave and chunk, 8-byte stores.
+struct adc_part_args {
+    short* buf;            // partial sums of this launch's groups
+    unsigned group0;       // first 8-query group of this launch (tables / thresholds are indexed by group0 + block group)
+    unsigned nchunks;      // 16-row chunks per group in `buf` (whole tiles)
+};
+
+template <int M, int NP, int R, bool IVF = false, int THREADS = ADC_THREADS, int PART = 0>
 __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t* __restrict__ image, int64_t N,
                                                                     const uint8_t* __restrict__ qlut,
                                                                     const int* __restrict__ tint, int nq,
                                                                     unsigned* __restrict__ id_count,
-                                                                    unsigned* __restrict__ ids, adc_ivf_tasks T) {
+                                                                    unsigned* __restrict__ ids, adc_ivf_tasks T,
+                                                                    adc_part_args PA) {
+    static_assert(PART == 0 || (NP == 2 && !IVF), "two-pass form: flat search with two table phases");
+    constexpr int NPE = PART ? 1 : NP;                     // table phases visited per round by THIS launch
     constexpr int PM = M / NP;
     using L = adc_cf<PM>;
     constexpr int STEPS = L::STEPS, NW = STEPS * ADC_IMG_ES / 4;   // code dwords per lane per chunk and phase
@@ -999,6 +1017,8 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     const int tid = threadIdx.x;
     unsigned bgroup = 0, btile = 0;
     if constexpr (!IVF) adc_xcd_remap(bgroup, btile);
+    const unsigned lgroup = bgroup;                          // group inside this launch (partial-sum buffer)
+    if constexpr (PART != 0) bgroup += PA.group0;
     const int q0 = (int)bgroup * 8;
     const uint8_t* qsrc = qlut + (size_t)bgroup * NP * L::TABLE_BYTES;
     // IVF: blocks are dealt to the XCDs round-robin; give every XCD a CONTIGUOUS range of the (cell-ordered) task list so
@@ -1119,12 +1139,21 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     // the epilogue, 24 bytes of scratch per lane, and the M = 96 screen got 3 % slower).  All row arithmetic is 32-bit and relative to the tile (<= 32768 rows x M bytes).
     const unsigned nrows = (unsigned)(t1 - t0);
     const int nrounds = (int)((nrows + ROUND - 1) / ROUND);
-    const int nsteps = nrounds * NP;
+    const int nsteps = nrounds * NPE;
     const uint8_t* __restrict__ tile = image + t0 * M * ADC_IMG_ES;
-    auto phase_of = [&](int it) { const int rd = it / NP, i = it % NP; return (rd & 1) ? NP - 1 - i : i; };
+    auto phase_of = [&](int it) {
+        if constexpr (PART != 0) return PART - 1;
+        const int rd = it / NP, i = it % NP;
+        return (rd & 1) ? NP - 1 - i : i;
+    };
+    // partial sums of chunk c of the round that starts at tile row r0: 8 bytes per lane with r < 8
+    auto part_ptr = [&](unsigned r0, int c) {
+        const size_t chunk = (size_t)((t0 + r0) >> 4) + (size_t)c;
+        return reinterpret_cast<adc_u32x2v*>(PA.buf + (((size_t)lgroup * PA.nchunks + chunk) * 32 + (size_t)(g * 8 + (r & 7))) * 4);
+    };
     const unsigned lane_off = (unsigned)(g * STEPS * ADC_IMG_ES), lane_row = (unsigned)(wv * R * 16 + r);
     auto load_step = [&](int it, unsigned (&dst)[R][NW]) {
-        const unsigned base = (unsigned)(it / NP) * ROUND + lane_row;
+        const unsigned base = (unsigned)(it / NPE) * ROUND + lane_row;
         const unsigned col = (unsigned)phase_of(it) * (PM * ADC_IMG_ES) + lane_off;
 #pragma unroll
         for (int c = 0; c < R; ++c) {
@@ -1137,14 +1166,21 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     };
     // ping-pong code buffers only where the registers allow: the IVF variant at 48 sub-quantisers per phase (table transpose +
     // aggregated survivor slots on top of the 12-step gather pipeline) spilled 100 bytes per lane with them
-    constexpr bool PREFETCH = (NP == 1) && !(IVF && PM == 48);
+    constexpr bool PREFETCH = (NPE == 1) && !(IVF && PM == 48);
     adc_i32x4v acc[R];
+    adc_u32x2v part[PART == 2 ? R : 1];                     // pass 2: the round's partial sums, requested at its start
     // one step: gather + fold the R chunks of step `it` from the codes in `w`; the next step's codes go to `wn`
     auto run_step = [&](int it, unsigned (&w)[R][NW], unsigned (&wn)[PREFETCH ? R : 1][NW], int& in_lds) {
         const int phase = phase_of(it);
-        if (it % NP == 0) {
+        if (it % NPE == 0) {
 #pragma unroll
             for (int c = 0; c < R; ++c) acc[c] = adc_i32x4v{0, 0, 0, 0};
+            if constexpr (PART == 2) {
+                const unsigned r0p = (unsigned)(it / NPE) * ROUND + (unsigned)(wv * R * 16);
+#pragma unroll
+                for (int c = 0; c < R; ++c)
+                    part[c] = (r < 8) ? __builtin_nontemporal_load(part_ptr(r0p, c)) : adc_u32x2v{0u, 0u};
+            }
         }
         if (in_lds != phase) {
             if (in_lds >= 0) __syncthreads();                 // every wave is done gathering from the old tables
@@ -1197,7 +1233,28 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             if (c + 2 < R) gather(c + 2, ea);
             if (c + 1 < R) fold(c + 1, eb);
         }
-        if (it % NP == NP - 1) {
+        if constexpr (PART == 1) {
+            // pass 1: the accumulators go to HBM as they are (int16 pairs), nothing is tested
+            const unsigned r0p = (unsigned)(it / NPE) * ROUND + (unsigned)(wv * R * 16);
+            if (r < 8) {
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const adc_u32x2v v = {__builtin_amdgcn_perm((unsigned)acc[c][1], (unsigned)acc[c][0], 0x05040100u),
+                                          __builtin_amdgcn_perm((unsigned)acc[c][3], (unsigned)acc[c][2], 0x05040100u)};
+                    __builtin_nontemporal_store(v, part_ptr(r0p, c));
+                }
+            }
+        }
+        if constexpr (PART == 2) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                acc[c][0] += ((int)(part[c].x << 16)) >> 16;
+                acc[c][1] += ((int)part[c].x) >> 16;
+                acc[c][2] += ((int)(part[c].y << 16)) >> 16;
+                acc[c][3] += ((int)part[c].y) >> 16;
+            }
+        }
+        if (PART != 1 && it % NPE == NPE - 1) {
             // survivors are rare (~2e-4 of the (row, query) pairs): one max over the round's accumulators decides
             int top = INT_MIN;
 #pragma unroll
@@ -1206,7 +1263,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
                 // Flat search: survivors are rare (~2e-4), one atomic each.  IVF: a query keeps a few per cent of the rows it
                 // probes, and one atomic per survivor on 1200 counters was half of the screen's time (nprobe 32) - there the
                 // four lanes (r, g = 0..3) of a query reserve their slots with ONE atomic per wave and round.
-                const unsigned r0 = (unsigned)(it / NP) * ROUND + (unsigned)(wv * R * 16);
+                const unsigned r0 = (unsigned)(it / NPE) * ROUND + (unsigned)(wv * R * 16);
                 if constexpr (!IVF) {
 #pragma unroll
                     for (int c = 0; c < R; ++c) {
@@ -1327,9 +1384,14 @@ __global__ __launch_bounds__(ADC_RESCORE_THREADS) void adc_rescore_kernel(const 
 
 // ------------------------------------------------------------------------------------------ host
 struct adc_ws_layout {
-    size_t lut, sample, thr, cnt, cand, qlut, tint, qstat, idcnt, ids, image, total;
+    size_t lut, sample, thr, cnt, cand, qlut, tint, qstat, idcnt, ids, image, partial, partial_bytes, total;
     int64_t S;
 };
+// partial sums of the two-pass M = 96 screen: 256 bytes per (group of 8 queries, chunk of 16 rows); at most ADC_PART_CAP
+// bytes are kept, the groups are processed in as many launches as that takes
+#define ADC_PART_CAP (8ull << 30)
+struct adc_part_plan { unsigned nchunks, groups_per_pass; size_t bytes; };
+static adc_part_plan adc_part_plan_for(int64_t N, int M, int nq);
 static int adc_qs_for(int M) { (void)M; return 16; }   // table groups are sized for 16 queries (covers the 8- and 4-query kernels)
 // conflict-free screen (adc_screen_cf_kernel): M = 16, 32, 48, 64 in one table phase, 96 in two
 static bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M == 64 || M == 96; }
@@ -1376,8 +1438,24 @@ static adc_ws_layout adc_layout(int64_t N, int M, int nq, bool own_image = true)
     }
     L.image = o;
     if (own_image && N >= ADC_SCREEN_MIN_N && adc_cf_supported(M)) o += rc_align_up((size_t)N * M * ADC_IMG_ES, 256);
+    L.partial = o;
+    L.partial_bytes = adc_part_plan_for(N, M, nq).bytes;
+    o += rc_align_up(L.partial_bytes, 256);
     L.total = o;
     return L;
+}
+static adc_part_plan adc_part_plan_for(int64_t N, int M, int nq) {
+    adc_part_plan P = {0u, 0u, 0};
+    if (M != 96 || N < ADC_SCREEN_MIN_N || nq <= 0) return P;
+    const int64_t tile = adc_cf_tile_rows(M);
+    P.nchunks = (unsigned)(((N + tile - 1) / tile) * (tile / 16));
+    const size_t per_group = (size_t)P.nchunks * 256;
+    const unsigned groups = (unsigned)((nq + 7) / 8);
+    size_t gp = ADC_PART_CAP / per_group;
+    if (gp < 1) gp = 1;
+    P.groups_per_pass = gp < groups ? (unsigned)gp : groups;
+    P.bytes = (size_t)P.groups_per_pass * per_group;
+    return P;
 }
 
 extern "C" size_t rc_adc_search_ws_bytes(int64_t N, int M, int K, int nq, int k) {
@@ -1430,7 +1508,7 @@ static int adc_qt_for(int M) {
 
 struct adc_bufs {
     float* lut; float* sample; float* thr; unsigned* cnt; unsigned long long* cand;
-    uint8_t* qlut; int* tint; unsigned* idcnt; unsigned* ids; float* qstat;
+    uint8_t* qlut; int* tint; unsigned* idcnt; unsigned* ids; float* qstat; short* partial;
 };
 
 template <int M, int QT>
@@ -1484,20 +1562,52 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP;
             constexpr int R = (NP > 1) ? 8 : ((M == 64 || (ADC_IMG_ES == 2 && M == 48)) ? 2 : 4);   // register budget
             constexpr int TH = ADC_THREADS;
-            auto kern = adc_screen_cf_kernel<M, NP, R, false, TH>;
             constexpr int sl = adc_cf<PM>::TABLE_BYTES;
             hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, b.qstat, b.tint);
             RC_LAUNCH_CHECK(h);
             hipLaunchKernelGGL(adc_qlut_cf_write_kernel<PM>, dim3((unsigned)((nq + 7) / 8), RC_K / 64, 4), dim3(64), 0, s, b.lut,
                                (const float*)b.qstat, M, nq, b.qlut);
             RC_LAUNCH_CHECK(h);
-            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
-            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             const unsigned cf_tiles = (unsigned)((N + adc_cf_tile_rows(M) - 1) / adc_cf_tile_rows(M));
-            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 7) / 8), cf_tiles), dim3(TH), sl, s, image, N, b.qlut,
-                               b.tint, nq, b.idcnt, b.ids, adc_ivf_tasks{});
-            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-            RC_LAUNCH_CHECK(h);
+            const unsigned groups = (unsigned)((nq + 7) / 8);
+            bool done = false;
+            if constexpr (NP == 2) {
+                // two passes with resident tables and the partial sums through HBM (see adc_part_args); RC_ADC_TWO_PASS=0
+                // or a workspace without the partial-sum buffer selects the one-launch form
+                const adc_part_plan pp = adc_part_plan_for(N, M, nq);
+                if (b.partial && pp.groups_per_pass > 0 && rc_env_int("RC_ADC_TWO_PASS", 1) != 0) {
+                    // chunks per wave and round: pass 2 carries the round's partial sums besides the M = 48 kernel's registers
+                    // (R = 4: 128 VGPRs + 36 bytes of scratch; R = 2: no spill); the layout of the partial sums does not
+                    // depend on R, so the passes may differ.  RC_ADC_PART_R1 / _R2 = 2 | 4 for A/B runs.
+                    auto k1 = rc_env_int("RC_ADC_PART_R1", 4) == 2 ? adc_screen_cf_kernel<M, NP, 2, false, TH, 1>
+                                                                   : adc_screen_cf_kernel<M, NP, 4, false, TH, 1>;
+                    auto k2 = rc_env_int("RC_ADC_PART_R2", 2) == 4 ? adc_screen_cf_kernel<M, NP, 4, false, TH, 2>
+                                                                   : adc_screen_cf_kernel<M, NP, 2, false, TH, 2>;
+                    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+                    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+                    rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+                    for (unsigned g0 = 0; g0 < groups; g0 += pp.groups_per_pass) {
+                        const unsigned ng = groups - g0 < pp.groups_per_pass ? groups - g0 : pp.groups_per_pass;
+                        const adc_part_args pa = {b.partial, g0, pp.nchunks};
+                        hipLaunchKernelGGL(k1, dim3(ng, cf_tiles), dim3(TH), sl, s, image, N, b.qlut, b.tint, nq, b.idcnt, b.ids,
+                                           adc_ivf_tasks{}, pa);
+                        hipLaunchKernelGGL(k2, dim3(ng, cf_tiles), dim3(TH), sl, s, image, N, b.qlut, b.tint, nq, b.idcnt, b.ids,
+                                           adc_ivf_tasks{}, pa);
+                    }
+                    rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+                    RC_LAUNCH_CHECK(h);
+                    done = true;
+                }
+            }
+            if (!done) {
+                auto kern = adc_screen_cf_kernel<M, NP, R, false, TH>;
+                RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+                rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+                hipLaunchKernelGGL(kern, dim3(groups, cf_tiles), dim3(TH), sl, s, image, N, b.qlut,
+                                   b.tint, nq, b.idcnt, b.ids, adc_ivf_tasks{}, adc_part_args{});
+                rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+                RC_LAUNCH_CHECK(h);
+            }
         }
     } else if constexpr (M % 8 == 0 && M > 64) {
         if (!valu_screen && !one_phase) src = screen(adc_screen_mfma2_kernel<M, 8, 2>, 8, (size_t)(M / 2) * RC_K * 8);
@@ -1615,7 +1725,8 @@ extern "C" int rc_adc_search_q(rc_handle_t h, const uint8_t* codes, const uint8_
     unsigned* cnt = (unsigned*)(w + L.cnt);
     unsigned long long* cand = (unsigned long long*)(w + L.cand);
     const adc_bufs bufs = {lut, (float*)(w + L.sample), (float*)(w + L.thr), cnt, cand, (uint8_t*)(w + L.qlut),
-                           (int*)(w + L.tint), (unsigned*)(w + L.idcnt), (unsigned*)(w + L.ids), (float*)(w + L.qstat)};
+                           (int*)(w + L.tint), (unsigned*)(w + L.idcnt), (unsigned*)(w + L.ids), (float*)(w + L.qstat),
+                           L.partial_bytes ? (short*)(w + L.partial) : nullptr};
     hipStream_t s = (hipStream_t)stream;
     int rc = rc_adc_lut(h, C, q, nq, D, M, K, lut, stream);
     if (rc != RC_OK) return rc;
@@ -1976,7 +2087,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
         TT.qbyte = qbyte;
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         hipLaunchKernelGGL(kern, dim3((unsigned)ntasks), dim3(TH), sl, s, image, N, (const uint8_t*)nullptr,
-                           (const int*)tint, nq, idcnt, ids, TT);
+                           (const int*)tint, nq, idcnt, ids, TT, adc_part_args{});
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         RC_LAUNCH_CHECK(h);
     }

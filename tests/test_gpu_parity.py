@@ -1703,8 +1703,11 @@ def test_deferred_search_and_the_retry_path():
     assert int(tight._status.item()) & 1                                               # too few candidates ...
     ts, ti = tight.result()                                                            # ... repaired by the retry
     assert np.array_equal(ti.cpu().numpy(), want_i)
-    with pytest.raises(Exception):
-        ops.adc_search(_t(codes), _t(C), _t(q), k, sel_slack=-1e6, max_retries=0)
+    # no retries allowed: the queries go straight to the exact path (rc_adc_search_exact) - search never raises
+    zero = ops.adc_search(_t(codes), _t(C), _t(q), k, sel_slack=-1e6, max_retries=0, defer=True)
+    zs, zi = zero.result()
+    assert zero.stats["exact_queries"] == nq and zero.stats["retried_queries"] == 0
+    assert np.array_equal(zi.cpu().numpy(), want_i) and np.array_equal(zs.cpu().numpy().view(np.uint32), want_s.view(np.uint32))
     # batch_search: all batches enqueued, then read == batch by batch
     idx = PQIndex(768, M)
     idx.set_centroids(_t(C))
