@@ -274,6 +274,13 @@ size_t rc_adc_scan_image_bytes(int64_t N, int M);
 int rc_adc_cf_describe(int M, int lane, int step, int* slot, int* m, int* slots_per_code, int* phases);
 int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
                       rc_stream_t stream);
+/* Layouts.  The flat-search image (rc_adc_scan_image; rc_adc_scan_image_bytes(N, M) bytes, what rc_adc_search_img takes) is
+ * row-major [N][M] for the one-phase M (16, 32, 48, 64) and, for M = 96, stored in tiles of 32768 rows, phase-major inside a
+ * tile — [n / T][phase][n % T][48] — so each of the two screen passes streams dense 48-byte rows; the buffer holds whole
+ * tiles, the position of a row does not depend on the buffer's capacity (rows can be appended).  The list-centric IVF search
+ * (rc_ivf_search_lists / _probes) takes the row-major image [N][M] for every M: rc_adc_scan_image_rows. */
+int rc_adc_scan_image_rows(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
+                           rc_stream_t stream);
 size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, int k);
 int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
                       const float* C, int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,

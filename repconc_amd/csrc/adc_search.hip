@@ -832,9 +832,13 @@ __host__ __device__ inline void adc_cf_step(int PM, int s, int r, int g, int& sl
     slot = base + ml + S * (lam / S);                      // S = 16: second copy for lanes 16-31
 }
 
-// image[n][phase][g][s] = codes[n][phase * PM + m(s; n mod 16, g)] for rows n0 <= n < n0 + cnt
+// image[n][phase][g][s] = codes[n][phase * PM + m(s; n mod 16, g)] for rows n0 <= n < n0 + cnt.
+// tile_rows > 0 (flat-search image of a two-phase M, round 3): the image is stored tile by tile, PHASE-MAJOR inside a tile of
+// tile_rows rows — [n / T][phase][n % T][PM] — so that a pass over one phase streams dense PM-byte rows (with 96-byte
+// rows a wave's 16-row code load touches twelve half-used cache lines instead of six full ones).  The layout does not
+// depend on the capacity of the buffer, so rows can still be appended; the buffer holds whole tiles.
 __global__ __launch_bounds__(256) void adc_scan_image_kernel(const uint8_t* __restrict__ codes, int64_t n0, int64_t cnt,
-                                                             int M, int PM, uint8_t* __restrict__ image) {
+                                                             int M, int PM, uint8_t* __restrict__ image, int64_t tile_rows) {
     const int64_t total = cnt * M;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t n = n0 + i / M;
@@ -844,8 +848,10 @@ __global__ __launch_bounds__(256) void adc_scan_image_kernel(const uint8_t* __re
         int slot, m;
         adc_cf_step(PM, st, (int)(n & 15), g, slot, m);
         const uint8_t c = codes[n * M + phase * PM + m];
-        if (ADC_IMG_ES == 2) reinterpret_cast<uint16_t*>(image)[n * M + pos] = c;
-        else image[n * M + pos] = c;
+        const int64_t at = tile_rows > 0 ? ((n / tile_rows) * (M / PM) + phase) * tile_rows * PM + (n % tile_rows) * PM + rem
+                                         : n * M + pos;
+        if (ADC_IMG_ES == 2) reinterpret_cast<uint16_t*>(image)[at] = c;
+        else image[at] = c;
     }
 }
 
@@ -1152,14 +1158,18 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
         return reinterpret_cast<adc_u32x2v*>(PA.buf + (((size_t)lgroup * PA.nchunks + chunk) * 32 + (size_t)(g * 8 + (r & 7))) * 4);
     };
     const unsigned lane_off = (unsigned)(g * STEPS * ADC_IMG_ES), lane_row = (unsigned)(wv * R * 16 + r);
+    // flat search with two table phases: the image is tile-blocked and phase-major (adc_scan_image_kernel), a block's tile
+    // is one storage tile: dense PM-byte rows per phase.  The IVF index keeps the row-major image (cells start anywhere).
+    constexpr bool BLOCKED = !IVF && NP > 1;
+    constexpr unsigned ROWB = (unsigned)((BLOCKED ? PM : M) * ADC_IMG_ES);
     auto load_step = [&](int it, unsigned (&dst)[R][NW]) {
         const unsigned base = (unsigned)(it / NPE) * ROUND + lane_row;
-        const unsigned col = (unsigned)phase_of(it) * (PM * ADC_IMG_ES) + lane_off;
+        const unsigned col = (unsigned)phase_of(it) * (BLOCKED ? (unsigned)(TILE * PM * ADC_IMG_ES) : (unsigned)(PM * ADC_IMG_ES)) + lane_off;
 #pragma unroll
         for (int c = 0; c < R; ++c) {
             unsigned n = base + 16u * c;
             n = n < nrows ? n : nrows - 1u;                    // rows past the end of the tile: the last row again
-            const unsigned* cp = reinterpret_cast<const unsigned*>(tile + (n * (unsigned)(M * ADC_IMG_ES) + col));
+            const unsigned* cp = reinterpret_cast<const unsigned*>(tile + (n * ROWB + col));
 #pragma unroll
             for (int j = 0; j < NW; ++j) dst[c][j] = cp[j];
         }
@@ -1383,6 +1393,7 @@ __global__ __launch_bounds__(ADC_RESCORE_THREADS) void adc_rescore_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------ host
+extern "C" size_t rc_adc_scan_image_bytes(int64_t N, int M);
 struct adc_ws_layout {
     size_t lut, sample, thr, cnt, cand, qlut, tint, qstat, idcnt, ids, image, partial, partial_bytes, total;
     int64_t S;
@@ -1437,7 +1448,7 @@ static adc_ws_layout adc_layout(int64_t N, int M, int nq, bool own_image = true)
         L.ids = o;   o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
     }
     L.image = o;
-    if (own_image && N >= ADC_SCREEN_MIN_N && adc_cf_supported(M)) o += rc_align_up((size_t)N * M * ADC_IMG_ES, 256);
+    if (own_image && N >= ADC_SCREEN_MIN_N && adc_cf_supported(M)) o += rc_align_up(rc_adc_scan_image_bytes(N, M), 256);
     L.partial = o;
     L.partial_bytes = adc_part_plan_for(N, M, nq).bytes;
     o += rc_align_up(L.partial_bytes, 256);
@@ -1467,10 +1478,14 @@ extern "C" size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, in
     if (N <= 0 || M <= 0 || K != RC_K || nq <= 0 || k <= 0) return 0;
     return adc_layout(N, M, nq, false).total;
 }
+// the flat-search image of a two-phase M is tile-blocked (whole tiles of adc_cf_tile_rows(M) rows)
+static int64_t adc_img_tile(int M) { return adc_cf_phase_m(M) != M ? adc_cf_tile_rows(M) : 0; }
 // bytes of the permuted code image of an N-row index (0: this M has no conflict-free screen, no image is used)
 extern "C" size_t rc_adc_scan_image_bytes(int64_t N, int M) {
     if (N < 0 || !adc_cf_supported(M)) return 0;
-    return (size_t)N * M * ADC_IMG_ES;
+    const int64_t T = adc_img_tile(M);
+    const int64_t rows = T > 0 ? (N + T - 1) / T * T : N;
+    return (size_t)rows * M * ADC_IMG_ES;
 }
 // Host-side description of the conflict-free layout (no GPU involved; what tests/test_abi.py checks): for lane `lane`
 // (0..63) of a wave and gather step `step` (0 .. steps_per_lane-1) of one table phase: the 8-byte LDS slot it reads and the
@@ -1486,8 +1501,8 @@ extern "C" int rc_adc_cf_describe(int M, int lane, int step, int* slot, int* m, 
 }
 
 // (Re)build rows [n0, n0 + n) of the image from the canonical codes [N, M] (both pointers = row 0 of the index).
-extern "C" int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
-                                 rc_stream_t stream) {
+static int adc_scan_image_impl(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image, int64_t tile,
+                               rc_stream_t stream) {
     rc_device_guard device_guard_(h);
     if (!h || !codes || !image || n0 < 0 || n < 0) return RC_EINVAL;
     if (!adc_cf_supported(M)) return RC_ESHAPE;
@@ -1495,9 +1510,19 @@ extern "C" int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0
     int64_t blocks = (n * M + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(adc_scan_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, codes, n0, n, M,
-                       adc_cf_phase_m(M), image);
+                       adc_cf_phase_m(M), image, tile);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
+}
+// flat-search image (what rc_adc_search_img / rc_adc_search_q take): rc_adc_scan_image_bytes(N, M) bytes
+extern "C" int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
+                                 rc_stream_t stream) {
+    return adc_scan_image_impl(h, codes, n0, n, M, image, adc_img_tile(M), stream);
+}
+// row-major image [N][M] (what the list-centric IVF search takes: its cells start at arbitrary rows)
+extern "C" int rc_adc_scan_image_rows(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
+                                      rc_stream_t stream) {
+    return adc_scan_image_impl(h, codes, n0, n, M, image, 0, stream);
 }
 
 static int adc_qt_for(int M) {

@@ -40,7 +40,7 @@ class PQIndex:
         self._codes = torch.empty((0, M), dtype=torch.uint8, device=self.device)
         # permuted copy of the codes streamed by the conflict-free ADC screen (csrc/adc_search.hip), kept in step
         # with `_codes` row for row; None for the M that do not use one
-        self._image = (torch.empty((0, ops.adc_image_row_bytes(M)), dtype=torch.uint8, device=self.device)
+        self._image = (torch.empty((0,), dtype=torch.uint8, device=self.device)        # flat buffer, ops.adc_image_bytes
                        if ops.adc_image_supported(M) else None)
         self.pq = SimpleNamespace(d=d, M=M, nbits=nbits, code_size=M, ksub=256, dsub=d // M, centroids=self._centroids)
 
@@ -75,8 +75,10 @@ class PQIndex:
             grown[: self.ntotal] = self._codes[: self.ntotal]
             self._codes = grown
             if self._image is not None:
-                gi = torch.empty((grown.shape[0], self._image.shape[1]), dtype=torch.uint8, device=self.device)
-                gi[: self.ntotal] = self._image[: self.ntotal]
+                # the image's layout does not depend on the capacity: the bytes of the rows held so far move as they are
+                gi = torch.empty((ops.adc_image_bytes(grown.shape[0], self.pq.M),), dtype=torch.uint8, device=self.device)
+                held = ops.adc_image_bytes(self.ntotal, self.pq.M)
+                gi[:held] = self._image[:held]
                 self._image = gi
         self._codes[self.ntotal:need] = c.to(self.device)
         if self._image is not None and n > 0:
@@ -103,7 +105,7 @@ class PQIndex:
         q = q.to(self.device, torch.float32, non_blocking=True)
         # prefixes of the row-major buffers are contiguous views: nothing is copied
         pending = ops.adc_search(self._codes[: self.ntotal], self._centroids, q, int(k), id_offset=self.id_offset,
-                                 scan_image=None if self._image is None else self._image[: self.ntotal], defer=True)
+                                 scan_image=self._image, defer=True)
 
         def finish():
             scores, ids = pending.result()

@@ -104,7 +104,7 @@ class IVFPQIndex:
         self.image = None
         if ops.adc_image_supported(self.M) and self.ntotal:
             self.image = torch.empty((self.ntotal, ops.adc_image_row_bytes(self.M)), dtype=torch.uint8, device=self.device)
-            ops.adc_scan_image_(self.codes, self.image)
+            ops.adc_scan_image_(self.codes, self.image, layout="rows")        # cells start at arbitrary rows: row-major
 
     def add(self, x, codes: Optional[torch.Tensor] = None):
         """Index (rotated) embeddings x [N,d]: nearest PQ codes (unless the model's `codes` are given) + coarse cell."""

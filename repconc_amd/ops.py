@@ -480,27 +480,39 @@ def adc_lut(centroids: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
 
 def adc_image_row_bytes(M: int) -> int:
     """Bytes per row of the permuted code image the ADC screen of this M streams (rc_adc_scan_image); 0 = none."""
-    return int(_lib.load().rc_adc_scan_image_bytes(1, int(M)))
+    return int(_lib.load().rc_adc_scan_image_bytes(1 << 20, int(M))) >> 20
+
+
+def adc_image_bytes(N: int, M: int) -> int:
+    """Bytes of the FLAT-SEARCH image of an N-row index (rc_adc_scan_image_bytes): N * row bytes, rounded up to whole
+    storage tiles for the M whose image is tile-blocked (M = 96: 32768-row tiles, phase-major inside a tile)."""
+    return int(_lib.load().rc_adc_scan_image_bytes(int(N), int(M)))
 
 
 def adc_image_supported(M: int) -> bool:
     return adc_image_row_bytes(M) > 0
 
 
-def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Optional[int] = None) -> torch.Tensor:
-    """(Re)build rows [n0, n0+n) of the permuted code image of an index: codes uint8 [>=n0+n, M], image uint8
-    [>=n0+n, adc_image_row_bytes(M)], both contiguous.  The image is what the conflict-free ADC screen streams; see
-    include/repconc_hip.h rc_adc_scan_image."""
+def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Optional[int] = None,
+                    layout: str = "flat") -> torch.Tensor:
+    """(Re)build rows [n0, n0+n) of the permuted code image of an index: codes uint8 [>=n0+n, M] contiguous; image a
+    contiguous uint8 buffer of at least adc_image_bytes(n0+n, M) bytes (layout "flat": what `adc_search` takes — row-major
+    for M in {16,32,48,64}, tile-blocked for M = 96) or (n0+n) * adc_image_row_bytes(M) bytes (layout "rows": row-major
+    [N, M] for every M, what the list-centric IVF search takes).  See include/repconc_hip.h rc_adc_scan_image."""
     _need_cuda(codes, image)
     if codes.dtype != torch.uint8 or image.dtype != torch.uint8 or not codes.is_contiguous() or not image.is_contiguous():
         raise ValueError("codes and image must be contiguous uint8")
+    if layout not in ("flat", "rows"):
+        raise ValueError("layout must be flat|rows")
     M = codes.shape[1]
     if n is None:
         n = codes.shape[0] - n0
-    if n0 < 0 or n < 0 or n0 + n > codes.shape[0] or n0 + n > image.shape[0] or image.shape[1] != adc_image_row_bytes(M):
+    need = adc_image_bytes(n0 + n, M) if layout == "flat" else (n0 + n) * adc_image_row_bytes(M)
+    if n0 < 0 or n < 0 or n0 + n > codes.shape[0] or adc_image_row_bytes(M) == 0 or image.numel() < need:
         raise ValueError("row range outside the code / image buffers")
     lib, h, s, _ = _ctx(codes)
-    _lib.check(lib.rc_adc_scan_image(h, _p(codes), int(n0), int(n), M, _p(image), s), "rc_adc_scan_image", h)
+    fn = lib.rc_adc_scan_image if layout == "flat" else lib.rc_adc_scan_image_rows
+    _lib.check(fn(h, _p(codes), int(n0), int(n), M, _p(image), s), "rc_adc_scan_image", h)
     return image
 
 
@@ -600,9 +612,9 @@ def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k:
     if codes.dtype != torch.uint8 or not codes.is_contiguous():
         raise ValueError("index codes must be contiguous uint8 [N, M]")
     if scan_image is not None and (scan_image.dtype != torch.uint8 or not scan_image.is_contiguous()
-                                   or scan_image.shape[0] < codes.shape[0]
-                                   or scan_image.shape[1] != adc_image_row_bytes(codes.shape[1])):
-        raise ValueError("scan_image must be contiguous uint8 [>=N, adc_image_row_bytes(M)]")
+                                   or adc_image_row_bytes(codes.shape[1]) == 0
+                                   or scan_image.numel() < adc_image_bytes(codes.shape[0], codes.shape[1])):
+        raise ValueError("scan_image must be a contiguous uint8 buffer of >= adc_image_bytes(N, M) bytes (adc_scan_image_)")
     c, q = _centroids(centroids), _rows_f32(q).contiguous()
     N, M = codes.shape
     nq, D = q.shape

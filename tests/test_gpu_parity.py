@@ -1156,15 +1156,26 @@ def test_adc_scan_image_is_a_row_permutation():
         codes = _t(np.concatenate([base] * 40 + [synth.uniform_codes(6 + M, 3, M)], 0))        # 643 rows, period 16
         rb = ops.adc_image_row_bytes(M)
         blank = torch.full((codes.shape[0], rb), 255, dtype=torch.uint8, device=DEV)
-        img = ops.adc_scan_image_(codes, blank.clone())
+        img = ops.adc_scan_image_(codes, blank.clone(), layout="rows")
         vals = img.cpu().numpy() if rb == M else img.cpu().numpy().view(np.uint16)     # 8- or 16-bit codes
         a, b = np.sort(codes.cpu().numpy(), axis=1), np.sort(vals, axis=1)
         assert np.array_equal(a, b)
         assert torch.equal(img[:16], img[16:32]) and torch.equal(img[:16], img[624:640])
         part = blank.clone()
-        ops.adc_scan_image_(codes, part, 100, 37)
+        ops.adc_scan_image_(codes, part, 100, 37, layout="rows")
         assert torch.equal(part[100:137], img[100:137])
         assert bool((part[:100] == 255).all()) and bool((part[137:] == 255).all())
+        # the flat-search image: the same rows; for M = 96 stored per 32768-row tile, phase-major inside the tile
+        flat = torch.full((ops.adc_image_bytes(codes.shape[0], M),), 255, dtype=torch.uint8, device=DEV)
+        ops.adc_scan_image_(codes, flat)
+        if M != 96:
+            assert flat.numel() == img.numel() and torch.equal(flat.view_as(img), img)
+        else:
+            T, n = 32768, codes.shape[0]
+            assert flat.numel() == T * 96
+            tile = flat.view(2, T, 48)
+            assert torch.equal(tile[0, :n], img[:, :48]) and torch.equal(tile[1, :n], img[:, 48:])
+            assert bool((tile[:, n:] == 255).all())
 
 
 @pytest.mark.parametrize("name", ["m48_b1024_sample", "m48_b1000_ragged", "m8_b2048_sample"])
@@ -1763,7 +1774,7 @@ def test_ivf_probes_entry_through_the_raw_c_abi():
     probes[0, :] = np.arange(nlist - nprobe, nlist)           # a query that probes (almost) only empty cells
     d_codes, d_off, d_ids = _t(codes[order]), _t(list_off), _t(order.astype(np.int64))
     image = torch.empty((N, ops.adc_image_row_bytes(M)), dtype=torch.uint8, device=DEV)
-    ops.adc_scan_image_(d_codes, image)
+    ops.adc_scan_image_(d_codes, image, layout="rows")
     lut = ops.adc_lut(_t(Cq), _t(q))
     d_probes = _t(probes)
     sizes = np.sort(np.diff(list_off))[::-1][:nprobe]
