@@ -1178,19 +1178,30 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     // aggregated survivor slots on top of the 12-step gather pipeline) spilled 100 bytes per lane with them
     constexpr bool PREFETCH = (NPE == 1) && !(IVF && PM == 48);
     adc_i32x4v acc[R];
-    adc_u32x2v part[PART == 2 ? R : 1];                     // pass 2: the round's partial sums, requested at its start
+    // pass 2: the partial sums stream from HBM (written once by pass 1, never cached): they are requested one round (R = 4
+    // chunks, ~2 us) ahead, ping-pong like the code buffers.  Only the lanes with r < 8 own a column of D, so the lanes with
+    // r >= 8 fetch the sums of chunk c + R/2 for their neighbour r - 8 (half the registers; a DPP row rotation by 8 hands
+    // them over when they are added).
+    constexpr int PR = PART == 2 ? (R + 1) / 2 : 1;
+    auto load_part = [&](int it, adc_u32x2v (&dst)[PR]) {
+        if constexpr (PART == 2) {
+            if (it < nsteps) {
+                const unsigned r0p = (unsigned)(it / NPE) * ROUND + (unsigned)(wv * R * 16);
+#pragma unroll
+                for (int c = 0; c < PR; ++c) {
+                    const int cc = (r < 8) ? c : c + PR;
+                    dst[c] = (cc < R) ? __builtin_nontemporal_load(part_ptr(r0p, cc)) : adc_u32x2v{0u, 0u};
+                }
+            }
+        }
+    };
     // one step: gather + fold the R chunks of step `it` from the codes in `w`; the next step's codes go to `wn`
-    auto run_step = [&](int it, unsigned (&w)[R][NW], unsigned (&wn)[PREFETCH ? R : 1][NW], int& in_lds) {
+    auto run_step = [&](int it, unsigned (&w)[R][NW], unsigned (&wn)[PREFETCH ? R : 1][NW], int& in_lds,
+                        const adc_u32x2v (&part)[PR]) {
         const int phase = phase_of(it);
         if (it % NPE == 0) {
 #pragma unroll
             for (int c = 0; c < R; ++c) acc[c] = adc_i32x4v{0, 0, 0, 0};
-            if constexpr (PART == 2) {
-                const unsigned r0p = (unsigned)(it / NPE) * ROUND + (unsigned)(wv * R * 16);
-#pragma unroll
-                for (int c = 0; c < R; ++c)
-                    part[c] = (r < 8) ? __builtin_nontemporal_load(part_ptr(r0p, c)) : adc_u32x2v{0u, 0u};
-            }
         }
         if (in_lds != phase) {
             if (in_lds >= 0) __syncthreads();                 // every wave is done gathering from the old tables
@@ -1258,10 +1269,13 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
         if constexpr (PART == 2) {
 #pragma unroll
             for (int c = 0; c < R; ++c) {
-                acc[c][0] += ((int)(part[c].x << 16)) >> 16;
-                acc[c][1] += ((int)part[c].x) >> 16;
-                acc[c][2] += ((int)(part[c].y << 16)) >> 16;
-                acc[c][3] += ((int)part[c].y) >> 16;
+                // chunk c < PR: this lane's own registers; chunk c >= PR: held by lane r + 8 (meaningful for r < 8 only)
+                unsigned px = part[c % PR].x, py = part[c % PR].y;
+                if (c >= PR) { px = (unsigned)rc_dpp_row_ror<8>((int)px); py = (unsigned)rc_dpp_row_ror<8>((int)py); }
+                acc[c][0] += ((int)(px << 16)) >> 16;
+                acc[c][1] += ((int)px) >> 16;
+                acc[c][2] += ((int)(py << 16)) >> 16;
+                acc[c][3] += ((int)py) >> 16;
             }
         }
         if (PART != 1 && it % NPE == NPE - 1) {
@@ -1320,16 +1334,20 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
         }
     };
     unsigned wa[R][NW], wb[PREFETCH ? R : 1][NW];
+    adc_u32x2v pa[PR], pb[PR];
     int in_lds = -1;
     if constexpr (PREFETCH) {
-        // ping-pong over the two code buffers: no register copies between steps
+        // ping-pong over the two code buffers (and, pass 2, the two partial-sum buffers): no register copies between steps
         load_step(0, wa);
+        load_part(0, pa);
         for (int it = 0; it < nsteps; it += 2) {              // block-uniform
-            run_step(it, wa, wb, in_lds);
-            if (it + 1 < nsteps) run_step(it + 1, wb, wa, in_lds);
+            load_part(it + 1, pb);
+            run_step(it, wa, wb, in_lds, pa);
+            load_part(it + 2, pa);
+            if (it + 1 < nsteps) run_step(it + 1, wb, wa, in_lds, pb);
         }
     } else {
-        for (int it = 0; it < nsteps; ++it) run_step(it, wa, wb, in_lds);
+        for (int it = 0; it < nsteps; ++it) run_step(it, wa, wb, in_lds, pa);
     }
 }
 
@@ -1457,7 +1475,7 @@ static adc_ws_layout adc_layout(int64_t N, int M, int nq, bool own_image = true)
 }
 static adc_part_plan adc_part_plan_for(int64_t N, int M, int nq) {
     adc_part_plan P = {0u, 0u, 0};
-    if (M != 96 || N < ADC_SCREEN_MIN_N || nq <= 0) return P;
+    if (M != 96 || N < ADC_SCREEN_MIN_N || nq <= 0 || rc_env_int("RC_ADC_TWO_PASS", 0) == 0) return P;
     const int64_t tile = adc_cf_tile_rows(M);
     P.nchunks = (unsigned)(((N + tile - 1) / tile) * (tile / 16));
     const size_t per_group = (size_t)P.nchunks * 256;
@@ -1597,16 +1615,20 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             const unsigned groups = (unsigned)((nq + 7) / 8);
             bool done = false;
             if constexpr (NP == 2) {
-                // two passes with resident tables and the partial sums through HBM (see adc_part_args); RC_ADC_TWO_PASS=0
-                // or a workspace without the partial-sum buffer selects the one-launch form
+                // two passes with resident tables and the partial sums through HBM (see adc_part_args): opt-in with
+                // RC_ADC_TWO_PASS=1 (and a workspace sized with it).  [MI355X, round 3] 1200 queries x 8.84 M rows: pass 1
+                // 3 x 3.8 ms + pass 2 3 x 4.7 ms = 25.5 ms against 26.7 ms for the one-launch form below — the barriers
+                // were NOT what the two-phase screen pays over 2 x 9.8 ms (the M = 48 kernel): each pass, with the M = 48
+                // kernel's schedule, resident tables and a dense 48-byte-row image, is still 16 % / 44 % slower than that
+                // kernel.  1.5 % for 8 GB of workspace: not the default.
                 const adc_part_plan pp = adc_part_plan_for(N, M, nq);
-                if (b.partial && pp.groups_per_pass > 0 && rc_env_int("RC_ADC_TWO_PASS", 1) != 0) {
+                if (b.partial && pp.groups_per_pass > 0) {
                     // chunks per wave and round: pass 2 carries the round's partial sums besides the M = 48 kernel's registers
                     // (R = 4: 128 VGPRs + 36 bytes of scratch; R = 2: no spill); the layout of the partial sums does not
                     // depend on R, so the passes may differ.  RC_ADC_PART_R1 / _R2 = 2 | 4 for A/B runs.
                     auto k1 = rc_env_int("RC_ADC_PART_R1", 4) == 2 ? adc_screen_cf_kernel<M, NP, 2, false, TH, 1>
                                                                    : adc_screen_cf_kernel<M, NP, 4, false, TH, 1>;
-                    auto k2 = rc_env_int("RC_ADC_PART_R2", 2) == 4 ? adc_screen_cf_kernel<M, NP, 4, false, TH, 2>
+                    auto k2 = rc_env_int("RC_ADC_PART_R2", 4) == 4 ? adc_screen_cf_kernel<M, NP, 4, false, TH, 2>
                                                                    : adc_screen_cf_kernel<M, NP, 2, false, TH, 2>;
                     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
                     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
