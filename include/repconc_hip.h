@@ -281,6 +281,12 @@ int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n
  * (rc_ivf_search_lists / _probes) takes the row-major image [N][M] for every M: rc_adc_scan_image_rows. */
 int rc_adc_scan_image_rows(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
                            rc_stream_t stream);
+/* Round 3: for the M whose flat search runs the 16-query screen (adc_screen_q16_kernel; M = 48 and 96 unless RC_ADC_Q16
+ * says otherwise — read once per process) the flat-search image is [n / 32768][phase = m / 16][n % 32768][16 bytes], the 16
+ * bytes of a (row, phase) ordered [lane quarter g][step j] = code of sub-quantiser 16 phase + slot(lane = (n & 15) + 16 g, j).
+ * rc_adc_q16_describe (host only, tests): *slot = slot(lane, step); returns 1 if this M's flat search uses the layout, 0 if
+ * not, RC_ESHAPE for an M without an image. */
+int rc_adc_q16_describe(int M, int lane, int step, int* slot);
 size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, int k);
 int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
                       const float* C, int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,

@@ -34,6 +34,7 @@
 #include "rc_common.h"
 
 #include <limits.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -1351,6 +1352,221 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     }
 }
 
+
+// ------------------------------------------------------------------------------------ 4b''. 16 queries per gather
+// Round 3.  PMC and the round-3 micro-benchmark (tools/ubench_lds_gather.hip, profiles/r03a_ubench_lds_gather.txt) agree
+// that the conflict-free 8-query screen above is not bound by the LDS array (2.0 of ~6 cycles per gather and CU) but by
+// instruction issue: two address instructions + half an i8 MFMA (~3 VALU-equivalents on the shared issue port) per
+// 8-byte gather.  A ds_read_b128 gather serves 16 queries for the same address arithmetic and one MFMA: 5.55 cycles per
+// 16 queries against 2 x 4.0 in the micro-benchmark.  The price is table size — 16 queries x M x 256 bytes no longer
+// fit the LDS — so the sub-quantisers are visited in PHASES of 16 (64 KiB of tables: [code][slot 0..15][16 queries], a
+// code's row = 256 bytes = all 64 banks once) with TWO buffers: while a phase is gathered, the next one is copied into
+// the other buffer by global_load_lds_dwordx4 (asynchronous, no registers), one barrier per phase change, no refill on
+// the critical path.  What round 2 measured against phases (synchronous 128 KiB refills from the memory-side cache: the
+// two-phase M = 96 screen pays 43 % for them) does not apply: the refill is prefetched, and the block -> (group, tile)
+// map gives every XCD a fixed set of ~10 query groups whose tables (192 KiB each at M = 48) stay in its L2.
+//
+// Conflict freedom for ds_read_b128: the LDS serves a wave in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,
+// 28-31} and the same +32; MI355X_MICROARCH.md), 16 lanes x 16 bytes = one pass over the 64 banks if they read 16
+// different 16-byte slots.  Lane l (row r = l & 15, quarter g = l >> 4) has position p(l & 31) in its service group and
+// reads slot (p + j + 4 (l >> 5)) mod 16 in step j = 0..3 — distinct inside every group, and the four lanes of a row
+// (positions a, a + 8 in both halves) cover the 16 slots exactly once.  As in the 8-query screen a lane must receive its
+// codes in its own visiting order: the flat-search image of these M is [tile][phase][row][quarter g][step j] (tiles of
+// ADC_Q16_TILE rows, phase-major inside a tile: a wave's code load for 16 rows is 256 contiguous bytes).
+// Accumulation: v_mfma_i32_16x16x64_i8 with A = the lane's 16 gathered bytes (one sub-quantiser x 16 queries), B[k][n] =
+// [k mod 16 == n]: D[row][query] += sum over the row's four lanes.  Everything downstream is unchanged.
+#define ADC_Q16_TILE 32768
+__host__ __device__ constexpr int adc_q16_pos(int h32) {
+    return (h32 < 4) ? h32 : (h32 < 12) ? h32 - 4 : (h32 < 16) ? h32 - 8 : (h32 < 20) ? h32 - 8 : (h32 < 28) ? h32 - 12 : h32 - 16;
+}
+// sub-quantiser (within its phase of 16) = LDS slot that lane `lane` of a wave reads in step j
+__host__ __device__ constexpr int adc_q16_slot(int lane, int j) { return (adc_q16_pos(lane & 31) + j + 4 * (lane >> 5)) & 15; }
+
+// image of rows n0 <= n < n0 + cnt: [n / T][phase][n % T][g][j] = codes[n][16 phase + slot(lane = (n & 15) + 16 g, j)]
+__global__ __launch_bounds__(256) void adc_q16_image_kernel(const uint8_t* __restrict__ codes, int64_t n0, int64_t cnt, int M,
+                                                            uint8_t* __restrict__ image) {
+    const int64_t total = cnt * M;
+    const int NPH = M / 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = n0 + i / M;
+        const int pos = (int)(i % M);
+        const int phase = pos >> 4, g = (pos >> 2) & 3, j = pos & 3;
+        const int m = 16 * phase + adc_q16_slot((int)(n & 15) + 16 * g, j);
+        const int64_t at = ((n / ADC_Q16_TILE) * NPH + phase) * (int64_t)ADC_Q16_TILE * 16 + (n % ADC_Q16_TILE) * 16 + (pos & 15);
+        image[at] = codes[n * M + m];
+    }
+}
+
+// byte tables [group of 16 queries][phase][code][slot][16 queries], biased by -128 (the MFMA is signed): thread = code
+__global__ __launch_bounds__(64) void adc_qlut16_write_kernel(const float* __restrict__ lut, const float* __restrict__ qstat,
+                                                              int M, int nq, uint8_t* __restrict__ qlut) {
+    const int G = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x, phase = blockIdx.z;
+    const int NPH = M / 16;
+    const int nv = (nq - 16 * G) < 16 ? (nq - 16 * G) : 16;
+    uint4* row = reinterpret_cast<uint4*>(qlut + (((size_t)G * NPH + phase) * RC_K + c) * 256);
+    for (int sl = 0; sl < 16; ++sl) {
+        const int m = 16 * phase + sl;
+        unsigned w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};    // absent queries: byte 0 -> -128
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            if (qq < nv) {
+                const int q = 16 * G + qq;
+                const unsigned l = adc_quant8(lut[((size_t)q * M + m) * RC_K + c], qstat[(size_t)q * ADC_QSTAT_STRIDE + m],
+                                              qstat[(size_t)q * ADC_QSTAT_STRIDE + ADC_QSTAT_STRIDE - 1]);
+                w[qq >> 2] = (w[qq >> 2] & ~(0xFFu << (8 * (qq & 3)))) | ((l ^ 0x80u) << (8 * (qq & 3)));
+            }
+        }
+        row[sl] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+typedef unsigned adc_u32x4v __attribute__((ext_vector_type(4)));
+
+// grid: 8 x ceil(groups / 8) x tiles blocks, dealt so that XCD x (= block id mod 8) owns the groups == x (mod 8).
+template <int M, int R, int THREADS>
+__global__ __launch_bounds__(THREADS) void adc_screen_q16_kernel(const uint8_t* __restrict__ image, int64_t N,
+                                                                 const uint8_t* __restrict__ qlut, const int* __restrict__ tint,
+                                                                 int nq, int groups, unsigned* __restrict__ id_count,
+                                                                 unsigned* __restrict__ ids) {
+    constexpr int NPH = M / 16, NWAVES = THREADS / 64, ROUND = NWAVES * R * 16, TILE = ADC_Q16_TILE;
+    constexpr int BUF = RC_K * 256;                           // 64 KiB: one phase of one group
+    static_assert(TILE % ROUND == 0, "whole rounds per tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const int r = l & 15, g = l >> 4;
+    const unsigned xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3;
+    const unsigned gpx = (unsigned)(groups + 7) / 8u;         // groups per XCD
+    const unsigned group = (jx % gpx) * 8u + xcd, btile = jx / gpx;
+    if (group >= (unsigned)groups) return;                    // block-uniform
+    const int q0 = (int)group * 16;
+    const uint8_t* qsrc = qlut + (size_t)group * NPH * BUF;
+    // asynchronous copy of one phase's tables into an LDS buffer: 16 waves x 4 pieces of 1 KiB
+    auto stage = [&](int phase, int buf) {
+        const uint8_t* src = qsrc + (size_t)phase * BUF;
+#pragma unroll
+        for (int i = 0; i < BUF / 1024 / NWAVES; ++i) {
+            const int piece = i * NWAVES + wv;               // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 1024 + l * 16),
+                                             (__attribute__((address_space(3))) void*)(smem + (size_t)buf * BUF + (size_t)piece * 1024),
+                                             16, 0, 0);
+        }
+    };
+    int tq = INT_MAX, myq = -1;
+    if (q0 + r < nq) {
+        myq = q0 + r;
+        const int t = tint[myq];
+        tq = (t == INT_MIN) ? INT_MIN : t - 128 * M;
+    }
+    adc_i32x4v bsel = {0, 0, 0, 0};                           // B[k][n = r] = [k mod 16 == r]
+    bsel[r >> 2] = 1 << (8 * (r & 3));
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+    unsigned off[4], offb[4];                                 // this lane's slot offsets (absolute LDS address) in buffer 0 / the current buffer
+#pragma unroll
+    for (int j = 0; j < 4; ++j) off[j] = lds0 + (unsigned)adc_q16_slot(l, j) * 16u;
+    const int64_t t0 = (int64_t)btile * TILE;
+    const int64_t t1 = (t0 + TILE < N) ? t0 + TILE : N;
+    const unsigned nrows = (unsigned)(t1 - t0);
+    const int nrounds = (int)((nrows + ROUND - 1) / ROUND);
+    const int nsteps = nrounds * NPH;
+    const uint8_t* __restrict__ tile = image + t0 * M;       // the tile's storage: [phase][TILE][16]
+    auto phase_of = [&](int it) { const int rd = it / NPH, i = it % NPH; return (rd & 1) ? NPH - 1 - i : i; };
+    // next step after `it` whose phase differs from phase_of(it) (nsteps if none)
+    auto next_change = [&](int it) {
+        int k = it + 1;
+        while (k < nsteps && phase_of(k) == phase_of(it)) ++k;
+        return k;
+    };
+    const unsigned lane_row = (unsigned)(wv * R * 16 + r), lane_off = (unsigned)(g * 4);
+    auto load_step = [&](int it, unsigned (&dst)[R]) {
+        const unsigned base = (unsigned)(it / NPH) * ROUND + lane_row;
+        const unsigned col = (unsigned)phase_of(it) * (unsigned)(TILE * 16) + lane_off;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            unsigned n = base + 16u * c;
+            n = n < nrows ? n : nrows - 1u;
+            dst[c] = *reinterpret_cast<const unsigned*>(tile + (n * 16u + col));
+        }
+    };
+    adc_i32x4v acc[R];
+    int buf = 0;
+    auto run_step = [&](int it, unsigned (&w)[R], unsigned (&wn)[R]) {
+        if (it % NPH == 0) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) acc[c] = adc_i32x4v{0, 0, 0, 0};
+        }
+        if (it > 0 && phase_of(it) != phase_of(it - 1)) {
+            // phase change: this phase's tables were requested into the other buffer one segment ago
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces have landed
+            __syncthreads();                                 // everybody's have, and everybody is done with the old buffer
+            buf ^= 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) offb[j] = off[j] + (unsigned)buf * (unsigned)BUF;
+            const int nx = next_change(it);
+            if (nx < nsteps) stage(phase_of(nx), buf ^ 1);   // the buffer just vacated
+        }
+        if (it + 1 < nsteps) load_step(it + 1, wn);
+        adc_u32x4v ea[4], eb[4];
+        auto gather = [&](int c, adc_u32x4v (&e)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned addr;
+                asm("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_add_u32 %0, %0, 8, %3" : "=&v"(addr) : "v"(w[c]), "n"(8 * j), "v"(offb[j]));
+                e[j] = *reinterpret_cast<const adc_u32x4v __attribute__((address_space(3)))*>(addr);
+            }
+        };
+        auto fold = [&](int c, const adc_u32x4v (&e)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const adc_i32x4v a = {(int)e[j][0], (int)e[j][1], (int)e[j][2], (int)e[j][3]};
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
+            }
+        };
+        gather(0, ea);
+#pragma unroll
+        for (int c = 0; c < R; c += 2) {
+            if (c + 1 < R) gather(c + 1, eb);
+            fold(c, ea);
+            if (c + 2 < R) gather(c + 2, ea);
+            if (c + 1 < R) fold(c + 1, eb);
+        }
+        if (it % NPH == NPH - 1) {
+            int top = INT_MIN;
+#pragma unroll
+            for (int c = 0; c < R; ++c) top = max(top, max(max(acc[c][0], acc[c][1]), max(acc[c][2], acc[c][3])));
+            if (__ballot(top >= tq)) {
+                const unsigned r0 = (unsigned)(it / NPH) * ROUND + (unsigned)(wv * R * 16);
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned n = r0 + 16u * c + 4u * g + e;   // D[row = 4 g + e][column = r]
+                        if (acc[c][e] >= tq && n < nrows) {
+                            const unsigned slot = atomicAdd(id_count + myq, 1u);
+                            if (slot < ADC_ID_CAP) ids[(size_t)myq * ADC_ID_CAP + slot] = (unsigned)(t0 + n);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // prologue: first phase into buffer 0, the next distinct phase into buffer 1
+    stage(phase_of(0), 0);
+    unsigned wa[R], wb[R];
+    load_step(0, wa);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const int nx = next_change(0);
+        if (nx < nsteps) stage(phase_of(nx), 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offb[j] = off[j];
+    for (int it = 0; it < nsteps; it += 2) {                 // block-uniform
+        run_step(it, wa, wb);
+        if (it + 1 < nsteps) run_step(it + 1, wb, wa);
+    }
+}
+
 // One block per query: exact fp32 score (m ascending, from 0) of every screened row; rows with score >= tau go
 // to the key list exactly as adc_scan_kernel<FILTER> would have put them.
 // 512 threads: a block's table is 4 M x 256 bytes of LDS (three blocks per CU at M = 48), and every survivor costs one
@@ -1496,8 +1712,20 @@ extern "C" size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, in
     if (N <= 0 || M <= 0 || K != RC_K || nq <= 0 || k <= 0) return 0;
     return adc_layout(N, M, nq, false).total;
 }
-// the flat-search image of a two-phase M is tile-blocked (whole tiles of adc_cf_tile_rows(M) rows)
-static int64_t adc_img_tile(int M) { return adc_cf_phase_m(M) != M ? adc_cf_tile_rows(M) : 0; }
+// Which M run the 16-query screen (adc_screen_q16_kernel) in the flat search.  The choice fixes the layout of the index's
+// flat-search image, so it is read ONCE per process: RC_ADC_Q16 = 0 (none) | all | unset (the default set below).
+static bool adc_q16_for(int M) {
+    static int mode = -1;                                    // 0 none, 1 default set, 2 all
+    if (mode < 0) {
+        const char* e = getenv("RC_ADC_Q16");
+        mode = (!e || !*e) ? 1 : (!strcmp(e, "0") ? 0 : (!strcmp(e, "all") ? 2 : 1));
+    }
+    if (mode == 0 || !adc_cf_supported(M)) return false;
+    return mode == 2 ? true : (M == 48 || M == 96);
+}
+// the flat-search image of a two-phase M is tile-blocked (whole tiles of adc_cf_tile_rows(M) rows); so is every image of
+// the 16-query screen (tiles of ADC_Q16_TILE rows)
+static int64_t adc_img_tile(int M) { return adc_q16_for(M) ? ADC_Q16_TILE : (adc_cf_phase_m(M) != M ? adc_cf_tile_rows(M) : 0); }
 // bytes of the permuted code image of an N-row index (0: this M has no conflict-free screen, no image is used)
 extern "C" size_t rc_adc_scan_image_bytes(int64_t N, int M) {
     if (N < 0 || !adc_cf_supported(M)) return 0;
@@ -1535,7 +1763,24 @@ static int adc_scan_image_impl(rc_handle_t h, const uint8_t* codes, int64_t n0, 
 // flat-search image (what rc_adc_search_img / rc_adc_search_q take): rc_adc_scan_image_bytes(N, M) bytes
 extern "C" int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
                                  rc_stream_t stream) {
+    if (adc_q16_for(M)) {
+        rc_device_guard device_guard_(h);
+        if (!h || !codes || !image || n0 < 0 || n < 0) return RC_EINVAL;
+        if (n == 0) return RC_OK;
+        int64_t blocks = (n * M + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(adc_q16_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, codes, n0, n, M, image);
+        RC_LAUNCH_CHECK(h);
+        return RC_OK;
+    }
     return adc_scan_image_impl(h, codes, n0, n, M, image, adc_img_tile(M), stream);
+}
+// host-side description of the 16-query screen's layout (tests): slot read by `lane` in step j, or RC_ESHAPE
+extern "C" int rc_adc_q16_describe(int M, int lane, int step, int* slot) {
+    if (!adc_cf_supported(M)) return RC_ESHAPE;
+    if (lane < 0 || lane > 63 || step < 0 || step > 3 || !slot) return RC_EINVAL;
+    *slot = adc_q16_slot(lane, step);
+    return adc_q16_for(M) ? 1 : 0;                           // 1: this M's flat search uses the layout
 }
 // row-major image [N][M] (what the list-centric IVF search takes: its cells start at arbitrary rows)
 extern "C" int rc_adc_scan_image_rows(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
@@ -1600,7 +1845,27 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
     constexpr int QS1 = (M <= 64) ? 8 : 4;                  // one-pass kernels: M * 256 * QS bytes of LDS
     int src = RC_OK;
     constexpr bool CF = (M == 16 || M == 32 || M == 48 || M == 64 || M == 96);
-    if (CF && image != nullptr) {
+    if (CF && image != nullptr && adc_q16_for(M)) {
+        if constexpr (CF) {
+            // 16 queries per ds_read_b128 gather, phases of 16 sub-quantisers, double-buffered tables (adc_screen_q16_kernel)
+            constexpr int R = 8, TH = ADC_THREADS;
+            auto kern = adc_screen_q16_kernel<M, R, TH>;
+            constexpr int sl = 2 * RC_K * 256;
+            const int groups = (nq + 15) / 16;
+            hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, b.qstat, b.tint);
+            RC_LAUNCH_CHECK(h);
+            hipLaunchKernelGGL(adc_qlut16_write_kernel, dim3((unsigned)groups, RC_K / 64, M / 16), dim3(64), 0, s, b.lut,
+                               (const float*)b.qstat, M, nq, b.qlut);
+            RC_LAUNCH_CHECK(h);
+            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+            const unsigned tiles16 = (unsigned)((N + ADC_Q16_TILE - 1) / ADC_Q16_TILE);
+            const unsigned gpx = (unsigned)(groups + 7) / 8u;
+            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+            hipLaunchKernelGGL(kern, dim3(8u * gpx * tiles16), dim3(TH), sl, s, image, N, b.qlut, b.tint, nq, groups, b.idcnt, b.ids);
+            rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+            RC_LAUNCH_CHECK(h);
+        }
+    } else if (CF && image != nullptr) {
         if constexpr (CF) {
             constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP;
             constexpr int R = (NP > 1) ? 8 : ((M == 64 || (ADC_IMG_ES == 2 && M == 48)) ? 2 : 4);   // register budget

@@ -1165,17 +1165,57 @@ def test_adc_scan_image_is_a_row_permutation():
         ops.adc_scan_image_(codes, part, 100, 37, layout="rows")
         assert torch.equal(part[100:137], img[100:137])
         assert bool((part[:100] == 255).all()) and bool((part[137:] == 255).all())
-        # the flat-search image: the same rows; for M = 96 stored per 32768-row tile, phase-major inside the tile
+        # the flat-search image: row-major for the one-phase 8-query screen; tile-blocked and phase-major for the two-phase
+        # one (M = 96 without the 16-query screen) and for the 16-query screen (rc_adc_q16_describe says which M use it)
+        import ctypes
+        from repconc_amd import _lib
+        lib = _lib.load()
         flat = torch.full((ops.adc_image_bytes(codes.shape[0], M),), 255, dtype=torch.uint8, device=DEV)
         ops.adc_scan_image_(codes, flat)
-        if M != 96:
+        slot = ctypes.c_int(0)
+        uses_q16 = lib.rc_adc_q16_describe(M, 0, 0, ctypes.byref(slot))
+        n, T = codes.shape[0], 32768
+        if uses_q16 == 1:
+            assert flat.numel() == T * M
+            tile = flat.view(M // 16, T, 16).cpu().numpy()
+            hc = codes.cpu().numpy()
+            want = np.empty((M // 16, n, 16), np.uint8)
+            for rr in range(16):
+                for gq in range(4):
+                    for j in range(4):
+                        assert lib.rc_adc_q16_describe(M, rr + 16 * gq, j, ctypes.byref(slot)) == 1
+                        for ph in range(M // 16):
+                            want[ph, rr::16, 4 * gq + j] = hc[rr::16, 16 * ph + slot.value]
+            assert np.array_equal(tile[:, :n], want) and bool((tile[:, n:] == 255).all())
+        elif M != 96:
             assert flat.numel() == img.numel() and torch.equal(flat.view_as(img), img)
         else:
-            T, n = 32768, codes.shape[0]
             assert flat.numel() == T * 96
             tile = flat.view(2, T, 48)
             assert torch.equal(tile[0, :n], img[:, :48]) and torch.equal(tile[1, :n], img[:, 48:])
             assert bool((tile[:, n:] == 255).all())
+
+
+def test_adc_q16_layout_is_conflict_free_and_covers_every_sub_quantiser():
+    """Host-side check of the 16-query screen's gather pattern (rc_adc_q16_describe): in every step the 16 lanes of each
+    ds_read_b128 service group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, and +32) read 16 different 16-byte slots, and the
+    four lanes of a row visit each of the 16 sub-quantisers of a phase exactly once."""
+    import ctypes
+    from repconc_amd import _lib
+    lib = _lib.load()
+    slot = ctypes.c_int(0)
+
+    def sl(lane, j):
+        assert lib.rc_adc_q16_describe(48, lane, j, ctypes.byref(slot)) >= 0
+        return slot.value
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[x + 32 for x in grp] for grp in groups]
+    for j in range(4):
+        for grp in groups:
+            assert sorted(sl(x, j) for x in grp) == list(range(16))
+    for r in range(16):
+        assert sorted(sl(r + 16 * gq, j) for gq in range(4) for j in range(4)) == list(range(16))
 
 
 @pytest.mark.parametrize("name", ["m48_b1024_sample", "m48_b1000_ragged", "m8_b2048_sample"])
