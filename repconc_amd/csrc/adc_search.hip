@@ -1376,13 +1376,27 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
 // Accumulation: v_mfma_i32_16x16x64_i8 with A = the lane's 16 gathered bytes (one sub-quantiser x 16 queries), B[k][n] =
 // [k mod 16 == n]: D[row][query] += sum over the row's four lanes.  Everything downstream is unchanged.
 #define ADC_Q16_TILE 32768
+#define ADC_Q16_R 8                // chunks of 16 rows per wave and round
+#define ADC_Q16_WAVES 16           // waves per block: a round = 16 x 8 x 16 = 2048 rows
 __host__ __device__ constexpr int adc_q16_pos(int h32) {
     return (h32 < 4) ? h32 : (h32 < 12) ? h32 - 4 : (h32 < 16) ? h32 - 8 : (h32 < 20) ? h32 - 8 : (h32 < 28) ? h32 - 12 : h32 - 16;
 }
 // sub-quantiser (within its phase of 16) = LDS slot that lane `lane` of a wave reads in step j
 __host__ __device__ constexpr int adc_q16_slot(int lane, int j) { return (adc_q16_pos(lane & 31) + j + 4 * (lane >> 5)) & 15; }
 
-// image of rows n0 <= n < n0 + cnt: [n / T][phase][n % T][g][j] = codes[n][16 phase + slot(lane = (n & 15) + 16 g, j)]
+// Image of rows n0 <= n < n0 + cnt.  Inside a (tile, phase) block of T x 16 bytes the bytes are ordered the way the
+// kernel's waves consume them: [round of 2048 rows][wave][lane = r + 16 g][chunk c][step j], row = 2048 round + 128 wave +
+// 16 c + r — a lane's codes for the 8 chunks of a step are 32 contiguous bytes (two 16-byte loads), a wave's 2 KiB.
+// byte (n, phase, g, j) = codes[n][16 phase + slot(lane = (n & 15) + 16 g, j)]
+__host__ __device__ inline int64_t adc_q16_image_at(int64_t n, int NPH, int phase, int g, int j) {
+    constexpr int64_t T = ADC_Q16_TILE;
+    constexpr int RW = ADC_Q16_R * 16;                       // rows per wave and round
+    const int64_t nt = n % T;
+    const int64_t round = nt / (RW * ADC_Q16_WAVES), nr = nt % (RW * ADC_Q16_WAVES);
+    const int wv = (int)(nr / RW), c = (int)((nr % RW) / 16), r = (int)(nr % 16);
+    return ((n / T) * NPH + phase) * T * 16 + round * (int64_t)(RW * ADC_Q16_WAVES * 16) + (int64_t)wv * (RW * 16) +
+           (int64_t)(r + 16 * g) * (ADC_Q16_R * 4) + c * 4 + j;
+}
 __global__ __launch_bounds__(256) void adc_q16_image_kernel(const uint8_t* __restrict__ codes, int64_t n0, int64_t cnt, int M,
                                                             uint8_t* __restrict__ image) {
     const int64_t total = cnt * M;
@@ -1392,8 +1406,7 @@ __global__ __launch_bounds__(256) void adc_q16_image_kernel(const uint8_t* __res
         const int pos = (int)(i % M);
         const int phase = pos >> 4, g = (pos >> 2) & 3, j = pos & 3;
         const int m = 16 * phase + adc_q16_slot((int)(n & 15) + 16 * g, j);
-        const int64_t at = ((n / ADC_Q16_TILE) * NPH + phase) * (int64_t)ADC_Q16_TILE * 16 + (n % ADC_Q16_TILE) * 16 + (pos & 15);
-        image[at] = codes[n * M + m];
+        image[adc_q16_image_at(n, NPH, phase, g, j)] = codes[n * M + m];
     }
 }
 
@@ -1423,14 +1436,16 @@ __global__ __launch_bounds__(64) void adc_qlut16_write_kernel(const float* __res
 typedef unsigned adc_u32x4v __attribute__((ext_vector_type(4)));
 
 // grid: 8 x ceil(groups / 8) x tiles blocks, dealt so that XCD x (= block id mod 8) owns the groups == x (mod 8).
-template <int M, int R, int THREADS>
-__global__ __launch_bounds__(THREADS) void adc_screen_q16_kernel(const uint8_t* __restrict__ image, int64_t N,
-                                                                 const uint8_t* __restrict__ qlut, const int* __restrict__ tint,
-                                                                 int nq, int groups, unsigned* __restrict__ id_count,
-                                                                 unsigned* __restrict__ ids) {
-    constexpr int NPH = M / 16, NWAVES = THREADS / 64, ROUND = NWAVES * R * 16, TILE = ADC_Q16_TILE;
+template <int M>
+__global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(const uint8_t* __restrict__ image, int64_t N,
+                                                                            const uint8_t* __restrict__ qlut,
+                                                                            const int* __restrict__ tint, int nq, int groups,
+                                                                            unsigned* __restrict__ id_count,
+                                                                            unsigned* __restrict__ ids) {
+    constexpr int R = ADC_Q16_R, NWAVES = ADC_Q16_WAVES;
+    constexpr int NPH = M / 16, ROUND = NWAVES * R * 16, TILE = ADC_Q16_TILE;
     constexpr int BUF = RC_K * 256;                           // 64 KiB: one phase of one group
-    static_assert(TILE % ROUND == 0, "whole rounds per tile");
+    static_assert(TILE % ROUND == 0 && R == 8, "whole rounds per tile; a lane's codes of a step = two 16-byte loads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     const int r = l & 15, g = l >> 4;
@@ -1460,7 +1475,7 @@ __global__ __launch_bounds__(THREADS) void adc_screen_q16_kernel(const uint8_t* 
     adc_i32x4v bsel = {0, 0, 0, 0};                           // B[k][n = r] = [k mod 16 == r]
     bsel[r >> 2] = 1 << (8 * (r & 3));
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
-    unsigned off[4], offb[4];                                 // this lane's slot offsets (absolute LDS address) in buffer 0 / the current buffer
+    unsigned off[4], offb[4];                                 // this lane's slot offsets (absolute LDS address): buffer 0 / current buffer
 #pragma unroll
     for (int j = 0; j < 4; ++j) off[j] = lds0 + (unsigned)adc_q16_slot(l, j) * 16u;
     const int64_t t0 = (int64_t)btile * TILE;
@@ -1468,7 +1483,7 @@ __global__ __launch_bounds__(THREADS) void adc_screen_q16_kernel(const uint8_t* 
     const unsigned nrows = (unsigned)(t1 - t0);
     const int nrounds = (int)((nrows + ROUND - 1) / ROUND);
     const int nsteps = nrounds * NPH;
-    const uint8_t* __restrict__ tile = image + t0 * M;       // the tile's storage: [phase][TILE][16]
+    const uint8_t* __restrict__ tile = image + t0 * M;       // the tile's storage: [phase][round][wave][lane][c][j]
     auto phase_of = [&](int it) { const int rd = it / NPH, i = it % NPH; return (rd & 1) ? NPH - 1 - i : i; };
     // next step after `it` whose phase differs from phase_of(it) (nsteps if none)
     auto next_change = [&](int it) {
@@ -1476,20 +1491,18 @@ __global__ __launch_bounds__(THREADS) void adc_screen_q16_kernel(const uint8_t* 
         while (k < nsteps && phase_of(k) == phase_of(it)) ++k;
         return k;
     };
-    const unsigned lane_row = (unsigned)(wv * R * 16 + r), lane_off = (unsigned)(g * 4);
-    auto load_step = [&](int it, unsigned (&dst)[R]) {
-        const unsigned base = (unsigned)(it / NPH) * ROUND + lane_row;
-        const unsigned col = (unsigned)phase_of(it) * (unsigned)(TILE * 16) + lane_off;
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            unsigned n = base + 16u * c;
-            n = n < nrows ? n : nrows - 1u;
-            dst[c] = *reinterpret_cast<const unsigned*>(tile + (n * 16u + col));
-        }
+    // this lane's 32 bytes of codes of step `it`: rows past the end of the index read the (allocated, unspecified) padding of
+    // the last tile — any byte is a valid code for the gathers, and those rows are masked at the survivor test
+    const unsigned lane_at = (unsigned)(wv * (R * 16 * 16) + l * (R * 4));
+    auto load_step = [&](int it, adc_u32x4v (&dst)[2]) {
+        const adc_u32x4v* cp = reinterpret_cast<const adc_u32x4v*>(tile + ((size_t)phase_of(it) * (TILE * 16) +
+                                                                          (size_t)(it / NPH) * (ROUND * 16) + lane_at));
+        dst[0] = cp[0];
+        dst[1] = cp[1];
     };
     adc_i32x4v acc[R];
     int buf = 0;
-    auto run_step = [&](int it, unsigned (&w)[R], unsigned (&wn)[R]) {
+    auto run_step = [&](int it, const adc_u32x4v (&w)[2], adc_u32x4v (&wn)[2]) {
         if (it % NPH == 0) {
 #pragma unroll
             for (int c = 0; c < R; ++c) acc[c] = adc_i32x4v{0, 0, 0, 0};
@@ -1505,12 +1518,15 @@ __global__ __launch_bounds__(THREADS) void adc_screen_q16_kernel(const uint8_t* 
             if (nx < nsteps) stage(phase_of(nx), buf ^ 1);   // the buffer just vacated
         }
         if (it + 1 < nsteps) load_step(it + 1, wn);
+        // Software pipeline over the chunks: the 4 gathers of chunk c + 1 are ISSUED before the 4 MFMAs of chunk c (the
+        // scheduler, left alone, reuses one register quad and waits for every gather: one LDS round trip per MFMA).
         adc_u32x4v ea[4], eb[4];
         auto gather = [&](int c, adc_u32x4v (&e)[4]) {
+            const unsigned wc = w[c >> 2][c & 3];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 unsigned addr;
-                asm("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_add_u32 %0, %0, 8, %3" : "=&v"(addr) : "v"(w[c]), "n"(8 * j), "v"(offb[j]));
+                asm("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_add_u32 %0, %0, 8, %3" : "=&v"(addr) : "v"(wc), "n"(8 * j), "v"(offb[j]));
                 e[j] = *reinterpret_cast<const adc_u32x4v __attribute__((address_space(3)))*>(addr);
             }
         };
@@ -1524,11 +1540,16 @@ __global__ __launch_bounds__(THREADS) void adc_screen_q16_kernel(const uint8_t* 
         gather(0, ea);
 #pragma unroll
         for (int c = 0; c < R; c += 2) {
-            if (c + 1 < R) gather(c + 1, eb);
+            __builtin_amdgcn_sched_barrier(0);
+            gather(c + 1, eb);
+            __builtin_amdgcn_sched_barrier(0);
             fold(c, ea);
+            __builtin_amdgcn_sched_barrier(0);
             if (c + 2 < R) gather(c + 2, ea);
-            if (c + 1 < R) fold(c + 1, eb);
+            __builtin_amdgcn_sched_barrier(0);
+            fold(c + 1, eb);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (it % NPH == NPH - 1) {
             int top = INT_MIN;
 #pragma unroll
@@ -1551,7 +1572,7 @@ __global__ __launch_bounds__(THREADS) void adc_screen_q16_kernel(const uint8_t* 
     };
     // prologue: first phase into buffer 0, the next distinct phase into buffer 1
     stage(phase_of(0), 0);
-    unsigned wa[R], wb[R];
+    adc_u32x4v wa[2], wb[2];
     load_step(0, wa);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1848,8 +1869,8 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
     if (CF && image != nullptr && adc_q16_for(M)) {
         if constexpr (CF) {
             // 16 queries per ds_read_b128 gather, phases of 16 sub-quantisers, double-buffered tables (adc_screen_q16_kernel)
-            constexpr int R = 8, TH = ADC_THREADS;
-            auto kern = adc_screen_q16_kernel<M, R, TH>;
+            auto kern = adc_screen_q16_kernel<M>;
+            constexpr int TH = ADC_Q16_WAVES * 64;
             constexpr int sl = 2 * RC_K * 256;
             const int groups = (nq + 15) / 16;
             hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, b.qstat, b.tint);

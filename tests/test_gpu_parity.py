@@ -1176,17 +1176,21 @@ def test_adc_scan_image_is_a_row_permutation():
         uses_q16 = lib.rc_adc_q16_describe(M, 0, 0, ctypes.byref(slot))
         n, T = codes.shape[0], 32768
         if uses_q16 == 1:
+            # [phase][round of 2048 rows][wave 16][lane = r + 16 g][chunk c 8][step j 4], row = 2048 round + 128 wave + 16 c + r
             assert flat.numel() == T * M
-            tile = flat.view(M // 16, T, 16).cpu().numpy()
+            tile = flat.view(M // 16, T // 2048, 16, 64, 8, 4).cpu().numpy()
             hc = codes.cpu().numpy()
-            want = np.empty((M // 16, n, 16), np.uint8)
+            seen = np.zeros_like(tile, dtype=bool)
             for rr in range(16):
                 for gq in range(4):
                     for j in range(4):
                         assert lib.rc_adc_q16_describe(M, rr + 16 * gq, j, ctypes.byref(slot)) == 1
+                        rows = np.arange(rr, n, 16)
+                        rd, wv_, cc = rows // 2048, (rows % 2048) // 128, (rows % 128) // 16
                         for ph in range(M // 16):
-                            want[ph, rr::16, 4 * gq + j] = hc[rr::16, 16 * ph + slot.value]
-            assert np.array_equal(tile[:, :n], want) and bool((tile[:, n:] == 255).all())
+                            assert np.array_equal(tile[ph, rd, wv_, rr + 16 * gq, cc, j], hc[rows, 16 * ph + slot.value])
+                            seen[ph, rd, wv_, rr + 16 * gq, cc, j] = True
+            assert bool((tile[~seen] == 255).all())
         elif M != 96:
             assert flat.numel() == img.numel() and torch.equal(flat.view_as(img), img)
         else:
