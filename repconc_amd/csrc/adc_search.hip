@@ -1503,10 +1503,6 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     adc_i32x4v acc[R];
     int buf = 0;
     auto run_step = [&](int it, const adc_u32x4v (&w)[2], adc_u32x4v (&wn)[2]) {
-        if (it % NPH == 0) {
-#pragma unroll
-            for (int c = 0; c < R; ++c) acc[c] = adc_i32x4v{0, 0, 0, 0};
-        }
         if (it > 0 && phase_of(it) != phase_of(it - 1)) {
             // phase change: this phase's tables were requested into the other buffer one segment ago
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces have landed
@@ -1530,11 +1526,13 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
                 e[j] = *reinterpret_cast<const adc_u32x4v __attribute__((address_space(3)))*>(addr);
             }
         };
+        const bool first = (it % NPH == 0);                   // block-uniform: the round's first step starts from zero
         auto fold = [&](int c, const adc_u32x4v (&e)[4]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const adc_i32x4v a = {(int)e[j][0], (int)e[j][1], (int)e[j][2], (int)e[j][3]};
-                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
+                if (j == 0 && first) acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, adc_i32x4v{0, 0, 0, 0}, 0, 0, 0);
+                else acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
             }
         };
         gather(0, ea);
@@ -1551,13 +1549,13 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
         }
         __builtin_amdgcn_sched_barrier(0);
         if (it % NPH == NPH - 1) {
-            int top = INT_MIN;
+            // A wave's round holds 128 rows x 16 queries: about every third round has a survivor (2e-4 per pair), so the
+            // test is made per CHUNK (one max3 pair + compare + ballot each) and only a chunk that has one is scanned.
+            const unsigned r0 = (unsigned)(it / NPH) * ROUND + (unsigned)(wv * R * 16);
 #pragma unroll
-            for (int c = 0; c < R; ++c) top = max(top, max(max(acc[c][0], acc[c][1]), max(acc[c][2], acc[c][3])));
-            if (__ballot(top >= tq)) {
-                const unsigned r0 = (unsigned)(it / NPH) * ROUND + (unsigned)(wv * R * 16);
-#pragma unroll
-                for (int c = 0; c < R; ++c) {
+            for (int c = 0; c < R; ++c) {
+                const int top = max(max(acc[c][0], acc[c][1]), max(acc[c][2], acc[c][3]));
+                if (__ballot(top >= tq)) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const unsigned n = r0 + 16u * c + 4u * g + e;   // D[row = 4 g + e][column = r]
