@@ -1378,6 +1378,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
 #define ADC_Q16_TILE 32768
 #define ADC_Q16_R 8                // chunks of 16 rows per wave and round
 #define ADC_Q16_WAVES 16           // waves per block: a round = 16 x 8 x 16 = 2048 rows
+#define ADC_Q16_SCAP 256           // survivor entries per wave held in LDS between flushes
 __host__ __device__ constexpr int adc_q16_pos(int h32) {
     return (h32 < 4) ? h32 : (h32 < 12) ? h32 - 4 : (h32 < 16) ? h32 - 8 : (h32 < 20) ? h32 - 8 : (h32 < 28) ? h32 - 12 : h32 - 16;
 }
@@ -1502,6 +1503,22 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     };
     adc_i32x4v acc[R];
     int buf = 0;
+    // per-wave survivor list in LDS: entries (row in tile << 4 | query column); flushed to the per-query id lists (one
+    // global atomic per entry, all of a flush in flight together) when 64 more might not fit, and at the end
+    constexpr int SCAP = ADC_Q16_SCAP;
+    unsigned* sbuf = reinterpret_cast<unsigned*>(smem + 2 * BUF) + wv * SCAP;
+    int scount = 0;                                          // wave-uniform
+    auto flush_survivors = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's list writes are in the LDS (in-order queue)
+        for (int i = l; i < scount; i += 64) {
+            const unsigned e = sbuf[i];
+            const int q = q0 + (int)(e & 15u);
+            const unsigned slot = atomicAdd(id_count + q, 1u);
+            if (slot < ADC_ID_CAP) ids[(size_t)q * ADC_ID_CAP + slot] = (unsigned)(t0 + (e >> 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // list reads done before it is overwritten
+        scount = 0;
+    };
     auto run_step = [&](int it, const adc_u32x4v (&w)[2], adc_u32x4v (&wn)[2]) {
         if (it > 0 && phase_of(it) != phase_of(it - 1)) {
             // phase change: this phase's tables were requested into the other buffer one segment ago
@@ -1551,6 +1568,8 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
         if (it % NPH == NPH - 1) {
             // A wave's round holds 128 rows x 16 queries: about every third round has a survivor (2e-4 per pair), so the
             // test is made per CHUNK (one max3 pair + compare + ballot each) and only a chunk that has one is scanned.
+            // Survivors go to the wave's LDS list (see flush_survivors): no global atomic — a ~2 us round trip — inside
+            // the loop, where one waiting wave holds up the other fifteen at the next phase change (9.7 -> 9.1 ms).
             const unsigned r0 = (unsigned)(it / NPH) * ROUND + (unsigned)(wv * R * 16);
 #pragma unroll
             for (int c = 0; c < R; ++c) {
@@ -1559,9 +1578,12 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const unsigned n = r0 + 16u * c + 4u * g + e;   // D[row = 4 g + e][column = r]
-                        if (acc[c][e] >= tq && n < nrows) {
-                            const unsigned slot = atomicAdd(id_count + myq, 1u);
-                            if (slot < ADC_ID_CAP) ids[(size_t)myq * ADC_ID_CAP + slot] = (unsigned)(t0 + n);
+                        const bool hit = acc[c][e] >= tq && n < nrows;
+                        const unsigned long long mask = __ballot(hit);
+                        if (mask) {                               // wave-uniform
+                            if (scount + 64 > SCAP) flush_survivors();
+                            if (hit) sbuf[scount + __popcll(mask & ((1ull << l) - 1ull))] = (n << 4) | (unsigned)r;
+                            scount += (int)__popcll(mask);
                         }
                     }
                 }
@@ -1584,6 +1606,7 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
         run_step(it, wa, wb);
         if (it + 1 < nsteps) run_step(it + 1, wb, wa);
     }
+    flush_survivors();
 }
 
 // One block per query: exact fp32 score (m ascending, from 0) of every screened row; rows with score >= tau go
@@ -1731,8 +1754,10 @@ extern "C" size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, in
     if (N <= 0 || M <= 0 || K != RC_K || nq <= 0 || k <= 0) return 0;
     return adc_layout(N, M, nq, false).total;
 }
-// Which M run the 16-query screen (adc_screen_q16_kernel) in the flat search.  The choice fixes the layout of the index's
-// flat-search image, so it is read ONCE per process: RC_ADC_Q16 = 0 (none) | all | unset (the default set below).
+// Which M run the 16-query screen (adc_screen_q16_kernel) in the flat search: all that have an image (M = 16/32/48/64/96:
+// 3.3 / 6.2 / 9.1 / 12.0 / 17.1 ms per 1200 queries x 8.84 M rows against 5.1 / 7.0 / 10.1 / 12.8 / 26.7 ms for the
+// 8-query screen).  The choice fixes the layout of the index's flat-search image, so it is read ONCE per process:
+// RC_ADC_Q16=0 selects the 8-query screens (development A/B).
 static bool adc_q16_for(int M) {
     static int mode = -1;                                    // 0 none, 1 default set, 2 all
     if (mode < 0) {
@@ -1740,7 +1765,8 @@ static bool adc_q16_for(int M) {
         mode = (!e || !*e) ? 1 : (!strcmp(e, "0") ? 0 : (!strcmp(e, "all") ? 2 : 1));
     }
     if (mode == 0 || !adc_cf_supported(M)) return false;
-    return mode == 2 ? true : (M == 48 || M == 96);
+    (void)mode;
+    return true;                                             // every M with an image: faster than the 8-query screen at all of them
 }
 // the flat-search image of a two-phase M is tile-blocked (whole tiles of adc_cf_tile_rows(M) rows); so is every image of
 // the 16-query screen (tiles of ADC_Q16_TILE rows)
@@ -1869,7 +1895,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             // 16 queries per ds_read_b128 gather, phases of 16 sub-quantisers, double-buffered tables (adc_screen_q16_kernel)
             auto kern = adc_screen_q16_kernel<M>;
             constexpr int TH = ADC_Q16_WAVES * 64;
-            constexpr int sl = 2 * RC_K * 256;
+            constexpr int sl = 2 * RC_K * 256 + ADC_Q16_WAVES * ADC_Q16_SCAP * 4;      // two table buffers + the survivor lists
             const int groups = (nq + 15) / 16;
             hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, b.qstat, b.tint);
             RC_LAUNCH_CHECK(h);

@@ -83,7 +83,8 @@ def test_adc_conflict_free_layout_properties():
                 assert len(banks) == 32, (M, s, half)                                           # (b)
     assert lib.rc_adc_cf_describe(24, 0, 0, C.byref(slot), C.byref(m), None, None) == -2     # RC_ESHAPE: no image for M=24
     # image sizes: N x M bytes, in whole 32768-row tiles for the tile-blocked layouts (M = 96; every M of the 16-query screen)
-    assert lib.rc_adc_scan_image_bytes(1000, 32) == 32000 and lib.rc_adc_scan_image_bytes(1000, 24) == 0
+    assert lib.rc_adc_scan_image_bytes(1000, 24) == 0
     assert lib.rc_adc_scan_image_bytes(1000, 96) == 32768 * 96 and lib.rc_adc_scan_image_bytes(40000, 96) == 2 * 32768 * 96
-    q16 = lib.rc_adc_q16_describe(48, 0, 0, C.byref(slot))
-    assert q16 in (0, 1) and lib.rc_adc_scan_image_bytes(1000, 48) == (32768 * 48 if q16 else 48000)
+    for MM in (16, 32, 48, 64):
+        q16 = lib.rc_adc_q16_describe(MM, 0, 0, C.byref(slot))
+        assert q16 in (0, 1) and lib.rc_adc_scan_image_bytes(1000, MM) == (32768 * MM if q16 else 1000 * MM)
