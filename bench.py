@@ -435,10 +435,10 @@ def main():
         scan_ms = ms_l.value / max(n_l.value, 1)
         adc_alg = per_rank * N_CORPUS * M          # N*M code bytes per query
         adc_ach = adc_alg / (scan_ms * 1e-3) / 1e9 if n_l.value else 0.0
-        # LDS gather roof ("then the bound is LDS gather rate"): one 8-byte table entry per (row,
-        # sub-quantiser, group of 8 queries), 256 CUs x 256 B/clk x 2.4 GHz for conflict-free ds_read_b64
+        # LDS gather roof ("then the bound is LDS gather rate"): one 16-byte table entry per (row,
+        # sub-quantiser, group of 16 queries), 256 CUs x 256 B/clk x 2.4 GHz for conflict-free ds_read_b128
         lds_peak = 256 * 256 * 2.4                                           # GB/s
-        lds_bytes = ((per_rank + 7) // 8) * N_CORPUS * M * 8
+        lds_bytes = ((per_rank + 15) // 16) * N_CORPUS * M * 16
         lds_ach = lds_bytes / (scan_ms * 1e-3) / 1e9 if n_l.value else 0.0
         out["adc"] = {
             "metric": "adc_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "k": k,
@@ -447,24 +447,28 @@ def main():
             "parallelism": f"index replicated, queries split x{world}",
             "parity": "ids and score bits equal the repo's C restatement of Faiss IndexPQ search (tests); Faiss itself is "
                       "not available offline: Faiss-side tie order / last-ulp LUT rounding unpinned",
-            "roofline": {"kernel": "adc_screen_cf_kernel<48,1,4> (8-bit screening scan: conflict-free LDS gathers of "
-                                   "8-query byte tables, 16x16x64 i8 MFMA accumulation)",
+            "roofline": {"kernel": "adc_screen_q16_kernel<48> (8-bit screening scan: conflict-free ds_read_b128 gathers of "
+                                   "16-query byte tables in phases of 16 sub-quantisers, tables double-buffered by LDS-DMA, "
+                                   "16x16x64 i8 MFMA accumulation)",
                          "bound": "lds-gather", "achieved": round(lds_ach, 1), "peak": round(lds_peak, 1), "unit": "GB/s",
                          "frac": round(lds_ach / lds_peak, 4), "lds_bytes_per_launch": lds_bytes,
                          "avg_launch_ms": round(scan_ms, 3), "launches_timed": n_l.value,
                          "measured_gather_roof": {
-                             "lds_alone_cycles_per_gather_per_cu": 2.03, "with_screen_address_and_mfma_cycles": 4.0,
+                             "lds_alone_cycles_per_b128_gather_per_cu": 4.05, "with_screen_address_and_mfma_cycles": 5.55,
                              "note": "tools/ubench_lds_gather.hip, round 3 (profiles/r03a_ubench_lds_gather.txt; whole-launch "
                                      "timing at a measured 2.3-2.4 GHz - the round-2 table timed wave 0 only and was wrong): "
-                                     "random conflict-free ds_read_b64 gathers with precomputed addresses run at 2.03 "
-                                     "cycles per wave-instruction per CU = 252 B/clk = the nominal roof used in `frac`; with "
-                                     "the screen's two address instructions per gather and its MFMAs the same loop needs "
-                                     "4.0 cycles (VALU + matrix-pipe issue, not the LDS array): the screen is issue-bound"},
+                                     "random conflict-free ds_read_b128 gathers with precomputed addresses run at 4.05 "
+                                     "cycles per wave-instruction per CU = 253 B/clk = the nominal roof used in `frac`; with "
+                                     "the screen's two address instructions and one i8 MFMA per gather the same loop needs "
+                                     "5.55 cycles (instruction issue, not the LDS array); the kernel itself runs at ~12 per "
+                                     "gather: a timing experiment without the phase-change barrier (wrong results) ran at "
+                                     "3.6 ms per launch against 9.1 ms - the synchronised table hand-over between the two "
+                                     "LDS buffers is what is left (DESIGN.md 4.3)"},
                          "hbm_equivalent": {"algorithmic_bytes_per_launch": adc_alg, "achieved_GBs": round(adc_ach, 1),
                                             "note": "N*M code bytes per query (SURVEY 8d) / kernel time: 8 queries share every "
                                                     "code read and tiles are re-read from L2, so this exceeds the HBM peak and is "
                                                     "not a roofline"},
-                         "traffic": pmc_traffic("adc_screen_cf_kernel"),
+                         "traffic": pmc_traffic("adc_screen_q16_kernel"),
                          "traffic_source": "profiles/pmc_summary.json, not this run"},
         }
 

@@ -11,7 +11,7 @@ note = sys.argv[3] if len(sys.argv) > 3 else ""
 B, M, K, NC, NQ, NB = 49152, 48, 256, 8841823, 1200, 1 << 20
 ALG = {  # SURVEY 8(d) per-unit bytes x units per launch
     "sk_sweep_kernel": ("sk_sweep2_kernel<2, true>", B * M * K * 4),
-    "adc_screen_cf_kernel": ("adc_screen_cf_kernel<48, 1, 4>", NQ * NC * M),
+    "adc_screen_q16_kernel": ("adc_screen_q16_kernel<48>", NQ * NC * M),
     "assign_mfma_kernel": ("assign_mfma_kernel<16>", NB * (768 * 4 + M)),
 }
 out = {"_how": "tools/pmc_collect.sh: rocprofv3 --pmc <group> --kernel-trace, one pass per counter group, over "

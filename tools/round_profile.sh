@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats_bench_steps3.csv
 grep -h "^{\"metric\"" $O/bench_prof.out > $O/${TAG}_bench_under_rocprof.json   # the bench line of the PROFILED run (its HIP-event average must match the CSV)
 tools/pmc_collect.sh $O/${TAG}_pmc_counters_raw.json -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-per-rank --no-opq --adc-batches 1 > $O/pmc.out 2>&1
-python tools/pmc_summary.py $O/${TAG}_pmc_counters_raw.json $O/pmc_summary.json "MI355X, round 2, profile $TAG." >> $O/pmc.out 2>&1
+python tools/pmc_summary.py $O/${TAG}_pmc_counters_raw.json $O/pmc_summary.json "MI355X, round 3, profile $TAG." >> $O/pmc.out 2>&1
 python tools/config_bench.py 2>&1 | grep constrained > $O/${TAG}_config_bench.txt
 python tools/adc_quick_bench.py 48 96 64 32 16 2>&1 | grep QPS >> $O/${TAG}_config_bench.txt
 tail -3 $O/${TAG}_pytest_gpu.txt; cat $O/${TAG}_bench.json | cut -c1-600
