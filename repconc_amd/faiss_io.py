@@ -42,25 +42,54 @@ def write_index(index: PQIndex, path: str):
         f.write(struct.pack("<iBi", 0, 0, 0))          # ST_PQ, encode_signs=false, polysemous_ht=0
 
 
-def read_index(path: str, device=None) -> PQIndex:
+def parse_index_file(path: str) -> dict:
+    """Strict reader of the byte layout above (no device involved): d, M, ntotal, metric, is_trained, centroids
+    [M,256,dsub] float32, codes [ntotal,M] uint8.  Anything that does not fit the layout — another fourcc, sizes that do
+    not match d / M / ntotal, a short file, bytes after the last field — raises ValueError: the layout was restated from
+    the published writer, not checked against a Faiss-written file, so a mismatch must be loud, never a silently wrong
+    index."""
+    def take(f, n, what):
+        b = f.read(n)
+        if len(b) != n:
+            raise ValueError(f"truncated IndexPQ file: {what} needs {n} bytes, {len(b)} left")
+        return b
+
     with open(path, "rb") as f:
-        if f.read(4) != b"IxPq":
-            raise ValueError("not a Faiss IndexPQ file (fourcc IxPq expected)")
-        d, ntotal, _, _, trained, metric = struct.unpack("<iqqqBi", f.read(4 + 8 * 3 + 1 + 4))
+        fourcc = f.read(4)
+        if fourcc != b"IxPq":
+            raise ValueError(f"not a Faiss IndexPQ file (fourcc {fourcc!r}, IxPq expected)")
+        d, ntotal, _, _, trained, metric = struct.unpack("<iqqqBi", take(f, 4 + 8 * 3 + 1 + 4, "index header"))
         if metric > 1:
-            f.read(4)
-        d2, M, nbits = struct.unpack("<QQQ", f.read(24))
-        if d2 != d or nbits != 8:
-            raise ValueError(f"unsupported ProductQuantizer (d={d2}, nbits={nbits})")
-        (n,) = struct.unpack("<Q", f.read(8))
-        cent = np.frombuffer(f.read(4 * n), dtype="<f4")
-        (n,) = struct.unpack("<Q", f.read(8))
-        codes = np.frombuffer(f.read(n), dtype=np.uint8)
-    index = PQIndex(d, M, 8, metric, device=device)
-    index.set_centroids(torch.from_numpy(cent.reshape(M, 256, d // M).copy()))
-    index.is_trained = bool(trained)
-    if ntotal:
-        index.add_codes(torch.from_numpy(codes.reshape(ntotal, M).copy()))
+            take(f, 4, "metric_arg")
+        if metric not in (0, 1) or trained not in (0, 1) or d <= 0 or ntotal < 0:
+            raise ValueError(f"implausible IndexPQ header (d={d}, ntotal={ntotal}, is_trained={trained}, metric={metric})")
+        d2, M, nbits = struct.unpack("<QQQ", take(f, 24, "ProductQuantizer header"))
+        if d2 != d or nbits != 8 or M == 0 or d % M != 0:
+            raise ValueError(f"unsupported ProductQuantizer (d={d2} vs index d={d}, M={M}, nbits={nbits})")
+        (n,) = struct.unpack("<Q", take(f, 8, "centroid vector size"))
+        if n != 256 * d:
+            raise ValueError(f"centroid vector holds {n} floats, M*256*dsub = {256 * d} expected")
+        cent = np.frombuffer(take(f, 4 * n, "centroids"), dtype="<f4")
+        (n,) = struct.unpack("<Q", take(f, 8, "code vector size"))
+        if n != ntotal * M:
+            raise ValueError(f"code vector holds {n} bytes, ntotal*M = {ntotal * M} expected")
+        codes = np.frombuffer(take(f, n, "codes"), dtype=np.uint8)
+        search_type, encode_signs, polysemous_ht = struct.unpack("<iBi", take(f, 9, "search_type / encode_signs / polysemous_ht"))
+        if search_type != 0:
+            raise ValueError(f"IndexPQ search_type {search_type}: only ST_PQ (0) is supported")
+        if f.read(1):
+            raise ValueError("bytes after the last IndexPQ field: not the layout this reader knows")
+    return {"d": d, "M": int(M), "ntotal": int(ntotal), "metric": metric, "is_trained": bool(trained),
+            "centroids": cent.reshape(int(M), 256, d // int(M)).copy(), "codes": codes.reshape(int(ntotal), int(M)).copy()}
+
+
+def read_index(path: str, device=None) -> PQIndex:
+    p = parse_index_file(path)
+    index = PQIndex(p["d"], p["M"], 8, p["metric"], device=device)
+    index.set_centroids(torch.from_numpy(p["centroids"]))
+    index.is_trained = p["is_trained"]
+    if p["ntotal"]:
+        index.add_codes(torch.from_numpy(p["codes"]))
     return index
 
 
