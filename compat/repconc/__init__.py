@@ -25,14 +25,25 @@ __version__ = getattr(_real, "__version__", "0")
 
 
 class _AliasLoader(importlib.abc.Loader):
+    _KEEP = ("__spec__", "__loader__", "__package__", "__name__", "__file__", "__path__", "__cached__")
+
     def __init__(self, module):
         self._module = module
+        self._saved = {}
 
     def create_module(self, spec):
-        return self._module                      # the real module object: state is shared, not duplicated
+        # the real module object: state is shared, not duplicated.  importlib's module_from_spec() now overwrites its
+        # import attributes with the ALIAS spec (name repconc.X, this loader); they are put back in exec_module so that
+        # relative imports inside repconc_amd.X, importlib.reload and spec-based tooling keep seeing the real module
+        self._saved = {k: getattr(self._module, k) for k in self._KEEP if hasattr(self._module, k)}
+        return self._module
 
     def exec_module(self, module):
-        pass
+        for k, v in self._saved.items():
+            try:
+                setattr(module, k, v)
+            except (AttributeError, TypeError):
+                pass
 
 
 class _AliasFinder(importlib.abc.MetaPathFinder):

@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
                                                                             const uint8_t* __restrict__ qlut,
                                                                             const int* __restrict__ tint, int nq, int groups,
                                                                             unsigned* __restrict__ id_count,
-                                                                            unsigned* __restrict__ ids) {
+                                                                            unsigned* __restrict__ ids, int flags) {
     constexpr int R = ADC_Q16_R, NWAVES = ADC_Q16_WAVES;
     constexpr int NPH = M / 16, ROUND = NWAVES * R * 16, TILE = ADC_Q16_TILE;
     constexpr int BUF = RC_K * 256;                           // 64 KiB: one phase of one group
@@ -1475,6 +1475,7 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     }
     adc_i32x4v bsel = {0, 0, 0, 0};                           // B[k][n = r] = [k mod 16 == r]
     bsel[r >> 2] = 1 << (8 * (r & 3));
+    const bool rc_q16_setprio = (flags & 1) != 0;
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     unsigned off[4], offb[4];                                 // this lane's slot offsets (absolute LDS address): buffer 0 / current buffer
 #pragma unroll
@@ -1555,6 +1556,15 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
         gather(0, ea);
 #pragma unroll
         for (int c = 0; c < R; c += 2) {
+            // Progress-proportional priority: the arbiter serves the OLDEST ready wave first, so without this wave 0 finishes
+            // a segment in a third of the time the block needs and the last waves run alone, latencies exposed, while
+            // the others wait at the phase change.  A wave that is behind in its segment outranks one that is ahead.
+            if (rc_q16_setprio) {
+                if (c == 0) __builtin_amdgcn_s_setprio(3);
+                else if (c == 2) __builtin_amdgcn_s_setprio(2);
+                else if (c == 4) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             gather(c + 1, eb);
             __builtin_amdgcn_sched_barrier(0);
@@ -1906,7 +1916,8 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             const unsigned tiles16 = (unsigned)((N + ADC_Q16_TILE - 1) / ADC_Q16_TILE);
             const unsigned gpx = (unsigned)(groups + 7) / 8u;
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-            hipLaunchKernelGGL(kern, dim3(8u * gpx * tiles16), dim3(TH), sl, s, image, N, b.qlut, b.tint, nq, groups, b.idcnt, b.ids);
+            hipLaunchKernelGGL(kern, dim3(8u * gpx * tiles16), dim3(TH), sl, s, image, N, b.qlut, b.tint, nq, groups, b.idcnt, b.ids,
+                               rc_env_int("RC_ADC_Q16_PRIO", 1));
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             RC_LAUNCH_CHECK(h);
         }

@@ -191,3 +191,23 @@ def test_indexpq_file_reader_is_strict(tmp_path):
     bad_m = bytearray(raw); off = 4 + 4 + 8 * 3 + 1 + 4 + 8              # M field of the ProductQuantizer header
     bad_m[off:off + 8] = (3).to_bytes(8, "little")
     check(bytes(bad_m), "ProductQuantizer")
+
+
+def test_alias_import_keeps_the_real_modules_spec():
+    """`import repconc.X` hands out the repconc_amd.X module object; its __spec__ / __name__ / __package__ must stay the
+    real ones (module_from_spec would otherwise leave the alias spec behind: relative imports inside the module then warn
+    about __package__ != __spec__.parent and importlib.reload breaks)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import warnings; warnings.simplefilter('error')\n"
+            "import repconc.models.repconc.modeling_repconc as a\n"
+            "import repconc_amd.models.repconc.modeling_repconc as b\n"
+            "assert a is b and b.__spec__.name == 'repconc_amd.models.repconc.modeling_repconc', b.__spec__\n"
+            "assert b.__name__ == 'repconc_amd.models.repconc.modeling_repconc' and b.__package__ == 'repconc_amd.models.repconc'\n"
+            "import importlib; importlib.reload(b)\n"
+            "import repconc.sharded_search as s; import repconc_amd.sharded_search as t; assert s is t and t.__spec__.name == 'repconc_amd.sharded_search'\n"
+            "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "compat") + os.pathsep + root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
