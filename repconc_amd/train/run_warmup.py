@@ -131,6 +131,8 @@ def procrustes_rotation(P: torch.Tensor, tol: float = 1e-13, max_iter: int = 160
     eye = torch.eye(n, dtype=P.dtype, device=P.device)
     ok = False
     first_check = 47                                            # OPQ's matrices need 45 - 60 steps: no reads before that
+    # one step = two library calls (G = X^T X, then X <- 1.5 X - 0.5 X G as ONE GEMM with its epilogue): the host issues
+    # ~110 launches per call instead of ~280 — on a slow host the round was launch-bound (17 - 31 ms against 7 ms of device time)
     for it in range(max_iter):
         G = X.T @ X
         if it >= first_check and (it - first_check) % 8 == 0:
@@ -138,12 +140,11 @@ def procrustes_rotation(P: torch.Tensor, tol: float = 1e-13, max_iter: int = 160
             if not (err == err) or err == float("inf"):
                 break                                           # singular / non-finite input: SVD below
             if err < tol ** 0.5:                                # quadratic: two more steps bring it far below tol
-                X = 1.5 * X - 0.5 * (X @ G)
-                G = X.T @ X
-                X = 1.5 * X - 0.5 * (X @ G)
+                X = torch.addmm(X, X, G, beta=1.5, alpha=-0.5)
+                X = torch.addmm(X, X, X.T @ X, beta=1.5, alpha=-0.5)
                 ok = True
                 break
-        X = 1.5 * X - 0.5 * (X @ G)
+        X = torch.addmm(X, X, G, beta=1.5, alpha=-0.5)
     if ok:
         ok = float((X.T @ X - eye).abs().max()) < 1e-9
         if ok:
@@ -185,7 +186,9 @@ def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, 
     n, D = x.shape
     if R0 is None:
         g = torch.Generator(device="cpu").manual_seed(seed)
-        R0 = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]        # same seed on every rank
+        # the same seeded Gaussian matrix on every rank, orthogonalised on the device (a 768 x 768 fp64 QR is tens of
+        # milliseconds on a host core, a few on the GPU; every rank of a job runs the same library on the same hardware)
+        R0 = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64).to(x.device))[0]
     R = R0.float().to(x.device).contiguous()
     C = None
     mses = []
