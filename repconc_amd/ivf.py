@@ -212,9 +212,36 @@ class IVFPQIndex:
                                      p(probes), p(base), p(count), nq, nprobe, stride, int(k), p(scores), p(ids),
                                      p(status), p(ws), wsb, s), "rc_ivf_search", h)
         if int(status.item()) & 2:
-            raise _lib.RepconcHipError("IVF search: more than 16384 rows tie at the k-th score")
+            # more than 16384 probed rows tie at the k-th score (duplicated passages): the path without any list
+            scores, ids = self._search_exact_probed(q, probes, int(k))
         if as_numpy:
             return scores.cpu().numpy(), ids.cpu().numpy()
+        return scores, ids
+
+    def _search_exact_probed(self, q: torch.Tensor, probes: torch.Tensor, k: int):
+        """The answer for ANY index content (the flat search's `rc_adc_search_exact`, query by query, over the rows of the
+        probed cells): exact scores of every probed row, the k best in (score desc, corpus id asc) order by radix select.
+        Slow — one gather of the probed rows per query — and only reached when the faster paths cannot decide (thousands of
+        identical rows in the probed cells)."""
+        nq = q.shape[0]
+        scores = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=self.device)
+        ids = torch.full((nq, k), -1, dtype=torch.int64, device=self.device)
+        off = self.list_off
+        for j in range(nq):
+            cells = probes[j].long()
+            a, b = off[cells], off[cells + 1]
+            rows = torch.cat([torch.arange(int(x), int(y), device=self.device) for x, y in zip(a.tolist(), b.tolist())]) \
+                if len(cells) else torch.empty(0, dtype=torch.int64, device=self.device)
+            if rows.numel() == 0:
+                continue
+            corpus = self.ids[rows]
+            order = torch.argsort(corpus)                        # local row order = corpus id order: the search's tie rule
+            rows, corpus = rows[order], corpus[order]
+            sub = self.codes[rows].contiguous()
+            s, i = ops.adc_search_exact(sub, self.pq_centroids, q[j:j + 1], k)
+            valid = i[0] >= 0
+            scores[j] = s[0]
+            ids[j, valid] = corpus[i[0][valid]]
         return scores, ids
 
     # ---- list-centric search
@@ -258,7 +285,8 @@ class IVFPQIndex:
             if st == 0:
                 return scores, ids
             slack = max(slack, 0.0) * 3.0 + 2.0 if (st & 1) else max(slack / 3.0, 0.0)
-        raise _lib.RepconcHipError(f"IVF candidate selection did not converge (status {st})")
+        # no slack gives every query a usable candidate list (degenerate cells): the per-query exact scan decides
+        return self.search(q, k, nprobe, method="scan")
 
     def _search_lists_host_plan(self, q: torch.Tensor, probes: torch.Tensor, k: int, nprobe: int, sel_slack: float = 6.0,
                                 max_retries: int = 3):
@@ -319,4 +347,4 @@ class IVFPQIndex:
             if st == 0:
                 return scores, ids
             slack = max(slack, 0.0) * 3.0 + 2.0 if (st & 1) else max(slack / 3.0, 0.0)
-        raise _lib.RepconcHipError(f"IVF candidate selection did not converge (status {st})")
+        return self.search(q, k, nprobe, method="scan")

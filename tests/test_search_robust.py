@@ -146,3 +146,26 @@ def test_in_place_centroid_write_reaches_every_part_of_a_multi_index(mode):
     ws, wi = c_oracle.adc_search(codes, C2, q, 50)
     _same(s, i, ws, wi)
     assert np.array_equal(faiss.vector_to_array(multi.pq.centroids), C2.ravel())
+
+
+@pytest.mark.parametrize("method", ["lists", "scan"])
+def test_ivf_search_never_raises_on_degenerate_cells(method):
+    """IVF cells full of identical rows (duplicated passages): the list-centric screen and the per-query scan both hand
+    over to the exact path instead of raising; answers equal the brute-force oracle (score desc, corpus id asc)."""
+    from oracle import pq_oracle
+    from repconc_amd.ivf import IVFPQIndex
+    M, nlist, N, nq, k = 48, 16, 60000, 5, 200
+    C, base, q = _case(M, 3, nq, seed=31)
+    rng = np.random.default_rng(32)
+    codes = base[rng.integers(0, 3, N)]                           # three distinct rows only
+    cells = rng.integers(0, nlist, N)
+    coarse = synth.gaussian(33, (nlist, 768))
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(_t(C))
+    ivf.coarse = _t(coarse)
+    ivf.set_lists(_t(codes), _t(cells))
+    for nprobe in (4, nlist):
+        s, i = ivf.search(_t(q), k, nprobe, method=method)
+        ws, wi = pq_oracle.ivf_search(q, C, codes, cells, coarse, k, nprobe)
+        assert np.array_equal(i.cpu().numpy(), wi), (method, nprobe)
+        assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
