@@ -32,6 +32,8 @@ class PQIndex:
         assert nbits == 8, "256 centroids per sub-quantiser (evaluate_repconc.py:80)"
         assert d % M == 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type == "cuda" and self.device.index is None:        # "cuda" -> the current device, by index
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.metric_type = metric
         self.is_trained = False
         self.ntotal = 0

@@ -71,6 +71,8 @@ def coarse_assign(x: torch.Tensor, cent: torch.Tensor, chunk: int = 1 << 20) -> 
 class IVFPQIndex:
     def __init__(self, d: int, M: int, nlist: int, device: Optional[torch.device] = None):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type == "cuda" and self.device.index is None:        # "cuda" -> the current device, by index
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.d, self.M, self.nlist = d, M, nlist
         self.coarse = None                                                  # [nlist, d]
         self.pq_centroids = torch.zeros((M, 256, d // M), dtype=torch.float32, device=self.device)
