@@ -284,8 +284,9 @@ def main():
             torch.cuda.synchronize()
             exchange = {"transport": chosen, "bytes_per_rank": rows.numel() * 8,
                         "us_per_allgather": round(max_over_ranks(e0.elapsed_time(e1)) * 1e3 / 200, 2),
-                        "what": "200 back-to-back rc_comm_allgather calls of one chain's row sums (push kernel + wait kernel "
-                                "+ copy-out); inside the solve the two chains overlap this with the other chain's sweep"}
+                        "what": "200 back-to-back rc_comm_allgather calls of one chain's row sums (fused push + wait "
+                                "kernel, copy-out); inside the solve (no copy-out) the two chains overlap this with the other "
+                                "chain's sweep"}
             barrier()
         del xs_loc, c_staged, gathered
 

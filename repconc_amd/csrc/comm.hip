@@ -177,6 +177,39 @@ __global__ __launch_bounds__(256) void ipc_push_kernel(const char* __restrict__ 
                                __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// push and wait in ONE launch (the solve's exchange: one kernel per iteration and chain instead of two): every block pushes
+// its share and signals as ipc_push_kernel does; block (0, 0) then waits for the LOCAL counter like ipc_wait_kernel.  The
+// waiting block holds one wave; all pushes of this rank are issued before it starts to wait, so two ranks cannot wait for
+// each other's pushes.
+__global__ __launch_bounds__(256) void ipc_pushwait_kernel(const char* __restrict__ src, size_t bytes, ipc_peers P, size_t region_off,
+                                                           size_t slot_off, size_t counter_off, unsigned long long* __restrict__ counter,
+                                                           unsigned long long want, int* __restrict__ flags, int* __restrict__ status,
+                                                           long long timeout_ticks) {
+    char* dst = P.p[blockIdx.y] + region_off + slot_off;
+    const size_t n16 = bytes / 16;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);       // the solve's row sums: 16-byte aligned, a multiple of 16 bytes
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d4[i] = s4[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(P.p[blockIdx.y] + counter_off), 1ull, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        bool ok = true;
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > timeout_ticks) { ok = false; break; }
+        }
+        __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok) {
+            if (flags) atomicOr(flags, RC_FLAG_COMM);
+            atomicOr(status, RC_FLAG_COMM);
+        }
+    }
+}
+
 __global__ void ipc_wait_kernel(unsigned long long* __restrict__ counter, unsigned long long want, int* __restrict__ flags,
                                 int* __restrict__ status, long long timeout_ticks) {
     const long long t0 = wall_clock64();                     // constant 100 MHz
@@ -216,6 +249,15 @@ int ipc_exchange(rc_handle_t h, int ch, unsigned long long n, const void* src, s
     ipc_peers P;
     for (int r = 0; r < RC_IPC_MAX_WORLD; ++r) P.p[r] = r < world ? h->ipc.peer[r] : nullptr;
     const size_t roff = ipc_region_off(world, ch, par), coff = ipc_counter_off(world, ch, par);
+    if (bytes && bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && rc_env_int("RC_IPC_FUSED", 1) != 0) {
+        hipLaunchKernelGGL(ipc_pushwait_kernel, dim3(IPC_PUSH_BLOCKS, world), dim3(256), 0, s, (const char*)src, bytes, P, roff,
+                           (size_t)rank * bytes, coff, (unsigned long long*)(h->ipc.mine + coff),
+                           (unsigned long long)IPC_PUSH_BLOCKS * world, flags, (int*)(h->ipc.mine + ipc_status_off(world)),
+                           ipc_timeout_ticks());
+        RC_LAUNCH_CHECK(h);
+        *region = h->ipc.mine + roff;
+        return RC_OK;
+    }
     if (bytes)
         hipLaunchKernelGGL(ipc_push_kernel, dim3(IPC_PUSH_BLOCKS, world), dim3(256), 0, s, (const char*)src, bytes, P, roff,
                            (size_t)rank * bytes, coff);
