@@ -1375,9 +1375,18 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
 // ADC_Q16_TILE rows, phase-major inside a tile: a wave's code load for 16 rows is 256 contiguous bytes).
 // Accumulation: v_mfma_i32_16x16x64_i8 with A = the lane's 16 gathered bytes (one sub-quantiser x 16 queries), B[k][n] =
 // [k mod 16 == n]: D[row][query] += sum over the row's four lanes.  Everything downstream is unchanged.
+#ifndef ADC_Q16_TILE
 #define ADC_Q16_TILE 32768
-#define ADC_Q16_R 8                // chunks of 16 rows per wave and round
-#define ADC_Q16_WAVES 16           // waves per block: a round = 16 x 8 x 16 = 2048 rows
+#endif
+#ifndef ADC_Q16_R
+#define ADC_Q16_R 8                // chunks of 16 rows per wave and round (16: accumulators kept as int16 pairs between phases)
+#endif
+#ifndef ADC_Q16_WAVES
+#define ADC_Q16_WAVES 16           // waves per block: a round = WAVES x R x 16 rows
+#endif
+#ifndef ADC_Q16_PACK
+#define ADC_Q16_PACK 0             // 1: accumulators kept as int16 pairs between phases (more chunks per wave in 128 VGPRs)
+#endif
 #define ADC_Q16_SCAP 256           // survivor entries per wave held in LDS between flushes
 __host__ __device__ constexpr int adc_q16_pos(int h32) {
     return (h32 < 4) ? h32 : (h32 < 12) ? h32 - 4 : (h32 < 16) ? h32 - 8 : (h32 < 20) ? h32 - 8 : (h32 < 28) ? h32 - 12 : h32 - 16;
@@ -1446,7 +1455,9 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     constexpr int R = ADC_Q16_R, NWAVES = ADC_Q16_WAVES;
     constexpr int NPH = M / 16, ROUND = NWAVES * R * 16, TILE = ADC_Q16_TILE;
     constexpr int BUF = RC_K * 256;                           // 64 KiB: one phase of one group
-    static_assert(TILE % ROUND == 0 && R == 8, "whole rounds per tile; a lane's codes of a step = two 16-byte loads");
+    static_assert(TILE % ROUND == 0 && R % 4 == 0, "whole rounds per tile; a lane's codes of a step = R / 4 16-byte loads");
+    constexpr int NV = R / 4;                                 // 16-byte code loads per lane and step
+    constexpr bool PACK = ADC_Q16_PACK != 0;                  // accumulators as int16 pairs between phases (|sum| <= 128 M)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     const int r = l & 15, g = l >> 4;
@@ -1460,11 +1471,12 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     auto stage = [&](int phase, int buf) {
         const uint8_t* src = qsrc + (size_t)phase * BUF;
 #pragma unroll
-        for (int i = 0; i < BUF / 1024 / NWAVES; ++i) {
+        for (int i = 0; i < (BUF / 1024 + NWAVES - 1) / NWAVES; ++i) {
             const int piece = i * NWAVES + wv;               // wave-uniform
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 1024 + l * 16),
-                                             (__attribute__((address_space(3))) void*)(smem + (size_t)buf * BUF + (size_t)piece * 1024),
-                                             16, 0, 0);
+            if (piece < BUF / 1024)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 1024 + l * 16),
+                                                 (__attribute__((address_space(3))) void*)(smem + (size_t)buf * BUF + (size_t)piece * 1024),
+                                                 16, 0, 0);
         }
     };
     int tq = INT_MAX, myq = -1;
@@ -1496,13 +1508,14 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     // this lane's 32 bytes of codes of step `it`: rows past the end of the index read the (allocated, unspecified) padding of
     // the last tile — any byte is a valid code for the gathers, and those rows are masked at the survivor test
     const unsigned lane_at = (unsigned)(wv * (R * 16 * 16) + l * (R * 4));
-    auto load_step = [&](int it, adc_u32x4v (&dst)[2]) {
+    auto load_step = [&](int it, adc_u32x4v (&dst)[NV]) {
         const adc_u32x4v* cp = reinterpret_cast<const adc_u32x4v*>(tile + ((size_t)phase_of(it) * (TILE * 16) +
                                                                           (size_t)(it / NPH) * (ROUND * 16) + lane_at));
-        dst[0] = cp[0];
-        dst[1] = cp[1];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dst[v] = cp[v];
     };
-    adc_i32x4v acc[R];
+    adc_i32x4v acc[PACK ? 1 : R];
+    unsigned accp[PACK ? R : 1][2];                           // PACK: (acc0 | acc1 << 16), (acc2 | acc3 << 16)
     int buf = 0;
     // per-wave survivor list in LDS: entries (row in tile << 4 | query column); flushed to the per-query id lists (one
     // global atomic per entry, all of a flush in flight together) when 64 more might not fit, and at the end
@@ -1520,7 +1533,24 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // list reads done before it is overwritten
         scount = 0;
     };
-    auto run_step = [&](int it, const adc_u32x4v (&w)[2], adc_u32x4v (&wn)[2]) {
+    // survivor test of one chunk's sums (D[row = 4 g + e][column = r]); survivors go to the wave's LDS list
+    auto test_chunk = [&](const adc_i32x4v& v, unsigned rbase) {
+        const int top = max(max(v[0], v[1]), max(v[2], v[3]));
+        if (__ballot(top >= tq)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned n = rbase + 4u * g + e;
+                const bool hit = v[e] >= tq && n < nrows;
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {                                       // wave-uniform
+                    if (scount + 64 > SCAP) flush_survivors();
+                    if (hit) sbuf[scount + __popcll(mask & ((1ull << l) - 1ull))] = (n << 4) | (unsigned)r;
+                    scount += (int)__popcll(mask);
+                }
+            }
+        }
+    };
+    auto run_step = [&](int it, const adc_u32x4v (&w)[NV], adc_u32x4v (&wn)[NV]) {
         if (it > 0 && phase_of(it) != phase_of(it - 1)) {
             // phase change: this phase's tables were requested into the other buffer one segment ago
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces have landed
@@ -1545,12 +1575,34 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             }
         };
         const bool first = (it % NPH == 0);                   // block-uniform: the round's first step starts from zero
+        const bool last = (it % NPH == NPH - 1);
+        const unsigned r0 = (unsigned)(it / NPH) * ROUND + (unsigned)(wv * R * 16);
         auto fold = [&](int c, const adc_u32x4v (&e)[4]) {
+            if constexpr (!PACK) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const adc_i32x4v a = {(int)e[j][0], (int)e[j][1], (int)e[j][2], (int)e[j][3]};
-                if (j == 0 && first) acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, adc_i32x4v{0, 0, 0, 0}, 0, 0, 0);
-                else acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const adc_i32x4v a = {(int)e[j][0], (int)e[j][1], (int)e[j][2], (int)e[j][3]};
+                    if (j == 0 && first) acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, adc_i32x4v{0, 0, 0, 0}, 0, 0, 0);
+                    else acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
+                }
+            } else {
+                // the chunk's sums live as two int16 pairs between phases: unpacked into the first MFMA's C, packed again after
+                // the fourth (v_perm), tested right here in the round's last phase
+                adc_i32x4v v = {0, 0, 0, 0};
+                if (!first)
+                    v = adc_i32x4v{((int)(accp[c][0] << 16)) >> 16, ((int)accp[c][0]) >> 16, ((int)(accp[c][1] << 16)) >> 16,
+                                   ((int)accp[c][1]) >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const adc_i32x4v a = {(int)e[j][0], (int)e[j][1], (int)e[j][2], (int)e[j][3]};
+                    v = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, v, 0, 0, 0);
+                }
+                if (last) {
+                    test_chunk(v, r0 + 16u * c);
+                } else {
+                    accp[c][0] = __builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x05040100u);
+                    accp[c][1] = __builtin_amdgcn_perm((unsigned)v[3], (unsigned)v[2], 0x05040100u);
+                }
             }
         };
         gather(0, ea);
@@ -1561,9 +1613,9 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             // the others wait at the phase change.  A wave that is behind in its segment outranks one that is ahead.
             if (rc_q16_setprio) {
                 if (c == 0) __builtin_amdgcn_s_setprio(3);
-                else if (c == 2) __builtin_amdgcn_s_setprio(2);
-                else if (c == 4) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
+                else if (c == R / 4) __builtin_amdgcn_s_setprio(2);
+                else if (c == R / 2) __builtin_amdgcn_s_setprio(1);
+                else if (c == 3 * R / 4) __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
             gather(c + 1, eb);
@@ -1575,34 +1627,20 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             fold(c + 1, eb);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (it % NPH == NPH - 1) {
-            // A wave's round holds 128 rows x 16 queries: about every third round has a survivor (2e-4 per pair), so the
-            // test is made per CHUNK (one max3 pair + compare + ballot each) and only a chunk that has one is scanned.
-            // Survivors go to the wave's LDS list (see flush_survivors): no global atomic — a ~2 us round trip — inside
-            // the loop, where one waiting wave holds up the other fifteen at the next phase change (9.7 -> 9.1 ms).
-            const unsigned r0 = (unsigned)(it / NPH) * ROUND + (unsigned)(wv * R * 16);
+        if constexpr (!PACK) {
+            if (last) {
+                // A wave's round holds 128 rows x 16 queries: about every third round has a survivor (2e-4 per pair), so the
+                // test is made per CHUNK (one max3 pair + compare + ballot each) and only a chunk that has one is scanned.
+                // Survivors go to the wave's LDS list (see flush_survivors): no global atomic — a ~2 us round trip — inside
+                // the loop, where one waiting wave holds up the other fifteen at the next phase change (9.7 -> 9.1 ms).
 #pragma unroll
-            for (int c = 0; c < R; ++c) {
-                const int top = max(max(acc[c][0], acc[c][1]), max(acc[c][2], acc[c][3]));
-                if (__ballot(top >= tq)) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned n = r0 + 16u * c + 4u * g + e;   // D[row = 4 g + e][column = r]
-                        const bool hit = acc[c][e] >= tq && n < nrows;
-                        const unsigned long long mask = __ballot(hit);
-                        if (mask) {                               // wave-uniform
-                            if (scount + 64 > SCAP) flush_survivors();
-                            if (hit) sbuf[scount + __popcll(mask & ((1ull << l) - 1ull))] = (n << 4) | (unsigned)r;
-                            scount += (int)__popcll(mask);
-                        }
-                    }
-                }
+                for (int c = 0; c < R; ++c) test_chunk(acc[c], r0 + 16u * c);
             }
         }
     };
     // prologue: first phase into buffer 0, the next distinct phase into buffer 1
     stage(phase_of(0), 0);
-    adc_u32x4v wa[2], wb[2];
+    adc_u32x4v wa[NV], wb[NV];
     load_step(0, wa);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
