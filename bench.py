@@ -227,12 +227,15 @@ def main():
             candidates = ["ipc"] if share_gpu else ["ipc", "rccl"]     # RCCL refuses two ranks on one device
         import subprocess
         for ti, transport in enumerate(candidates):
-            env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 17 + ti), RC_COMM=transport)
+            # the probe's exchange waits give up after 8 s (RC_FLAG_COMM), the probe itself after 150 s: a transport that does
+            # not work on this node costs minutes at most, never the run
+            env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 17 + ti), RC_COMM=transport,
+                       RC_IPC_TIMEOUT_MS=os.environ.get("RC_IPC_TIMEOUT_MS", "8000"))
             env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # the child makes its own TCP store on the new port
             child = subprocess.Popen([sys.executable, "-m", "repconc_amd.dist_probe"], cwd=ROOT, env=env,
                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             try:
-                prc = child.wait(timeout=240)
+                prc = child.wait(timeout=150)
             except subprocess.TimeoutExpired:
                 child.kill()
                 child.wait()
