@@ -79,3 +79,28 @@ def test_sharded_and_replicated_search_gathers_on_ipc_ranks(tmp_path):
     replica search (query slices, gather) with the result gathers on the IPC layer equal the whole-index search."""
     world = 3
     assert run_ranks(world, ["search"], str(tmp_path), timeout=300) == [0] * world, rank_logs(str(tmp_path), world)
+
+
+def test_bench_gpus2_typed_as_is_on_a_shared_gpu():
+    """`python bench.py --gpus 2` without a launcher (how the driver types it): bench.py spawns its two ranks; with
+    RC_BENCH_SHARE_GPU=1 they share cuda:0, the handshake runs over gloo and the exchange over the IPC transport.  ONE JSON
+    line, n_gpus 2, native C loop, sharded codes == unsharded codes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    if torch.cuda.device_count() < 2:
+        env["RC_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu",
+                        "--no-adc", "--batch", "8192"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    chk = d["multi_gpu_check"]
+    assert chk["sharded_equals_unsharded"] is True and chk["transport"] in ("ipc", "rccl") and chk["native_equals_staged"] is True
+    assert d["exchange"]["us_per_allgather"] > 0
