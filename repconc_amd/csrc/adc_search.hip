@@ -1462,9 +1462,17 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     const int r = l & 15, g = l >> 4;
     const unsigned xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3;
-    const unsigned gpx = (unsigned)(groups + 7) / 8u;         // groups per XCD
-    const unsigned group = (jx % gpx) * 8u + xcd, btile = jx / gpx;
-    if (group >= (unsigned)groups) return;                    // block-uniform
+    unsigned group, btile;
+    if (groups >= 8) {                                        // XCD x owns the groups == x (mod 8), every tile
+        const unsigned gpx = (unsigned)(groups + 7) / 8u;     // groups per XCD
+        group = (jx % gpx) * 8u + xcd;
+        btile = jx / gpx;
+        if (group >= (unsigned)groups) return;                // block-uniform
+    } else {                                                  // few queries (JPQ steps, validation): every XCD takes all the
+        group = jx % (unsigned)groups;                        // groups (their tables fit any L2) and the tiles == x (mod 8)
+        btile = (jx / (unsigned)groups) * 8u + xcd;
+        if ((int64_t)btile * TILE >= N) return;
+    }
     const int q0 = (int)group * 16;
     const uint8_t* qsrc = qlut + (size_t)group * NPH * BUF;
     // asynchronous copy of one phase's tables into an LDS buffer: 16 waves x 4 pieces of 1 KiB
@@ -1953,8 +1961,9 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
             const unsigned tiles16 = (unsigned)((N + ADC_Q16_TILE - 1) / ADC_Q16_TILE);
             const unsigned gpx = (unsigned)(groups + 7) / 8u;
+            const unsigned nblocks = groups >= 8 ? 8u * gpx * tiles16 : 8u * (unsigned)groups * ((tiles16 + 7u) / 8u);
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
-            hipLaunchKernelGGL(kern, dim3(8u * gpx * tiles16), dim3(TH), sl, s, image, N, b.qlut, b.tint, nq, groups, b.idcnt, b.ids,
+            hipLaunchKernelGGL(kern, dim3(nblocks), dim3(TH), sl, s, image, N, b.qlut, b.tint, nq, groups, b.idcnt, b.ids,
                                rc_env_int("RC_ADC_Q16_PRIO", 1));
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             RC_LAUNCH_CHECK(h);
