@@ -104,8 +104,7 @@ class RepCONCEvaluater:
             most = max((n * (r + 1)) // world - (n * r) // world for r in range(world))
             pad = torch.zeros((most, width), dtype=dt, device=dev)
             pad[: local.shape[0]] = local
-            got = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(got, pad)
+            got = ops.all_gather(pad)                               # [world, most, width]: the handle's exchange layer
             local = torch.cat([got[r][: (n * (r + 1)) // world - (n * r) // world] for r in range(world)], 0)
         return SimpleNamespace(predictions=local.cpu().numpy(), label_ids=None, metrics={})
 

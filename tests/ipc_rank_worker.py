@@ -5,6 +5,7 @@
     python tests/ipc_rank_worker.py timeout                                   a missing peer is reported, not waited for
     python tests/ipc_rank_worker.py warmup                                    corpus-sharded OPQ + PQ training
     python tests/ipc_rank_worker.py search                                    row-sharded + replicated search gathers
+    python tests/ipc_rank_worker.py encode                                    corpus encoding, rows split over the ranks
 
 RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment; torch.distributed (gloo) only carries the
 set-up handshake, the exchanges themselves run on the IPC transport of librepconc_hip.so.  All ranks share cuda:0 unless
@@ -142,6 +143,39 @@ def main() -> int:
         for nm, (s, i) in (("sharded", (s1, i1)), ("replicated", (s2, i2))):
             if not (torch.equal(s, ws) and torch.equal(i, wi)):
                 print(f"rank {rank}: {nm} search differs from the whole-index search")
+                rc = 1
+    elif what == "encode":
+        # evaluate_repconc.py:51-75 + the Trainer's prediction gather: every rank encodes a contiguous share of the corpus
+        # to nearest codes, the (padded) shares are gathered; every rank ends with the codes of the WHOLE corpus.
+        from types import SimpleNamespace
+        from repconc_amd.models.repconc import RepCONC
+        from repconc_amd.models.repconc.evaluate_repconc import RepCONCEvaluater
+        from oracle import pq_oracle, synth
+        n = 1003                                                   # ragged shares
+        table = synth.clustered_embeddings(31, n)
+        C = synth.sample_centroids(32, table, 48)
+
+        class Enc(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.register_buffer("table", torch.from_numpy(table))
+                self.config = SimpleNamespace(hidden_size=768)
+
+            def forward(self, input_ids, attention_mask):
+                return self.table[input_ids[:, 0]]
+
+        cfg = SimpleNamespace(MCQ_M=48, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_IP")
+        model = RepCONC(cfg, Enc(), False, None, None).to(dev)
+        with torch.no_grad():
+            model.centroids.copy_(torch.from_numpy(C))
+        rows = [{"input_ids": [i, 0], "attention_mask": [1, 1]} for i in range(n)]
+        collate = lambda items: {k: torch.tensor([it[k] for it in items]) for k in items[0]}
+        args = SimpleNamespace(per_device_eval_batch_size=100, fp16=False, bf16=False)
+        for fmt in ("code", "continuous_embedding"):
+            got = RepCONCEvaluater(fmt, model=model, args=args, data_collator=collate).predict(rows).predictions
+            want = pq_oracle.quantize(table, C, False).astype(np.uint8) if fmt == "code" else table
+            if got.shape != want.shape or not (np.array_equal(got, want) if fmt == "code" else np.allclose(got, want, rtol=1e-5, atol=1e-6)):
+                print(f"rank {rank}: gathered {fmt} predictions differ from the oracle's")
                 rc = 1
     else:
         raise SystemExit(f"unknown scenario {what}")

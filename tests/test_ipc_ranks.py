@@ -81,6 +81,13 @@ def test_sharded_and_replicated_search_gathers_on_ipc_ranks(tmp_path):
     assert run_ranks(world, ["search"], str(tmp_path), timeout=300) == [0] * world, rank_logs(str(tmp_path), world)
 
 
+def test_corpus_encoding_split_over_ipc_ranks(tmp_path):
+    """Corpus encoding with the rows split over three processes (ragged shares, a partial last batch): the shares' codes /
+    embeddings are gathered on the IPC layer; every rank holds the oracle's nearest codes of the whole corpus."""
+    world = 3
+    assert run_ranks(world, ["encode"], str(tmp_path), timeout=300) == [0] * world, rank_logs(str(tmp_path), world)
+
+
 def test_bench_gpus2_typed_as_is_on_a_shared_gpu():
     """`python bench.py --gpus 2` without a launcher (how the driver types it): bench.py spawns its two ranks; with
     RC_BENCH_SHARE_GPU=1 they share cuda:0, the handshake runs over gloo and the exchange over the IPC transport.  ONE JSON
