@@ -1005,6 +1005,15 @@ struct adc_part_args {
     unsigned nchunks;      // 16-row chunks per group in `buf` (whole tiles)
 };
 
+#ifdef RC_IVF_TRACE
+__device__ unsigned long long adc_ivf_trace[32768 * 8];
+extern "C" int rc_debug_ivf_trace(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(adc_ivf_trace), sizeof(adc_ivf_trace));
+}
+#define IVF_STAMP(i) do { if (IVF && threadIdx.x == 0 && task < 32768u) adc_ivf_trace[task * 8u + (i)] = wall_clock64(); } while (0)
+#else
+#define IVF_STAMP(i) do { } while (0)
+#endif
 template <int M, int NP, int R, bool IVF = false, int THREADS = ADC_THREADS, int PART = 0>
 __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t* __restrict__ image, int64_t N,
                                                                     const uint8_t* __restrict__ qlut,
@@ -1037,6 +1046,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
         if (j >= q + (xcd < rr ? 1u : 0u)) return;                           // padding (block-uniform)
         task = (xcd < rr ? xcd * (q + 1u) : rr * (q + 1u) + (xcd - rr) * q) + j;
     }
+    IVF_STAMP(0);
     // the task's queries (block-uniform scalars), -1 = empty slot
     int tqid[8];
     if constexpr (IVF) {
@@ -1210,6 +1220,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             __syncthreads();
             in_lds = phase;
         }
+        IVF_STAMP(2 + 3 * (it & 1));
         if constexpr (PREFETCH) {
             if (it + 1 < nsteps) load_step(it + 1, wn);
         } else {
@@ -1255,6 +1266,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             if (c + 2 < R) gather(c + 2, ea);
             if (c + 1 < R) fold(c + 1, eb);
         }
+        IVF_STAMP(3 + 3 * (it & 1));
         if constexpr (PART == 1) {
             // pass 1: the accumulators go to HBM as they are (int16 pairs), nothing is tested
             const unsigned r0p = (unsigned)(it / NPE) * ROUND + (unsigned)(wv * R * 16);
@@ -1337,6 +1349,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     unsigned wa[R][NW], wb[PREFETCH ? R : 1][NW];
     adc_u32x2v pa[PR], pb[PR];
     int in_lds = -1;
+    IVF_STAMP(1);
     if constexpr (PREFETCH) {
         // ping-pong over the two code buffers (and, pass 2, the two partial-sum buffers): no register copies between steps
         load_step(0, wa);
@@ -1348,7 +1361,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             if (it + 1 < nsteps) run_step(it + 1, wb, wa, in_lds, pb);
         }
     } else {
-        for (int it = 0; it < nsteps; ++it) run_step(it, wa, wb, in_lds, pa);
+        for (int it = 0; it < nsteps; ++it) { run_step(it, wa, wb, in_lds, pa); IVF_STAMP(4 + 3 * (it & 1)); }
     }
 }
 
@@ -1749,6 +1762,12 @@ static bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M 
 // keeps the tables L2-resident.  What the two-phase screen pays over 2 x the one-phase time (20 ms) is the pipeline
 // drain and ramp-up of 16 waves around the two barriers of every 2048-row round.
 static int adc_cf_phase_m(int M) { return M == 96 ? 48 : M; }
+#ifndef RC_IVF96_NP
+#define RC_IVF96_NP 2
+#define RC_IVF96_R 8
+#define RC_IVF96_TH ADC_THREADS
+#endif
+static int adc_ivf_phase_m(int M) { return M == 96 ? 96 / RC_IVF96_NP : M; }   // list-centric IVF screen (ivfl_launch)
 static size_t adc_cf_table_bytes(int M) {                  // per group of 8 queries, all phases
     const int PM = adc_cf_phase_m(M);
     return (size_t)(M / PM) * RC_K * (32 * (PM / 32 + (PM % 32) / 16)) * 8;
@@ -1856,8 +1875,9 @@ static int adc_scan_image_impl(rc_handle_t h, const uint8_t* codes, int64_t n0, 
     if (n == 0) return RC_OK;
     int64_t blocks = (n * M + 255) / 256;
     if (blocks > 65536) blocks = 65536;
+    // rows layout (tile == 0) = the IVF search's image: its table phases may differ from the flat search's
     hipLaunchKernelGGL(adc_scan_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, codes, n0, n, M,
-                       adc_cf_phase_m(M), image, tile);
+                       tile == 0 ? adc_ivf_phase_m(M) : adc_cf_phase_m(M), image, tile);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
@@ -1884,9 +1904,24 @@ extern "C" int rc_adc_q16_describe(int M, int lane, int step, int* slot) {
     return adc_q16_for(M) ? 1 : 0;                           // 1: this M's flat search uses the layout
 }
 // row-major image [N][M] (what the list-centric IVF search takes: its cells start at arbitrary rows)
+static bool ivf_pipe() {                                    // RC_IVF_PIPE=0: the round-2 IVF screen (one block per task)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("RC_IVF_PIPE"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+__global__ void ivfs_image_kernel(const uint8_t* __restrict__ codes, int64_t n0, int64_t cnt, int M, uint8_t* __restrict__ image);
 extern "C" int rc_adc_scan_image_rows(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
                                       rc_stream_t stream) {
-    return adc_scan_image_impl(h, codes, n0, n, M, image, 0, stream);
+    if (!ivf_pipe()) return adc_scan_image_impl(h, codes, n0, n, M, image, 0, stream);
+    rc_device_guard device_guard_(h);
+    if (!h || !codes || !image || n0 < 0 || n < 0) return RC_EINVAL;
+    if (!adc_cf_supported(M)) return RC_ESHAPE;
+    if (n == 0) return RC_OK;
+    int64_t blocks = (n * M + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(ivfs_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, codes, n0, n, M, image);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
 }
 
 static int adc_qt_for(int M) {
@@ -2355,6 +2390,489 @@ extern "C" int rc_adc_search_exact(rc_handle_t h, const uint8_t* codes, int64_t 
 // The host builds the task list (cells sorted, 8 queries per task) and the sample ranks; status bit0 = a query kept
 // fewer than min(k, rows probed) candidates (retry with more slack), bit1 = a list overflowed (less slack).
 
+// ------------------------------------------------------------------------------------ 5'. pipelined IVF screen (round 3)
+// A wall-clock trace of the screen above on the BASELINE configs[3] shape (M = 96, 5000 cells of ~1770 rows, nprobe 128:
+// 19 k tasks of 8 queries; tools/_exp/ivf_trace.py) showed where a task's 15.9 us go: 1.6 us of dependent scalar loads
+// (task -> queries -> thresholds), 2.9 + 4.3 us for the two synchronous table fills (128 KiB each: loads from the
+// memory-side cache, byte transposes, a block-wide barrier either side), 2.2 + 1.6 us of gathers and 3.1 us for the
+// returning atomics of the survivor slots — with one 128 KiB block per CU nothing overlaps any of it.  Two blocks per CU
+// (three 64 KiB phases) measured the same: more fills and barriers eat what the overlap gives.
+// This kernel keeps ONE persistent block per CU and overlaps by construction:
+//   * table phases of 32 sub-quantisers (+ one of 16 for M = 16 / 48): 64 KiB, TWO buffers.  The next stage's tables are
+//     requested (global loads into 16 registers) before the current stage's gathers start and are transposed into the other
+//     buffer after them: one barrier per stage, no load latency on the critical path;
+//   * the block walks its tasks (XCD x owns a contiguous eighth of the cell-ordered task list, its blocks take the tasks
+//     round-robin so that the tasks of one cell run side by side in one L2); task descriptors are read two tasks ahead,
+//     thresholds one task ahead;
+//   * the codes of the next stage are requested right after the current stage's last gather (same registers);
+//   * survivors: the wave writes them to its LDS list, issues ONE atomic per (wave, query) for the slots and moves on; the
+//     list is copied out one task later, when the atomic has long returned.  (A wave that keeps more than its list holds —
+//     queries that keep every row — takes the synchronous path.)
+// The per-query byte tables are stored biased (b ^ 0x80) by ivf_qbyte_write_kernel; image: [row][phase][g][step].
+#define IVFS_WAVES 16
+#define IVFS_THREADS (64 * IVFS_WAVES)
+#define IVFS_R 8
+#define IVFS_BUF 65536
+#define IVFS_MAX_BLOCKS 256      // persistent blocks (one per CU); sizes the survivor streams of the workspace
+#ifndef IVFS_SCAP
+#define IVFS_SCAP 512           // survivor stacks: 8 rows per lane (2 x 64 KiB of tables + 32 KiB = the CU's 160 KiB)
+#endif
+#ifndef IVFS_PRIO
+#define IVFS_PRIO 1
+#endif
+__host__ __device__ constexpr int ivfs_phases(int M) { return (M + 31) / 32; }
+__host__ __device__ constexpr int ivfs_pm(int M, int p) { return (M - 32 * p) >= 32 ? 32 : 16; }
+
+// image[n][32 p + g * (PMp / 4) + s] = codes[n][32 p + m(s; n mod 16, g)]
+__global__ __launch_bounds__(256) void ivfs_image_kernel(const uint8_t* __restrict__ codes, int64_t n0, int64_t cnt, int M,
+                                                         uint8_t* __restrict__ image) {
+    const int64_t total = cnt * M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = n0 + i / M;
+        const int pos = (int)(i % M);
+        const int p = pos / 32, rem = pos % 32, PM = ivfs_pm(M, p);
+        const int g = rem / (PM / 4), st = rem % (PM / 4);
+        int slot, m;
+        adc_cf_step(PM, st, (int)(n & 15), g, slot, m);
+        image[n * M + pos] = codes[n * M + 32 * p + m];
+    }
+}
+
+// per-query byte tables, [phase][code][PMp] one biased byte per sub-quantiser (phase p starts at byte 256 * 32 p)
+__global__ __launch_bounds__(RC_K) void ivfs_qbyte_write_kernel(const float* __restrict__ lut, const float* __restrict__ qstat,
+                                                                int M, uint8_t* __restrict__ qbyte) {
+    const int qi = blockIdx.x, c = threadIdx.x;
+    const float* lq = lut + (size_t)qi * M * RC_K;
+    const float* st = qstat + (size_t)qi * ADC_QSTAT_STRIDE;
+    const float delta = st[ADC_QSTAT_STRIDE - 1];
+    for (int b16 = 0; b16 < M / 16; ++b16) {
+        const int p = b16 / 2, PM = ivfs_pm(M, p), j0 = 16 * (b16 & 1);
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = 32 * p + j0 + j;
+            w[j >> 2] |= (adc_quant8(lq[m * RC_K + c], st[m], delta) ^ 0x80u) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint4*>(qbyte + (size_t)qi * M * RC_K + (size_t)RC_K * 32 * p + (size_t)c * PM + j0) =
+            make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+struct ivfs_task {
+    int valid;
+    int qid[8];
+    unsigned t0;              // first (16-aligned) row of the range
+    unsigned row_lo, nrows;   // rows [row_lo, nrows) counted from t0 are the cell's (nrows = 0: nothing to scan)
+};
+
+template <int M>
+__global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint8_t* __restrict__ image,
+                                                                      const int* __restrict__ tint,
+                                                                      unsigned* __restrict__ stream_cnt,
+                                                                      unsigned* __restrict__ stream, unsigned stream_cap,
+                                                                      int* __restrict__ status, adc_ivf_tasks T,
+                                                                      int ntasks_arg) {
+    constexpr int NPH = ivfs_phases(M), R = IVFS_R, ROUND = IVFS_WAVES * R * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x;
+    const int l = (int)(tid & 63u), wv = __builtin_amdgcn_readfirstlane((int)(tid >> 6)), r = l & 15, g = l >> 4;
+    // ---- this block's tasks
+    const unsigned total = (unsigned)__builtin_amdgcn_readfirstlane(T.ntasks ? *T.ntasks : ntasks_arg);
+    const unsigned xcd = blockIdx.x % 8u, jb = blockIdx.x / 8u, pxb = (gridDim.x - xcd + 7u) / 8u;
+    const unsigned tq8 = total / 8u, tr8 = total % 8u;
+    const unsigned lo = xcd < tr8 ? xcd * (tq8 + 1u) : tr8 * (tq8 + 1u) + (xcd - tr8) * tq8, cnt = tq8 + (xcd < tr8 ? 1u : 0u);
+    auto load_task = [&](unsigned k) {
+        ivfs_task d;
+        const unsigned at = jb + k * pxb;
+        d.valid = at < cnt ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d.qid[j] = -1;
+        d.t0 = 0; d.row_lo = 0; d.nrows = 0;
+        if (d.valid) {
+            // (block-uniform values; the loads are vector loads - the kernel also stores - so pin them to scalars)
+            auto sc = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+            const unsigned task = lo + at;
+            const int qs = sc(T.task_qstart[task]), qc = sc(T.task_qcnt[task]), cell = sc(T.task_list[task]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d.qid[j] = (j < qc) ? sc(T.sorted_q[qs + j]) : -1;
+            const unsigned a = (unsigned)sc((int)T.list_off[cell]), b = (unsigned)sc((int)T.list_off[cell + 1]);   // N < 2^32
+            if (qc > 0 && b > a) {
+                const unsigned t0 = a & ~15u;
+                d.t0 = t0; d.row_lo = a - t0; d.nrows = b - t0;
+            }
+        }
+        return d;
+    };
+    auto rounds_of = [&](const ivfs_task& d) { return d.nrows ? (int)((d.nrows + ROUND - 1) / ROUND) : 1; };
+    // threshold and query id of this lane's column (r < 8) for a task
+    auto lane_q = [&](const ivfs_task& d) {
+        int q = -1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q = (r == j) ? d.qid[j] : q;
+        return q;
+    };
+    auto lane_thr = [&](int q) {
+        if (q < 0) return INT_MAX;
+        const int t = tint[q];
+        return (t == INT_MIN) ? INT_MIN : t - 128 * M;
+    };
+    // ---- tables: global -> registers -> (byte transpose) -> LDS
+    // dword i of a query's phase table ([code][PM] bytes) = sub-quantisers 4 u .. 4 u + 3 of code i / (PM / 4); its LDS
+    // entries are slots 4 u .. 4 u + 3 of that code's row (256 bytes = 32 slots x 8 queries; a 16-block is stored twice)
+    constexpr int DD = 2;                                     // 2048 dwords per query and 32-phase / 1024 threads
+    // Buffer loads: ONE vector offset (tid * 4) for all eight queries, the query's table comes in through the scalar offset
+    // (with flat pointers the compiler forms eight 64-bit vector addresses, hoists them and spills)
+    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)T.qbyte, 0, -1, 0x00020000);
+    auto load_tables = [&](auto PMc, int p, const ivfs_task& d, unsigned (&dd)[DD][8]) {
+        constexpr int PM = decltype(PMc)::value;
+        constexpr int FI = RC_K * PM / 4 / IVFS_THREADS;      // 2 (PM = 32) or 1
+#pragma unroll
+        for (int f = 0; f < FI; ++f)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                // (an empty slot reads query 0's table: its column is masked by the threshold INT_MAX)
+                dd[f][j] = __builtin_amdgcn_raw_buffer_load_b32(qrsrc, tid * 4u, (unsigned)(d.qid[j] < 0 ? 0 : d.qid[j]) * (unsigned)(M * RC_K) +
+                                                                (unsigned)(RC_K * 32 * p + f * 4 * IVFS_THREADS), 0);
+    };
+    auto write_tables = [&](auto PMc, const unsigned (&dd)[DD][8], unsigned bufoff) {
+        constexpr int PM = decltype(PMc)::value;
+        constexpr int FI = RC_K * PM / 4 / IVFS_THREADS;
+#pragma unroll
+        for (int f = 0; f < FI; ++f) {
+            const unsigned i = tid + (unsigned)(f * IVFS_THREADS);
+            const unsigned (&d)[8] = dd[f];
+            unsigned o[8];                                   // o[2 t] = queries 0-3 of entry t, o[2 t + 1] = queries 4-7
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const unsigned a0 = d[4 * hq], a1 = d[4 * hq + 1], a2 = d[4 * hq + 2], a3 = d[4 * hq + 3];
+                const unsigned t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+                const unsigned u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+                o[0 + hq] = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+                o[2 + hq] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+                o[4 + hq] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+                o[6 + hq] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+            }
+            const uint4 lo4 = make_uint4(o[0], o[1], o[2], o[3]), hi4 = make_uint4(o[4], o[5], o[6], o[7]);
+            if constexpr (PM == 32) {
+                uint4* e = reinterpret_cast<uint4*>(smem + (bufoff + i * 32u));
+                e[0] = lo4;
+                e[1] = hi4;
+            } else {
+                uint4* e = reinterpret_cast<uint4*>(smem + (bufoff + (i >> 2) * 256u + (i & 3u) * 32u));
+                e[0] = lo4;
+                e[1] = hi4;
+                e[8] = lo4;                                  // second copy, 16 slots further
+                e[9] = hi4;
+            }
+        }
+    };
+    // ---- codes of one stage: chunk c of wave wv is chunk 16 c + wv of the round (the waves share a short cell evenly:
+    // a cell of 1770 rows = 111 chunks costs every wave 7 chunks, not the first 14 waves 8); PM / 16 dwords per lane and chunk
+    auto chunks_of = [&](unsigned nrows, int rd) {            // chunks this wave owns in round rd (wave-uniform, 0 .. R)
+        const unsigned done = (unsigned)rd * ROUND;
+        if (nrows <= done) return 0;
+        unsigned nc = (nrows - done + 15u) / 16u;             // chunks of the round that hold rows of the cell
+        if (nc > (unsigned)(ROUND / 16)) nc = ROUND / 16;
+        const int mine = ((int)nc - wv + IVFS_WAVES - 1) / IVFS_WAVES;
+        return mine < 0 ? 0 : mine;
+    };
+    auto load_codes = [&](auto PMc, int p, unsigned t0, unsigned nrows, int rd, unsigned (&w)[R][2]) {
+        constexpr int PM = decltype(PMc)::value;
+        constexpr int NW = PM / 16;
+        const int reff = chunks_of(nrows, rd);
+        if (reff == 0) return;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(image + (size_t)t0 * M), 0, -1, 0x00020000);
+        const unsigned base = (unsigned)rd * ROUND + (unsigned)(wv * 16 + r);
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            if (c < reff) {                                    // wave-uniform
+                unsigned n = base + (unsigned)(16 * IVFS_WAVES * c);
+                n = n < nrows ? n : nrows - 1u;                // rows past the end: the last row again (masked later)
+                const unsigned o = n * (unsigned)M + (unsigned)(g * (PM / 4));
+                if constexpr (NW == 2) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, o, (unsigned)(32 * p), 0);
+                    w[c][0] = v.x; w[c][1] = v.y;
+                } else {
+                    w[c][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, o, (unsigned)(32 * p), 0);
+                }
+            }
+        }
+    };
+    adc_i32x4v bsel = {0, 0, 0, 0};                          // B[k][j = r] = [k % 8 == r]
+    if (r < 8) {
+        const int one = 1 << (8 * (r & 3));
+        bsel[r >> 2] = one;
+        bsel[2 + (r >> 2)] = one;
+    }
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+    adc_i32x4v acc[R];
+    // ---- gathers + folds of one stage
+    auto gathers = [&](auto PMc, bool first, const unsigned (&w)[R][2], unsigned bufoff, int reff) {
+        constexpr int PM = decltype(PMc)::value;
+        constexpr int STEPS = PM / 4;
+        unsigned off[STEPS];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            int slot, m;
+            adc_cf_step(PM, s, r, g, slot, m);
+            off[s] = lds0 + bufoff + (unsigned)slot * 8u;
+        }
+        // units of 4 gathers (half a chunk of a 32-phase, a chunk of a 16-phase) = 2 MFMAs; the gathers of the next unit are
+        // issued before the MFMAs of the current one (8 gathers per wave in flight; 16 did not fit the 128 registers of 4 waves/SIMD)
+        constexpr int UPC = STEPS / 4;
+        uint2 ea[4], eb[4];
+        auto gather = [&](int c, int hh, uint2 (&e)[4]) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                unsigned addr;
+                asm("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_add_u32 %0, %0, 8, %3" : "=&v"(addr) : "v"(w[c][hh]), "n"(8 * s4), "v"(off[4 * hh + s4]));
+                typedef unsigned adc_u32x2 __attribute__((ext_vector_type(2)));
+                const adc_u32x2 v = *reinterpret_cast<const adc_u32x2 __attribute__((address_space(3)))*>(addr);
+                e[s4] = make_uint2(v.x, v.y);
+            }
+        };
+        auto fold = [&](int c, int hh, const uint2 (&e)[4]) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const adc_i32x4v a = {(int)e[2 * s2].x, (int)e[2 * s2].y, (int)e[2 * s2 + 1].x, (int)e[2 * s2 + 1].y};
+                if (hh == 0 && s2 == 0 && first) acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, adc_i32x4v{0, 0, 0, 0}, 0, 0, 0);
+                else acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
+            }
+        };
+        if (reff <= 0) return;                                // wave-uniform
+        gather(0, 0, ea);
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            if (c < reff) {                                   // wave-uniform
+#if IVFS_PRIO
+                // progress-proportional priority (see the 16-query screen): a wave that is behind in its stage outranks one ahead
+                if (c == 0) __builtin_amdgcn_s_setprio(3);
+                else if (c == R / 4) __builtin_amdgcn_s_setprio(2);
+                else if (c == R / 2) __builtin_amdgcn_s_setprio(1);
+                else if (c == 3 * R / 4) __builtin_amdgcn_s_setprio(0);
+#endif
+                if constexpr (UPC == 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    gather(c, 1, eb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fold(c, 0, ea);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c + 1 < R && c + 1 < reff) gather(c + 1, 0, ea);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fold(c, 1, eb);
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c + 1 < R && c + 1 < reff) gather(c + 1, 0, (c & 1) ? ea : eb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fold(c, 0, (c & 1) ? eb : ea);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#if IVFS_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    // ---- survivors
+    // No atomics here: a returning atomic costs the wave its round trip at the next vmcnt wait on anything older (the
+    // counter is in-order), ~1-3 us per task with sixteen waves meeting at the next barrier.  Every wave appends (query, row)
+    // pairs to its OWN stream in global memory (stream_cap pairs, running offset in a scalar); ivfs_bucket_kernel deals the
+    // streams to the per-query id lists afterwards, with the whole chip's parallelism to hide its atomics.
+    // A lane collects its survivors of one (task, round) in a private LDS stack of LCAP rows (entry j of lane l at [j][l]:
+    // conflict-free) in ONE pass over the sums; the lanes' counts give the positions (query column major, so a stream holds
+    // runs of equal query ids).  A wave with a fuller lane (queries that keep every row) makes a second pass instead.
+    constexpr int LCAP = IVFS_SCAP / 64;
+    unsigned* sbuf = reinterpret_cast<unsigned*>(smem + 2 * IVFS_BUF) + wv * IVFS_SCAP + l;
+    const __amdgpu_buffer_rsrc_t strsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(stream + (size_t)(blockIdx.x * IVFS_WAVES + (unsigned)wv) * stream_cap * 2u), 0, -1, 0x00020000);
+    unsigned woff = 0;                                        // wave-uniform: pairs in the wave's stream
+    typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+    auto epilogue = [&](unsigned t0, unsigned row_lo, unsigned nrows, int rd, int tq, int myq, int reff) {
+        if (reff <= 0) return;                                // wave-uniform: no rows of the cell in this wave's share
+        const unsigned rb = (unsigned)rd * ROUND + (unsigned)(wv * 16);      // first row of the wave's chunk 0
+        // rows outside the cell (before its first row in the first chunk, after its last in the last): never survivors
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const unsigned cb = rb + (unsigned)(16 * IVFS_WAVES * c);
+            if (c < reff && (cb < row_lo || cb + 16u > nrows)) {           // wave-uniform, rare
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned n = cb + 4u * g + e;
+                    if (n < row_lo || n >= nrows) acc[c][e] = INT_MIN;
+                }
+            }
+        }
+        const bool keep_all = (tq == INT_MIN);                // INT_MIN sums above must not pass a keep-everything threshold
+        unsigned cnt = 0;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            if (c < reff) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool hit = keep_all ? (acc[c][e] != INT_MIN) : (acc[c][e] >= tq);
+                    if (hit) {
+                        if (cnt < (unsigned)LCAP) sbuf[cnt * 64u] = t0 + rb + (unsigned)(16 * IVFS_WAVES * c) + 4u * g + e;
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        if (!__ballot(cnt != 0)) return;
+        const unsigned c0 = __shfl(cnt, r), c1 = __shfl(cnt, r + 16), c2 = __shfl(cnt, r + 32), c3 = __shfl(cnt, r + 48);
+        const unsigned tot = c0 + c1 + c2 + c3;
+        const unsigned lane_first = (g > 0 ? c0 : 0u) + (g > 1 ? c1 : 0u) + (g > 2 ? c2 : 0u);
+        unsigned inc = tot;                                   // inclusive prefix over the query columns r of the lane's row
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {                      // (columns 8 .. 15 hold nothing)
+            const unsigned t = __shfl_up(inc, o, 16);
+            if (r >= o) inc += t;
+        }
+        const unsigned wtotal = (unsigned)__builtin_amdgcn_readlane((int)inc, 7);
+        if (woff + wtotal > stream_cap) {                     // wave-uniform; the search reports an overflowed list
+            if (l == 0) atomicOr(status, 2);
+            return;
+        }
+        unsigned at = (woff + (inc - tot) + lane_first) * 8u;  // byte offset of the lane's first pair
+        if (!__ballot(cnt > (unsigned)LCAP)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < LCAP; ++j) {
+                if ((unsigned)j < cnt) {
+                    const u32x2s v = {(unsigned)myq, sbuf[j * 64]};
+                    __builtin_amdgcn_raw_buffer_store_b64(v, strsrc, at + 8u * j, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stack reads done before the stacks are rewritten
+        } else {
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                if (c < reff) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool hit = keep_all ? (acc[c][e] != INT_MIN) : (acc[c][e] >= tq);
+                        if (hit) {
+                            const u32x2s v = {(unsigned)myq, t0 + rb + (unsigned)(16 * IVFS_WAVES * c) + 4u * g + e};
+                            __builtin_amdgcn_raw_buffer_store_b64(v, strsrc, at, 0, 0);
+                            at += 8u;
+                        }
+                    }
+                }
+            }
+        }
+        woff += wtotal;
+    };
+    auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- prologue
+    ivfs_task cur = load_task(0);
+    if (!cur.valid) return;                                   // block-uniform
+    int myq = lane_q(cur), tq = lane_thr(myq);
+    unsigned dd[DD][8];
+    unsigned w[R][2];
+    using P0 = std::integral_constant<int, ivfs_pm(M, 0)>;
+    load_tables(P0{}, 0, cur, dd);
+    load_codes(P0{}, 0, cur.t0, cur.nrows, 0, w);
+    write_tables(P0{}, dd, 0u);
+    unsigned bufoff = 0;
+    unsigned k = 0;
+    for (;;) {                                                // tasks of this block
+        const ivfs_task nxt = load_task(k + 1);               // used in this task's LAST stage (and for its thresholds after)
+        const int nrounds = rounds_of(cur);
+        for (int rd = 0; rd < nrounds; ++rd) {
+            const bool more = rd + 1 < nrounds;               // block-uniform
+            auto stage = [&](auto Pc) {
+                constexpr int P = decltype(Pc)::value;
+                constexpr bool LASTP = (P == NPH - 1);
+                constexpr int PN = LASTP ? 0 : P + 1;         // phase of the next stage
+                using PMc = std::integral_constant<int, ivfs_pm(M, P)>;
+                using PMn = std::integral_constant<int, ivfs_pm(M, PN)>;
+                block_sync();
+#ifdef RC_IVF_TRACE
+#define IVFS_STAMP(i) do { if (tid == 0 && k < 16u && rd == 0) adc_ivf_trace[((blockIdx.x * 16u + k) * 3u + P) * 8u + (i)] = wall_clock64(); } while (0)
+#else
+#define IVFS_STAMP(i) do { } while (0)
+#endif
+                IVFS_STAMP(0);
+                // the next stage: same task (next phase / next round) or the next task's first
+                const bool to_next = LASTP && !more;          // block-uniform
+                const bool has_next = !to_next || nxt.valid;
+                ivfs_task nd;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nd.qid[j] = to_next ? nxt.qid[j] : cur.qid[j];
+                nd.t0 = to_next ? nxt.t0 : cur.t0;
+                nd.nrows = to_next ? nxt.nrows : cur.nrows;
+                const int nrd = to_next ? 0 : (LASTP ? rd + 1 : rd);
+                // its tables are requested now and transposed after this stage's gathers
+#ifndef IVFS_EXP
+#define IVFS_EXP 0
+#endif
+                if ((IVFS_EXP & 2) == 0 && has_next) load_tables(PMn{}, PN, nd, dd);
+                IVFS_STAMP(1);
+                const int reff = chunks_of(cur.nrows, rd);
+                if ((IVFS_EXP & 1) == 0) gathers(PMc{}, P == 0, w, bufoff, reff);
+                IVFS_STAMP(2);
+                // (last phase: the codes are requested AFTER the survivor pass - a wait inside it would otherwise also wait for them)
+                if constexpr (!LASTP) { if ((IVFS_EXP & 8) == 0 && has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w); }
+                IVFS_STAMP(3);
+                if constexpr (LASTP) {
+                    if ((IVFS_EXP & 4) == 0) epilogue(cur.t0, cur.row_lo, cur.nrows, rd, tq, myq, reff);
+                    if ((IVFS_EXP & 16) != 0) {                 // experiment: keep the sums alive, nothing else
+                        int top = INT_MIN;
+#pragma unroll
+                        for (int c = 0; c < R; ++c) top = max(top, max(max(acc[c][0], acc[c][1]), max(acc[c][2], acc[c][3])));
+                        if (top == 0x7fffffff) stream[tid] = 1u;
+                    }
+                }
+                if constexpr (LASTP) { if ((IVFS_EXP & 8) == 0 && has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w); }
+                IVFS_STAMP(4);
+                if ((IVFS_EXP & 2) == 0 && has_next) write_tables(PMn{}, dd, bufoff ^ (unsigned)IVFS_BUF);
+                IVFS_STAMP(5);
+                bufoff ^= (unsigned)IVFS_BUF;
+            };
+            stage(std::integral_constant<int, 0>{});
+            if constexpr (NPH > 1) stage(std::integral_constant<int, 1>{});
+            if constexpr (NPH > 2) stage(std::integral_constant<int, 2>{});
+        }
+        if (!nxt.valid) break;
+        cur = nxt;
+        myq = lane_q(cur); tq = lane_thr(myq);
+        ++k;
+    }
+    if (l == 0) stream_cnt[blockIdx.x * IVFS_WAVES + (unsigned)wv] = woff;
+}
+
+// Deal the waves' (query, row) streams to the per-query id lists.  An atomic on one address takes ~0.2 us and the atomics
+// of one address do not overlap: 2.4 M runs (one per wave, task and query) on 1200 counters cost 0.44 ms however many waves
+// issue them.  The sixteen streams of ONE screen block hold the same (task, query) pairs, so one bucket block takes them
+// all: a histogram over the queries in LDS (pass 1), ONE global atomic per query present (~600 of 1200 per block: 128 per
+// counter over the whole grid), then every pair finds its slot with an LDS atomic (pass 2).
+#define IVFS_BUCKET_THREADS 1024
+__global__ __launch_bounds__(IVFS_BUCKET_THREADS) void ivfs_bucket_kernel(const unsigned* __restrict__ stream_cnt,
+                                                                          const unsigned* __restrict__ stream, unsigned stream_cap,
+                                                                          int nq, unsigned* __restrict__ id_count,
+                                                                          unsigned* __restrict__ ids) {
+    extern __shared__ unsigned bk_hist[];                     // [nq] pairs of the query in this block's streams, then its first slot
+    const unsigned tid = threadIdx.x, wv = tid >> 6, l = tid & 63u;
+    for (int q = (int)tid; q < nq; q += IVFS_BUCKET_THREADS) bk_hist[q] = 0u;
+    __syncthreads();
+    const unsigned sidx = blockIdx.x * IVFS_WAVES + wv;       // wave w of the bucket block reads stream w of the screen block
+    const unsigned n = stream_cnt[sidx];
+    const uint2* st = reinterpret_cast<const uint2*>(stream) + (size_t)sidx * stream_cap;
+    for (unsigned i = l; i < n; i += 64u) atomicAdd(&bk_hist[st[i].x], 1u);
+    __syncthreads();
+    for (int q = (int)tid; q < nq; q += IVFS_BUCKET_THREADS) {
+        const unsigned c = bk_hist[q];
+        if (c) bk_hist[q] = atomicAdd(id_count + q, c);
+    }
+    __syncthreads();
+    for (unsigned i = l; i < n; i += 64u) {
+        const uint2 e = st[i];
+        const unsigned slot = atomicAdd(&bk_hist[e.x], 1u);
+        if (slot < ADC_ID_CAP) ids[(size_t)e.x * ADC_ID_CAP + slot] = e.y;
+    }
+}
+
 // grid (nq, slices): the query's sample entries 0 .. scount[qi] are dealt to the threads of its blocks; an entry finds its
 // cell by binary search over the query's sbase row (no per-cell loop: a probed cell contributes only a few dozen sampled
 // rows, and walking the cells one after the other would serialise two dependent loads per cell).
@@ -2440,7 +2958,7 @@ __global__ void ivf_check_kernel(const unsigned* __restrict__ cand_count, const 
 
 namespace {
 struct ivfl_ws {
-    size_t sample, thr, tint, qstat, qbyte, idcnt, ids, cnt, cand, total;
+    size_t sample, thr, tint, qstat, qbyte, idcnt, ids, cnt, cand, stream_cnt, stream, stream_cap, total;
 };
 ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
     ivfl_ws L;
@@ -2454,6 +2972,12 @@ ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
     L.ids = o;    o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
     L.cnt = o;    o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
     L.cand = o;   o += rc_align_up((size_t)nq * ADC_CAND_CAP * sizeof(unsigned long long), 256);
+    // (query, row) streams of the pipelined screen: one per wave of its <= IVFS_MAX_BLOCKS persistent blocks
+    size_t cap = (size_t)nq * (ADC_ID_CAP / 2) / (IVFS_MAX_BLOCKS * IVFS_WAVES);
+    if (cap < 4096) cap = 4096;
+    L.stream_cap = cap;
+    L.stream_cnt = o; o += rc_align_up((size_t)IVFS_MAX_BLOCKS * IVFS_WAVES * sizeof(unsigned), 256);
+    L.stream = o;     o += rc_align_up((size_t)IVFS_MAX_BLOCKS * IVFS_WAVES * cap * 8, 256);
     L.total = o;
     return L;
 }
@@ -2463,9 +2987,14 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
                 int64_t N, const float* lut, int nq, const int* probes, const int* sbase, const int* scount,
                 const int* rows, const int* rank, int nprobe, int64_t sstride, int ss, const adc_ivf_tasks& T, int ntasks,
                 int k, float* scores, int64_t* out_ids, int* status, char* w, const ivfl_ws& L, hipStream_t s) {
-    constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP;
-    constexpr int R = (NP > 1) ? 8 : (M == 64 ? 2 : 4);
-    constexpr int TH = ADC_THREADS;
+#ifndef RC_IVF96_NP
+#define RC_IVF96_NP 2
+#define RC_IVF96_R 8
+#define RC_IVF96_TH ADC_THREADS
+#endif
+    constexpr int NP = (M == 96) ? RC_IVF96_NP : 1, PM = M / NP;
+    constexpr int R = (NP > 1) ? RC_IVF96_R : (M == 64 ? 2 : 4);
+    constexpr int TH = (NP > 1) ? RC_IVF96_TH : ADC_THREADS;
     float* sample = (float*)(w + L.sample);
     float* thr = (float*)(w + L.thr);
     int* tint = (int*)(w + L.tint);
@@ -2490,11 +3019,39 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     RC_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)thr, M, qstat, tint);
     RC_LAUNCH_CHECK(h);
-    hipLaunchKernelGGL(adc_qbyte_write_kernel<PM>, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)qstat, M, qbyte);
+    if (ivf_pipe())
+        hipLaunchKernelGGL(ivfs_qbyte_write_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)qstat, M, qbyte);
+    else
+        hipLaunchKernelGGL(adc_qbyte_write_kernel<PM>, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)qstat, M, qbyte);
     RC_LAUNCH_CHECK(h);
     RC_HIP_CHECK(h, hipMemsetAsync(idcnt, 0, (size_t)nq * sizeof(unsigned), s));
     RC_HIP_CHECK(h, hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(unsigned), s));
-    {
+    if (ivf_pipe()) {
+        auto kern = ivfs_screen_kernel<M>;
+        constexpr int sl = 2 * IVFS_BUF + IVFS_WAVES * IVFS_SCAP * 4;
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+        adc_ivf_tasks TT = T;
+        TT.qbyte = qbyte;
+        int blocks = h->num_cus > 0 ? h->num_cus : 256;       // persistent: one block per CU
+        if (blocks > IVFS_MAX_BLOCKS) blocks = IVFS_MAX_BLOCKS;
+        if (!T.ntasks && ntasks < blocks) blocks = ntasks;
+        unsigned* stream_cnt = (unsigned*)(w + L.stream_cnt);
+        unsigned* stream = (unsigned*)(w + L.stream);
+        const unsigned nstreams = (unsigned)blocks * IVFS_WAVES;
+        RC_HIP_CHECK(h, hipMemsetAsync(stream_cnt, 0, (size_t)nstreams * sizeof(unsigned), s));
+        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(IVFS_THREADS), sl, s, image, (const int*)tint, stream_cnt, stream,
+                           (unsigned)L.stream_cap, status, TT, ntasks);
+        RC_LAUNCH_CHECK(h);
+        {
+            const size_t bl = (size_t)nq * sizeof(unsigned);
+            RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)ivfs_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bl));
+            hipLaunchKernelGGL(ivfs_bucket_kernel, dim3((unsigned)blocks), dim3(IVFS_BUCKET_THREADS), bl, s, (const unsigned*)stream_cnt,
+                               (const unsigned*)stream, (unsigned)L.stream_cap, nq, idcnt, ids);
+        }
+        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
+        RC_LAUNCH_CHECK(h);
+    } else {
         auto kern = adc_screen_cf_kernel<M, NP, R, true, TH>;
         constexpr int sl = adc_cf<PM>::TABLE_BYTES;
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
