@@ -278,9 +278,14 @@ int rc_adc_scan_image(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n
  * row-major [N][M] for the one-phase M (16, 32, 48, 64) and, for M = 96, stored in tiles of 32768 rows, phase-major inside a
  * tile — [n / T][phase][n % T][48] — so each of the two screen passes streams dense 48-byte rows; the buffer holds whole
  * tiles, the position of a row does not depend on the buffer's capacity (rows can be appended).  The list-centric IVF search
- * (rc_ivf_search_lists / _probes) takes the row-major image [N][M] for every M: rc_adc_scan_image_rows. */
+ * (rc_ivf_search_lists / _probes) takes its own image for every M (rc_adc_scan_image_rows; layout below). */
 int rc_adc_scan_image_rows(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
                            rc_stream_t stream);
+/* The IVF image is blocked by chunks of 16 rows (round 3: a wave's load of one chunk and table phase is contiguous), so
+ * its buffer holds whole chunks: rc_adc_scan_image_rows_bytes(N, M) bytes.  rc_adc_scan_image_rows_at (host only, no GPU)
+ * = byte offset of codes[n][m] in it, -1 for arguments out of range: image[at(n, m)] == codes[n][m] is the whole contract. */
+size_t rc_adc_scan_image_rows_bytes(int64_t N, int M);
+int64_t rc_adc_scan_image_rows_at(int M, int64_t n, int m);
 /* Round 3: for the M whose flat search runs the 16-query screen (adc_screen_q16_kernel; M = 48 and 96 unless RC_ADC_Q16
  * says otherwise — read once per process) the flat-search image is [n / 32768][phase = m / 16][n % 32768][16 bytes], the 16
  * bytes of a (row, phase) ordered [lane quarter g][step j] = code of sub-quantiser 16 phase + slot(lane = (n & 15) + 16 g, j).

@@ -70,6 +70,8 @@ PROTOTYPES = {
     "rc_adc_scan_image": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp]),
     "rc_adc_q16_describe": (_i, [_i, _i, _i, C.POINTER(_i)]),
     "rc_adc_scan_image_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp]),
+    "rc_adc_scan_image_rows_bytes": (_sz, [_i64, _i]),
+    "rc_adc_scan_image_rows_at": (_i64, [_i, _i64, _i]),
     "rc_adc_search_img_ws_bytes": (_sz, [_i64, _i, _i, _i, _i]),
     "rc_adc_search_img": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_adc_search_q": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1910,6 +1910,33 @@ static bool ivf_pipe() {                                    // RC_IVF_PIPE=0: th
     return v != 0;
 }
 __global__ void ivfs_image_kernel(const uint8_t* __restrict__ codes, int64_t n0, int64_t cnt, int M, uint8_t* __restrict__ image);
+// bytes of the IVF image of N rows (whole chunks of 16 rows)
+extern "C" size_t rc_adc_scan_image_rows_bytes(int64_t N, int M) {
+    if (!adc_cf_supported(M) || N < 0) return 0;
+    return (size_t)((N + 15) / 16 * 16) * M * ADC_IMG_ES;
+}
+// host-side description of that image (no GPU involved): byte offset of codes[n][m], or -1
+extern "C" int64_t rc_adc_scan_image_rows_at(int M, int64_t n, int m) {
+    if (!adc_cf_supported(M) || n < 0 || m < 0 || m >= M) return -1;
+    if (!ivf_pipe()) {                                      // round-2 layout: row-major, adc_cf_step order inside the row
+        const int PM = adc_ivf_phase_m(M), ph = m / PM;
+        for (int g = 0; g < 4; ++g)
+            for (int st = 0; st < PM / 4; ++st) {
+                int slot, mm;
+                adc_cf_step(PM, st, (int)(n & 15), g, slot, mm);
+                if (mm == m - ph * PM) return n * M + ph * PM + g * (PM / 4) + st;
+            }
+        return -1;
+    }
+    const int p = m / 32, PM = (M - 32 * p) >= 32 ? 32 : 16;
+    for (int g = 0; g < 4; ++g)
+        for (int st = 0; st < PM / 4; ++st) {
+            int slot, mm;
+            adc_cf_step(PM, st, (int)(n & 15), g, slot, mm);
+            if (mm == m - 32 * p) return (n >> 4) * (int64_t)(16 * M) + 16 * 32 * p + (g * 16 + (int)(n & 15)) * (PM / 4) + st;
+        }
+    return -1;
+}
 extern "C" int rc_adc_scan_image_rows(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
                                       rc_stream_t stream) {
     if (!ivf_pipe()) return adc_scan_image_impl(h, codes, n0, n, M, image, 0, stream);
@@ -2414,16 +2441,20 @@ extern "C" int rc_adc_search_exact(rc_handle_t h, const uint8_t* codes, int64_t 
 #define IVFS_R 8
 #define IVFS_BUF 65536
 #define IVFS_MAX_BLOCKS 256      // persistent blocks (one per CU); sizes the survivor streams of the workspace
-#ifndef IVFS_SCAP
-#define IVFS_SCAP 512           // survivor stacks: 8 rows per lane (2 x 64 KiB of tables + 32 KiB = the CU's 160 KiB)
-#endif
 #ifndef IVFS_PRIO
 #define IVFS_PRIO 1
 #endif
 __host__ __device__ constexpr int ivfs_phases(int M) { return (M + 31) / 32; }
 __host__ __device__ constexpr int ivfs_pm(int M, int p) { return (M - 32 * p) >= 32 ? 32 : 16; }
 
-// image[n][32 p + g * (PMp / 4) + s] = codes[n][32 p + m(s; n mod 16, g)]
+// Image of the list-centric IVF search, blocked by chunks of 16 rows (the unit a wave gathers for): chunk n / 16 holds
+// [phase p][lane quarter g][row n mod 16][step s] = codes[n][32 p + m(s; n mod 16, g)], i.e. a wave's load of one chunk and
+// phase is 64 lanes x PMp / 4 bytes of CONTIGUOUS memory (with row-major rows it was sixteen 32-byte pieces 96 bytes apart:
+// 12-16 cache lines per instruction, and the sixteen waves of a block issue theirs at the same moment).
+__host__ __device__ inline int64_t ivfs_image_at(int M, int64_t n, int p, int g, int st) {
+    const int PM = ivfs_pm(M, p);
+    return (n >> 4) * (int64_t)(16 * M) + (int64_t)(16 * 32 * p) + (int64_t)((g * 16 + (int)(n & 15)) * (PM / 4) + st);
+}
 __global__ __launch_bounds__(256) void ivfs_image_kernel(const uint8_t* __restrict__ codes, int64_t n0, int64_t cnt, int M,
                                                          uint8_t* __restrict__ image) {
     const int64_t total = cnt * M;
@@ -2434,7 +2465,7 @@ __global__ __launch_bounds__(256) void ivfs_image_kernel(const uint8_t* __restri
         const int g = rem / (PM / 4), st = rem % (PM / 4);
         int slot, m;
         adc_cf_step(PM, st, (int)(n & 15), g, slot, m);
-        image[n * M + pos] = codes[n * M + 32 * p + m];
+        image[ivfs_image_at(M, n, p, g, st)] = codes[n * M + 32 * p + m];
     }
 }
 
@@ -2581,20 +2612,21 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
         constexpr int NW = PM / 16;
         const int reff = chunks_of(nrows, rd);
         if (reff == 0) return;
+        // t0 is a multiple of 16: the cell's first chunk; a chunk and phase = 64 lanes x PM / 4 contiguous bytes.  Rows of the
+        // last chunk past the cell's end are another cell's (or, past the index, the padding of the last chunk): masked later
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(image + (size_t)t0 * M), 0, -1, 0x00020000);
-        const unsigned base = (unsigned)rd * ROUND + (unsigned)(wv * 16 + r);
+        const unsigned lane_at = (unsigned)((g * 16 + r) * (PM / 4));
+        const unsigned first = ((unsigned)rd * (unsigned)(ROUND / 16) + (unsigned)wv) * (unsigned)(16 * M) + (unsigned)(16 * 32 * p);
 #pragma unroll
         for (int c = 0; c < R; ++c) {
             if (c < reff) {                                    // wave-uniform
-                unsigned n = base + (unsigned)(16 * IVFS_WAVES * c);
-                n = n < nrows ? n : nrows - 1u;                // rows past the end: the last row again (masked later)
-                const unsigned o = n * (unsigned)M + (unsigned)(g * (PM / 4));
+                const unsigned so = first + (unsigned)(c * IVFS_WAVES * 16 * M);
                 if constexpr (NW == 2) {
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, o, (unsigned)(32 * p), 0);
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_at, so, 0);
                     w[c][0] = v.x; w[c][1] = v.y;
                 } else {
-                    w[c][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, o, (unsigned)(32 * p), 0);
+                    w[c][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane_at, so, 0);
                 }
             }
         }
@@ -2678,19 +2710,26 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
     // No atomics here: a returning atomic costs the wave its round trip at the next vmcnt wait on anything older (the
     // counter is in-order), ~1-3 us per task with sixteen waves meeting at the next barrier.  Every wave appends (query, row)
     // pairs to its OWN stream in global memory (stream_cap pairs, running offset in a scalar); ivfs_bucket_kernel deals the
-    // streams to the per-query id lists afterwards, with the whole chip's parallelism to hide its atomics.
-    // A lane collects its survivors of one (task, round) in a private LDS stack of LCAP rows (entry j of lane l at [j][l]:
-    // conflict-free) in ONE pass over the sums; the lanes' counts give the positions (query column major, so a stream holds
-    // runs of equal query ids).  A wave with a fuller lane (queries that keep every row) makes a second pass instead.
-    constexpr int LCAP = IVFS_SCAP / 64;
-    unsigned* sbuf = reinterpret_cast<unsigned*>(smem + 2 * IVFS_BUF) + wv * IVFS_SCAP + l;
+    // streams to the per-query id lists afterwards.
+    // One branch-free pass over the wave's 32 sums per lane builds a bit mask of the lane's survivors (a divergent branch per
+    // sum cost 3 us per task); the lanes' counts give the positions (query column major: a stream holds runs of equal
+    // query ids), then the lanes write out one survivor per trip of a wave-uniform loop (max count over the lanes: 1-3 trips).
     const __amdgpu_buffer_rsrc_t strsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(stream + (size_t)(blockIdx.x * IVFS_WAVES + (unsigned)wv) * stream_cap * 2u), 0, -1, 0x00020000);
     unsigned woff = 0;                                        // wave-uniform: pairs in the wave's stream
     typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+    static_assert(R * 4 <= 32, "one mask bit per sum");
     auto epilogue = [&](unsigned t0, unsigned row_lo, unsigned nrows, int rd, int tq, int myq, int reff) {
         if (reff <= 0) return;                                // wave-uniform: no rows of the cell in this wave's share
         const unsigned rb = (unsigned)rd * ROUND + (unsigned)(wv * 16);      // first row of the wave's chunk 0
+        unsigned m = 0;                                       // bit 4 c + e: D[row 4 g + e of chunk c][column r] survives
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            if (c < reff) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m |= (acc[c][e] >= tq) ? (1u << (4 * c + e)) : 0u;
+            }
+        }
         // rows outside the cell (before its first row in the first chunk, after its last in the last): never survivors
 #pragma unroll
         for (int c = 0; c < R; ++c) {
@@ -2699,25 +2738,11 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned n = cb + 4u * g + e;
-                    if (n < row_lo || n >= nrows) acc[c][e] = INT_MIN;
+                    if (n < row_lo || n >= nrows) m &= ~(1u << (4 * c + e));
                 }
             }
         }
-        const bool keep_all = (tq == INT_MIN);                // INT_MIN sums above must not pass a keep-everything threshold
-        unsigned cnt = 0;
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-            if (c < reff) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool hit = keep_all ? (acc[c][e] != INT_MIN) : (acc[c][e] >= tq);
-                    if (hit) {
-                        if (cnt < (unsigned)LCAP) sbuf[cnt * 64u] = t0 + rb + (unsigned)(16 * IVFS_WAVES * c) + 4u * g + e;
-                        ++cnt;
-                    }
-                }
-            }
-        }
+        const unsigned cnt = (unsigned)__popc(m);
         if (!__ballot(cnt != 0)) return;
         const unsigned c0 = __shfl(cnt, r), c1 = __shfl(cnt, r + 16), c2 = __shfl(cnt, r + 32), c3 = __shfl(cnt, r + 48);
         const unsigned tot = c0 + c1 + c2 + c3;
@@ -2734,30 +2759,14 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
             return;
         }
         unsigned at = (woff + (inc - tot) + lane_first) * 8u;  // byte offset of the lane's first pair
-        if (!__ballot(cnt > (unsigned)LCAP)) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < LCAP; ++j) {
-                if ((unsigned)j < cnt) {
-                    const u32x2s v = {(unsigned)myq, sbuf[j * 64]};
-                    __builtin_amdgcn_raw_buffer_store_b64(v, strsrc, at + 8u * j, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stack reads done before the stacks are rewritten
-        } else {
-#pragma unroll
-            for (int c = 0; c < R; ++c) {
-                if (c < reff) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool hit = keep_all ? (acc[c][e] != INT_MIN) : (acc[c][e] >= tq);
-                        if (hit) {
-                            const u32x2s v = {(unsigned)myq, t0 + rb + (unsigned)(16 * IVFS_WAVES * c) + 4u * g + e};
-                            __builtin_amdgcn_raw_buffer_store_b64(v, strsrc, at, 0, 0);
-                            at += 8u;
-                        }
-                    }
-                }
+        const unsigned row0 = t0 + rb + 4u * (unsigned)g;
+        while (__ballot(m != 0)) {                             // wave-uniform
+            if (m) {
+                const unsigned idx = (unsigned)__builtin_ctz(m);
+                m &= m - 1u;
+                const u32x2s v = {(unsigned)myq, row0 + (idx >> 2) * (unsigned)(16 * IVFS_WAVES) + (idx & 3u)};
+                __builtin_amdgcn_raw_buffer_store_b64(v, strsrc, at, 0, 0);
+                at += 8u;
             }
         }
         woff += wtotal;
@@ -3028,7 +3037,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     RC_HIP_CHECK(h, hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(unsigned), s));
     if (ivf_pipe()) {
         auto kern = ivfs_screen_kernel<M>;
-        constexpr int sl = 2 * IVFS_BUF + IVFS_WAVES * IVFS_SCAP * 4;
+        constexpr int sl = 2 * IVFS_BUF;
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
         adc_ivf_tasks TT = T;
         TT.qbyte = qbyte;

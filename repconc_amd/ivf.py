@@ -105,8 +105,8 @@ class IVFPQIndex:
         self._sizes_desc = np.sort(cnt.cpu().numpy())[::-1].astype(np.int64)     # host copy: bounds the sample array
         self.image = None
         if ops.adc_image_supported(self.M) and self.ntotal:
-            self.image = torch.empty((self.ntotal, ops.adc_image_row_bytes(self.M)), dtype=torch.uint8, device=self.device)
-            ops.adc_scan_image_(self.codes, self.image, layout="rows")        # cells start at arbitrary rows: row-major
+            self.image = torch.empty((ops.adc_image_rows_bytes(self.ntotal, self.M),), dtype=torch.uint8, device=self.device)
+            ops.adc_scan_image_(self.codes, self.image, layout="rows")        # blocked by chunks of 16 rows: cells start anywhere
 
     def add(self, x, codes: Optional[torch.Tensor] = None):
         """Index (rotated) embeddings x [N,d]: nearest PQ codes (unless the model's `codes` are given) + coarse cell."""

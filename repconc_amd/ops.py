@@ -493,12 +493,23 @@ def adc_image_supported(M: int) -> bool:
     return adc_image_row_bytes(M) > 0
 
 
+def adc_image_rows_bytes(N: int, M: int) -> int:
+    """Bytes of the IVF search's image (layout "rows") of an N-row index: whole chunks of 16 rows."""
+    return int(_lib.load().rc_adc_scan_image_rows_bytes(int(N), int(M)))
+
+
+def adc_image_rows_at(M: int, n: int, m: int) -> int:
+    """Byte offset of codes[n][m] in the IVF search's image (host-side description, no GPU involved)."""
+    return int(_lib.load().rc_adc_scan_image_rows_at(int(M), int(n), int(m)))
+
+
 def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Optional[int] = None,
                     layout: str = "flat") -> torch.Tensor:
     """(Re)build rows [n0, n0+n) of the permuted code image of an index: codes uint8 [>=n0+n, M] contiguous; image a
     contiguous uint8 buffer of at least adc_image_bytes(n0+n, M) bytes (layout "flat": what `adc_search` takes — row-major
-    for M in {16,32,48,64}, tile-blocked for M = 96) or (n0+n) * adc_image_row_bytes(M) bytes (layout "rows": row-major
-    [N, M] for every M, what the list-centric IVF search takes).  See include/repconc_hip.h rc_adc_scan_image."""
+    for M in {16,32,48,64}, tile-blocked for M = 96) or adc_image_rows_bytes(n0+n, M) bytes (layout "rows": what the
+    list-centric IVF search takes, blocked by chunks of 16 rows; `adc_image_rows_at(M, n, m)` is the byte offset of
+    codes[n][m] in it).  See include/repconc_hip.h rc_adc_scan_image."""
     _need_cuda(codes, image)
     if codes.dtype != torch.uint8 or image.dtype != torch.uint8 or not codes.is_contiguous() or not image.is_contiguous():
         raise ValueError("codes and image must be contiguous uint8")
@@ -507,7 +518,7 @@ def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Op
     M = codes.shape[1]
     if n is None:
         n = codes.shape[0] - n0
-    need = adc_image_bytes(n0 + n, M) if layout == "flat" else (n0 + n) * adc_image_row_bytes(M)
+    need = adc_image_bytes(n0 + n, M) if layout == "flat" else adc_image_rows_bytes(n0 + n, M)
     if n0 < 0 or n < 0 or n0 + n > codes.shape[0] or adc_image_row_bytes(M) == 0 or image.numel() < need:
         raise ValueError("row range outside the code / image buffers")
     lib, h, s, _ = _ctx(codes)

@@ -84,6 +84,11 @@ def test_adc_conflict_free_layout_properties():
     assert lib.rc_adc_cf_describe(24, 0, 0, C.byref(slot), C.byref(m), None, None) == -2     # RC_ESHAPE: no image for M=24
     # image sizes: N x M bytes, in whole 32768-row tiles for the tile-blocked layouts (M = 96; every M of the 16-query screen)
     assert lib.rc_adc_scan_image_bytes(1000, 24) == 0
+    # the IVF search's image: whole chunks of 16 rows; the host-side description is a bijection onto the chunks' bytes
+    assert lib.rc_adc_scan_image_rows_bytes(1000, 24) == 0 and lib.rc_adc_scan_image_rows_bytes(1001, 96) == 1008 * 96
+    for MM in (16, 32, 48, 64, 96):
+        at = sorted(lib.rc_adc_scan_image_rows_at(MM, n, m) for n in range(16, 48) for m in range(MM))
+        assert at == list(range(16 * MM, 48 * MM)) and lib.rc_adc_scan_image_rows_at(MM, 0, MM) == -1
     assert lib.rc_adc_scan_image_bytes(1000, 96) == 32768 * 96 and lib.rc_adc_scan_image_bytes(40000, 96) == 2 * 32768 * 96
     for MM in (16, 32, 48, 64):
         q16 = lib.rc_adc_q16_describe(MM, 0, 0, C.byref(slot))
