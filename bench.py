@@ -561,15 +561,20 @@ def main():
                                            "bound": "mfma", "achieved": round(2.0 * (1 << 18) * nlist * D / cdt / 1e12, 2),
                                            "peak": 157.3, "unit": "TFLOP/s",
                                            "frac": round(2.0 * (1 << 18) * nlist * D / cdt / 1e12 / 157.3, 4)}},
-            "roofline": {"kernel": "adc_screen_cf_kernel<96,2,8,IVF> (list-centric: one block per (cell, <= 8 probing queries), "
-                                   "conflict-free 8-bit screen + exact rescoring); nprobe < 6 takes the per-query scan",
+            "roofline": {"kernel": "ivfs_screen_kernel<96> (list-centric: one persistent block per CU walks (cell, <= 8 probing "
+                                   "queries) tasks; 64 KiB table phases of 32 sub-quantisers in two LDS buffers, the next phase's "
+                                   "tables requested a stage ahead and byte-transposed into the other buffer; conflict-free "
+                                   "ds_read_b64 gathers + i8 MFMA accumulation; survivors to per-wave streams); nprobe < 6 takes "
+                                   "the per-query scan",
                          "bound": "lds-gather", "achieved": round(ivf_gather, 1), "peak": round(256 * 256 * 2.4, 1),
                          "unit": "GB/s", "frac": round(ivf_gather / (256 * 256 * 2.4), 4),
                          "screen_kernel_ms": round(ivf_scan_ms, 3), "nprobe": 128,
                          "note": "nprobe = 128, the screen kernel alone (HIP events): one table byte per (probed row, "
                                  "sub-quantiser, query) - an 8-byte entry per task of 8 queries - against the nominal "
-                                 "conflict-free ds_read_b64 rate (256 CUs x 256 B/clk x 2.4 GHz).  A task is one cell x <= 8 queries: ~7 us of gathers "
-                                 "behind two table fills of 96 KiB each - fill- and latency-bound, not gather-bound",
+                                 "conflict-free ds_read_b64 rate (256 CUs x 256 B/clk x 2.4 GHz).  The 8-query gather engine "
+                                 "itself runs at ~6 cycles per gather (issue/latency, DESIGN 4.2), i.e. 1/3 of that rate; a task "
+                                 "also moves 192 KiB of tables (3.8 GB per 1200-query batch from the memory-side cache) and the "
+                                 "sixteen waves of a block meet at one barrier per table phase",
                          "whole_search_equivalent_code_GBs": round(nq_batch * rows128 * M3 / t128 / 1e9, 1)}}
         del ivf, flat3
         torch.cuda.empty_cache()

@@ -1005,15 +1005,6 @@ struct adc_part_args {
     unsigned nchunks;      // 16-row chunks per group in `buf` (whole tiles)
 };
 
-#ifdef RC_IVF_TRACE
-__device__ unsigned long long adc_ivf_trace[32768 * 8];
-extern "C" int rc_debug_ivf_trace(unsigned long long* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(adc_ivf_trace), sizeof(adc_ivf_trace));
-}
-#define IVF_STAMP(i) do { if (IVF && threadIdx.x == 0 && task < 32768u) adc_ivf_trace[task * 8u + (i)] = wall_clock64(); } while (0)
-#else
-#define IVF_STAMP(i) do { } while (0)
-#endif
 template <int M, int NP, int R, bool IVF = false, int THREADS = ADC_THREADS, int PART = 0>
 __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t* __restrict__ image, int64_t N,
                                                                     const uint8_t* __restrict__ qlut,
@@ -1046,7 +1037,6 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
         if (j >= q + (xcd < rr ? 1u : 0u)) return;                           // padding (block-uniform)
         task = (xcd < rr ? xcd * (q + 1u) : rr * (q + 1u) + (xcd - rr) * q) + j;
     }
-    IVF_STAMP(0);
     // the task's queries (block-uniform scalars), -1 = empty slot
     int tqid[8];
     if constexpr (IVF) {
@@ -1220,7 +1210,6 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             __syncthreads();
             in_lds = phase;
         }
-        IVF_STAMP(2 + 3 * (it & 1));
         if constexpr (PREFETCH) {
             if (it + 1 < nsteps) load_step(it + 1, wn);
         } else {
@@ -1266,7 +1255,6 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             if (c + 2 < R) gather(c + 2, ea);
             if (c + 1 < R) fold(c + 1, eb);
         }
-        IVF_STAMP(3 + 3 * (it & 1));
         if constexpr (PART == 1) {
             // pass 1: the accumulators go to HBM as they are (int16 pairs), nothing is tested
             const unsigned r0p = (unsigned)(it / NPE) * ROUND + (unsigned)(wv * R * 16);
@@ -1349,7 +1337,6 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
     unsigned wa[R][NW], wb[PREFETCH ? R : 1][NW];
     adc_u32x2v pa[PR], pb[PR];
     int in_lds = -1;
-    IVF_STAMP(1);
     if constexpr (PREFETCH) {
         // ping-pong over the two code buffers (and, pass 2, the two partial-sum buffers): no register copies between steps
         load_step(0, wa);
@@ -1361,7 +1348,7 @@ __global__ __launch_bounds__(THREADS, 4) void adc_screen_cf_kernel(const uint8_t
             if (it + 1 < nsteps) run_step(it + 1, wb, wa, in_lds, pb);
         }
     } else {
-        for (int it = 0; it < nsteps; ++it) { run_step(it, wa, wb, in_lds, pa); IVF_STAMP(4 + 3 * (it & 1)); }
+        for (int it = 0; it < nsteps; ++it) run_step(it, wa, wb, in_lds, pa);
     }
 }
 
@@ -1762,12 +1749,7 @@ static bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M 
 // keeps the tables L2-resident.  What the two-phase screen pays over 2 x the one-phase time (20 ms) is the pipeline
 // drain and ramp-up of 16 waves around the two barriers of every 2048-row round.
 static int adc_cf_phase_m(int M) { return M == 96 ? 48 : M; }
-#ifndef RC_IVF96_NP
-#define RC_IVF96_NP 2
-#define RC_IVF96_R 8
-#define RC_IVF96_TH ADC_THREADS
-#endif
-static int adc_ivf_phase_m(int M) { return M == 96 ? 96 / RC_IVF96_NP : M; }   // list-centric IVF screen (ivfl_launch)
+static int adc_ivf_phase_m(int M) { return adc_cf_phase_m(M); }   // table phase of the round-2 IVF screen (RC_IVF_PIPE=0)
 static size_t adc_cf_table_bytes(int M) {                  // per group of 8 queries, all phases
     const int PM = adc_cf_phase_m(M);
     return (size_t)(M / PM) * RC_K * (32 * (PM / 32 + (PM % 32) / 16)) * 8;
@@ -2557,20 +2539,25 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
     auto load_tables = [&](auto PMc, int p, const ivfs_task& d, unsigned (&dd)[DD][8]) {
         constexpr int PM = decltype(PMc)::value;
         constexpr int FI = RC_K * PM / 4 / IVFS_THREADS;      // 2 (PM = 32) or 1
+        // (an empty slot reads query 0's table: its column is masked by the threshold INT_MAX)
 #pragma unroll
-        for (int f = 0; f < FI; ++f)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                // (an empty slot reads query 0's table: its column is masked by the threshold INT_MAX)
-                dd[f][j] = __builtin_amdgcn_raw_buffer_load_b32(qrsrc, tid * 4u, (unsigned)(d.qid[j] < 0 ? 0 : d.qid[j]) * (unsigned)(M * RC_K) +
-                                                                (unsigned)(RC_K * 32 * p + f * 4 * IVFS_THREADS), 0);
+        for (int j = 0; j < 8; ++j) {
+            const unsigned so = (unsigned)(d.qid[j] < 0 ? 0 : d.qid[j]) * (unsigned)(M * RC_K) + (unsigned)(RC_K * 32 * p);
+            if constexpr (FI == 2) {                           // dwords 2 tid, 2 tid + 1 of the query's phase table in one load
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(qrsrc, tid * 8u, so, 0);
+                dd[0][j] = v.x; dd[1][j] = v.y;
+            } else {
+                dd[0][j] = __builtin_amdgcn_raw_buffer_load_b32(qrsrc, tid * 4u, so, 0);
+            }
+        }
     };
     auto write_tables = [&](auto PMc, const unsigned (&dd)[DD][8], unsigned bufoff) {
         constexpr int PM = decltype(PMc)::value;
         constexpr int FI = RC_K * PM / 4 / IVFS_THREADS;
 #pragma unroll
         for (int f = 0; f < FI; ++f) {
-            const unsigned i = tid + (unsigned)(f * IVFS_THREADS);
+            const unsigned i = FI == 2 ? 2u * tid + (unsigned)f : tid;
             const unsigned (&d)[8] = dd[f];
             unsigned o[8];                                   // o[2 t] = queries 0-3 of entry t, o[2 t + 1] = queries 4-7
 #pragma unroll
@@ -2797,12 +2784,6 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
                 using PMc = std::integral_constant<int, ivfs_pm(M, P)>;
                 using PMn = std::integral_constant<int, ivfs_pm(M, PN)>;
                 block_sync();
-#ifdef RC_IVF_TRACE
-#define IVFS_STAMP(i) do { if (tid == 0 && k < 16u && rd == 0) adc_ivf_trace[((blockIdx.x * 16u + k) * 3u + P) * 8u + (i)] = wall_clock64(); } while (0)
-#else
-#define IVFS_STAMP(i) do { } while (0)
-#endif
-                IVFS_STAMP(0);
                 // the next stage: same task (next phase / next round) or the next task's first
                 const bool to_next = LASTP && !more;          // block-uniform
                 const bool has_next = !to_next || nxt.valid;
@@ -2813,30 +2794,17 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
                 nd.nrows = to_next ? nxt.nrows : cur.nrows;
                 const int nrd = to_next ? 0 : (LASTP ? rd + 1 : rd);
                 // its tables are requested now and transposed after this stage's gathers
-#ifndef IVFS_EXP
-#define IVFS_EXP 0
-#endif
-                if ((IVFS_EXP & 2) == 0 && has_next) load_tables(PMn{}, PN, nd, dd);
-                IVFS_STAMP(1);
+                if (has_next) load_tables(PMn{}, PN, nd, dd);
                 const int reff = chunks_of(cur.nrows, rd);
-                if ((IVFS_EXP & 1) == 0) gathers(PMc{}, P == 0, w, bufoff, reff);
-                IVFS_STAMP(2);
-                // (last phase: the codes are requested AFTER the survivor pass - a wait inside it would otherwise also wait for them)
-                if constexpr (!LASTP) { if ((IVFS_EXP & 8) == 0 && has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w); }
-                IVFS_STAMP(3);
+                gathers(PMc{}, P == 0, w, bufoff, reff);
+                // the codes of the next stage go into the registers the gathers just released (last phase: after the survivor
+                // pass, whose few waits would otherwise also wait for them)
+                if constexpr (!LASTP) { if (has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w); }
                 if constexpr (LASTP) {
-                    if ((IVFS_EXP & 4) == 0) epilogue(cur.t0, cur.row_lo, cur.nrows, rd, tq, myq, reff);
-                    if ((IVFS_EXP & 16) != 0) {                 // experiment: keep the sums alive, nothing else
-                        int top = INT_MIN;
-#pragma unroll
-                        for (int c = 0; c < R; ++c) top = max(top, max(max(acc[c][0], acc[c][1]), max(acc[c][2], acc[c][3])));
-                        if (top == 0x7fffffff) stream[tid] = 1u;
-                    }
+                    epilogue(cur.t0, cur.row_lo, cur.nrows, rd, tq, myq, reff);
+                    if (has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w);
                 }
-                if constexpr (LASTP) { if ((IVFS_EXP & 8) == 0 && has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w); }
-                IVFS_STAMP(4);
-                if ((IVFS_EXP & 2) == 0 && has_next) write_tables(PMn{}, dd, bufoff ^ (unsigned)IVFS_BUF);
-                IVFS_STAMP(5);
+                if (has_next) write_tables(PMn{}, dd, bufoff ^ (unsigned)IVFS_BUF);
                 bufoff ^= (unsigned)IVFS_BUF;
             };
             stage(std::integral_constant<int, 0>{});
@@ -2996,14 +2964,9 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
                 int64_t N, const float* lut, int nq, const int* probes, const int* sbase, const int* scount,
                 const int* rows, const int* rank, int nprobe, int64_t sstride, int ss, const adc_ivf_tasks& T, int ntasks,
                 int k, float* scores, int64_t* out_ids, int* status, char* w, const ivfl_ws& L, hipStream_t s) {
-#ifndef RC_IVF96_NP
-#define RC_IVF96_NP 2
-#define RC_IVF96_R 8
-#define RC_IVF96_TH ADC_THREADS
-#endif
-    constexpr int NP = (M == 96) ? RC_IVF96_NP : 1, PM = M / NP;
-    constexpr int R = (NP > 1) ? RC_IVF96_R : (M == 64 ? 2 : 4);
-    constexpr int TH = (NP > 1) ? RC_IVF96_TH : ADC_THREADS;
+    constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP;
+    constexpr int R = (NP > 1) ? 8 : (M == 64 ? 2 : 4);
+    constexpr int TH = ADC_THREADS;
     float* sample = (float*)(w + L.sample);
     float* thr = (float*)(w + L.thr);
     int* tint = (int*)(w + L.tint);
@@ -3051,6 +3014,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(IVFS_THREADS), sl, s, image, (const int*)tint, stream_cnt, stream,
                            (unsigned)L.stream_cap, status, TT, ntasks);
+        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         RC_LAUNCH_CHECK(h);
         {
             const size_t bl = (size_t)nq * sizeof(unsigned);
@@ -3058,7 +3022,6 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
             hipLaunchKernelGGL(ivfs_bucket_kernel, dim3((unsigned)blocks), dim3(IVFS_BUCKET_THREADS), bl, s, (const unsigned*)stream_cnt,
                                (const unsigned*)stream, (unsigned)L.stream_cap, nq, idcnt, ids);
         }
-        rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         RC_LAUNCH_CHECK(h);
     } else {
         auto kern = adc_screen_cf_kernel<M, NP, R, true, TH>;
@@ -3109,7 +3072,7 @@ extern "C" int rc_ivf_search_lists(rc_handle_t h, const uint8_t* codes, const ui
         !task_list || !task_qstart || !task_qcnt || !sorted_q || !scores || !out_ids || !status || N <= 0 || nq < 0 ||
         nprobe <= 0 || sstride <= 0 || ss <= 0 || ntasks < 0 || k <= 0)
         return RC_EINVAL;
-    if (K != RC_K || !adc_cf_supported(M) || k > ADC_CAND_CAP / 2 || N > 0xFFFFFFFFll || RC_ADC_IMG16) return RC_ESHAPE;
+    if (K != RC_K || !adc_cf_supported(M) || k > ADC_CAND_CAP / 2 || N > 0xFFFFFFFFll || RC_ADC_IMG16 || nq > 32768) return RC_ESHAPE;
     if (nq == 0) return RC_OK;
     const ivfl_ws L = ivfl_layout(M, nq, sstride);
     if (!ws || ws_bytes < L.total) return RC_EWORKSPACE;
@@ -3385,7 +3348,7 @@ extern "C" int rc_ivf_search_probes(rc_handle_t h, const uint8_t* codes, const u
     if (!h || !codes || !image || !list_off || !rowmap || !lut || !probes || !scores || !out_ids || !status || N <= 0 ||
         nq < 0 || nprobe <= 0 || nlist <= 0 || nprobe > nlist || sstride <= 0 || ss <= 0 || k <= 0)
         return RC_EINVAL;
-    if (K != RC_K || !adc_cf_supported(M) || k > ADC_CAND_CAP / 2 || N > 0xFFFFFFFFll || RC_ADC_IMG16) return RC_ESHAPE;
+    if (K != RC_K || !adc_cf_supported(M) || k > ADC_CAND_CAP / 2 || N > 0xFFFFFFFFll || RC_ADC_IMG16 || nq > 32768) return RC_ESHAPE;
     if (nq == 0) return RC_OK;
     const ivfl_ws L = ivfl_layout(M, nq, sstride);
     const ivfp_ws P = ivfp_layout(L.total, nq, nprobe, nlist);

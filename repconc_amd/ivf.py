@@ -182,6 +182,10 @@ class IVFPQIndex:
         q = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if as_numpy else x).to(self.device, torch.float32)
         q = q.contiguous()
         nq = q.shape[0]
+        if nq > self.MAX_QUERY_BATCH:                      # the C entries index their per-query workspaces with 32 bits
+            parts = [self.search(q[i:i + self.MAX_QUERY_BATCH], k, nprobe, method) for i in range(0, nq, self.MAX_QUERY_BATCH)]
+            scores, ids = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+            return (scores.cpu().numpy(), ids.cpu().numpy()) if as_numpy else (scores, ids)
         nprobe = min(int(nprobe), self.nlist)
         probes = self.probe(q, nprobe, ordered=False)
         if method not in ("auto", "lists", "lists_host_plan", "scan"):
@@ -251,6 +255,7 @@ class IVFPQIndex:
     SAMPLE_ROWS = 6144              # ... so that about this many sampled rows per query place the candidate threshold
     CAND_CAP = 16384                # candidate keys per query (ADC_CAND_CAP)
     KEEP_ALL_ROWS = 4096            # queries probing no more rows than this re-score every row (no threshold)
+    MAX_QUERY_BATCH = 16384         # queries per C call (rc_ivf_search_lists / _probes refuse more than 32768)
     LISTS_MIN_ROWS = 10000          # "auto": average probed rows per query from which the list-centric search pays (M = 96, 1200 queries: equal at ~8 k)
 
     def _sample_step(self, nprobe: int) -> int:
