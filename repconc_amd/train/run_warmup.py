@@ -22,7 +22,9 @@ the local shard's codes with `id_offset` = its global position.
 """
 from __future__ import annotations
 
+import functools
 import logging
+import math
 from typing import Optional
 
 import numpy as np
@@ -108,47 +110,47 @@ def _reseed_empty(C: torch.Tensor, counts: torch.Tensor):
     ops.kmeans_split_empty_(C, counts.contiguous())
 
 
-def procrustes_rotation(P: torch.Tensor, tol: float = 1e-13, max_iter: int = 160) -> torch.Tensor:
+@functools.lru_cache(maxsize=8)
+def _polar_schedule(lower: float):
+    """Coefficients (a_k, b_k) of the optimally scaled Newton-Schulz iteration X <- a X + b X X^T X for singular values in
+    [lower, 1]: the odd cubic that maps [l, 1] onto [l', 1] with the largest l' equioscillates — p(l) = p(1) = l', maximum 1 at
+    x* = sqrt(a / (-3 b)) — which gives, with s = 1 + l + l^2 and m = (2 s / 3) sqrt(s / 3):  a = s / m,  b = -1 / m,
+    l' = a l + b l^3  (~2.6 l while l is small; a -> 1.5, b -> -0.5, the plain iteration, as l -> 1).  Known on the host
+    without looking at the matrix: the whole iteration enqueues without a synchronisation."""
+    out, ell = [], float(lower)
+    while 1.0 - ell > 1e-16 and len(out) < 200:
+        s = 1.0 + ell + ell * ell
+        m = (2.0 * s / 3.0) * math.sqrt(s / 3.0)
+        a, b = s / m, -1.0 / m
+        out.append((a, b))
+        ell = a * ell + b * ell ** 3
+    return tuple(out) + ((1.5, -0.5),) * 2                     # two plain steps: quadratic, far below fp64 resolution
+
+
+def procrustes_rotation(P: torch.Tensor, lower: float = 1e-12, defer: bool = False):
     """argmax_R tr(R^T P) over the orthogonal matrices = U V^T for P = U S V^T — the orthogonal polar factor of P.
-    Computed with the Newton-Schulz iteration X <- 1.5 X - 0.5 X X^T X (GEMMs only: fp64 768^3 products run on the matrix
-    cores in ~30 us each, where the Jacobi SVD of the library takes 0.23 s — 50 of them were most of the warm-up).
-    The iteration multiplies a small singular value by 1.5 per step and converges quadratically once all of them are near
-    1, i.e. after ~log_1.5(cond) + 5 steps; the Procrustes matrices of OPQ have cond 1e6 ... 1e9 (45 - 60 steps), so
-      * X0 = P / (1.05 sigma_max), sigma_max from a few power iterations (an under-estimate is harmless: the iteration
-        converges for singular values below sqrt(3)) — the norm bound sqrt(|P|_1 |P|_inf) sits 10x above and costs 6 steps;
-      * the convergence test (one host synchronisation) runs every 8th step only.
-    A (numerically) singular P has no unique polar factor: then, or whenever the result is not orthogonal to 1e-9, fall
-    back to the SVD."""
+    Computed with a Newton-Schulz iteration (GEMMs only: fp64 768^3 products run on the matrix cores in ~35 us each, where
+    the Jacobi SVD of the library takes 0.23 s — 50 of them were most of the warm-up).  The plain iteration
+    X <- 1.5 X - 0.5 X X^T X multiplies a small singular value by 1.5 per step; the Procrustes matrices of OPQ have
+    cond 1e6 ... 1e9, i.e. 45 - 60 steps, and its convergence test is a host synchronisation (rounds 2/3a: 3 - 4 per call,
+    17 - 31 ms per OPQ round on a slow host against 7 ms of device time).  Here:
+      * X0 = P / |P|_F: every singular value is <= 1 whatever P is (the scaled steps flip the sign of a singular value above
+        1 — an estimate of sigma_max is not enough);
+      * the steps are scaled optimally for singular values in [lower, 1] (`_polar_schedule`): x2.6 per step while they are
+        small, 36 steps for lower = 1e-12, the same for every matrix — nothing is read back while the iteration runs;
+      * one orthogonality check at the end: |X^T X - I|_max, on the device.  defer=False reads it (ONE synchronisation) and
+        falls back to the library SVD when it is not below 1e-9 (singular P has no unique polar factor; cond above ~1/lower
+        does not converge in the fixed number of steps); defer=True returns (X, err) and leaves the decision to the caller."""
     P = P.double()
     n = P.shape[0]
-    v = torch.ones((n, 1), dtype=P.dtype, device=P.device) / n ** 0.5
-    for _ in range(8):                                          # power iteration on P^T P
-        v = P.T @ (P @ v)
-        v = v / torch.linalg.vector_norm(v).clamp_min(1e-300)
-    scale = 1.05 * torch.linalg.vector_norm(P @ v)
-    # No read of `scale` here: a zero / non-finite scale makes X non-finite, which the convergence reads below report.
-    X = P / scale
-    eye = torch.eye(n, dtype=P.dtype, device=P.device)
-    ok = False
-    first_check = 47                                            # OPQ's matrices need 45 - 60 steps: no reads before that
-    # one step = two library calls (G = X^T X, then X <- 1.5 X - 0.5 X G as ONE GEMM with its epilogue): the host issues
-    # ~110 launches per call instead of ~280 — on a slow host the round was launch-bound (17 - 31 ms against 7 ms of device time)
-    for it in range(max_iter):
-        G = X.T @ X
-        if it >= first_check and (it - first_check) % 8 == 0:
-            err = float((G - eye).abs().max())                  # one host synchronisation
-            if not (err == err) or err == float("inf"):
-                break                                           # singular / non-finite input: SVD below
-            if err < tol ** 0.5:                                # quadratic: two more steps bring it far below tol
-                X = torch.addmm(X, X, G, beta=1.5, alpha=-0.5)
-                X = torch.addmm(X, X, X.T @ X, beta=1.5, alpha=-0.5)
-                ok = True
-                break
-        X = torch.addmm(X, X, G, beta=1.5, alpha=-0.5)
-    if ok:
-        ok = float((X.T @ X - eye).abs().max()) < 1e-9
-        if ok:
-            return X
+    X = P / torch.linalg.matrix_norm(P)                        # zero / non-finite P: X non-finite, reported by `err`
+    for a, b in _polar_schedule(float(lower)):
+        X = torch.addmm(X, X, X.T @ X, beta=a, alpha=b)        # one step = two library calls
+    err = (X.T @ X - torch.eye(n, dtype=P.dtype, device=P.device)).abs().max()
+    if defer:
+        return X, err
+    if float(err) < 1e-9:                                      # (NaN compares false)
+        return X
     U, _, Vh = torch.linalg.svd(P)
     return U @ Vh
 
@@ -179,7 +181,7 @@ def train_pq(x: torch.Tensor, M: int, n_iter: int, centroids: Optional[torch.Ten
 
 
 def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, n_pq: int = 4, seed: int = SEED,
-              R0: Optional[torch.Tensor] = None, history: Optional[list] = None):
+              R0: Optional[torch.Tensor] = None, history: Optional[list] = None, _sync_procrustes: bool = False):
     """OPQ rotation R [D,D] (x_rot = x @ R) by alternating PQ training and orthogonal Procrustes.  `R0`: starting
     rotation (default: QR of a seeded Gaussian matrix, the same on every rank); `history`: list that receives the
     reconstruction MSE of every round (what oracle/pq_oracle.py::train_opq returns, for the parity test)."""
@@ -191,19 +193,32 @@ def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, 
         R0 = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64).to(x.device))[0]
     R = R0.float().to(x.device).contiguous()
     C = None
-    mses = []
+    mses, errs = [], []
     for it in range(n_outer):
         xr = (x @ R).contiguous()
-        # the round's only host synchronisations are the convergence reads of the Procrustes iteration: the Lloyd
-        # iterations (assignment, statistics, update, empty-cluster rule) and the error enqueue without one
+        # No host synchronisation in a round: the Lloyd iterations (assignment, statistics, update, empty-cluster rule), the
+        # error and the Procrustes iteration (fixed schedule, orthogonality check left on the device) only enqueue; the
+        # checks of all rounds are read once, after the last one.
         C, mse = train_pq(xr, M, n_pq_first if it == 0 else n_pq, centroids=C, seed=seed, mse_on_device=True)
         mses.append(mse)
         codes = ops.assign_nearest(xr, C, torch.uint8)
         xrec = ops.decode_raw(codes, C)
         P = (x.T @ xrec).double()
         rank_ordered_sum_(P)                                    # Procrustes matrix over the rows of every rank
-        R = procrustes_rotation(P).float().contiguous()        # fp64: keeps R orthogonal to ~1e-7 after the cast
-    mses = [float(v) for v in torch.stack(mses).cpu()] if mses else []
+        if _sync_procrustes:
+            R = procrustes_rotation(P)
+        else:
+            R, err = procrustes_rotation(P, defer=True)
+            errs.append(err)
+        R = R.float().contiguous()                              # fp64 iteration: R stays orthogonal to ~1e-7 after the cast
+    vals = [float(v) for v in torch.stack(mses + errs).double().cpu()] if mses else []     # the one synchronisation
+    mses, errs = vals[:len(mses)], vals[len(mses):]
+    if any(not (e < 1e-9) for e in errs):
+        # a Procrustes matrix the fixed schedule did not orthogonalise (singular, or cond above ~1e12): every rank sees the
+        # same values and repeats the training with the checked iteration (library SVD as its fall-back)
+        logger.warning("OPQ: a Procrustes step did not converge (max |R^T R - I| = %.3g); repeating with per-round checks",
+                       max((e for e in errs if e == e), default=float("nan")))
+        return train_opq(x, M, n_outer, n_pq_first, n_pq, seed, R0, history, _sync_procrustes=True)
     if history is not None:
         history.extend(mses)
     for it, v in enumerate(mses):
