@@ -2952,6 +2952,10 @@ ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
     // (query, row) streams of the pipelined screen: one per wave of its <= IVFS_MAX_BLOCKS persistent blocks
     size_t cap = (size_t)nq * (ADC_ID_CAP / 2) / (IVFS_MAX_BLOCKS * IVFS_WAVES);
     if (cap < 4096) cap = 4096;
+    if (const char* e = getenv("RC_IVF_STREAM_CAP")) {      // tests: provoke the overflow path (status bit 1 -> less slack -> scan)
+        const long v = atol(e);
+        if (v > 0) cap = (size_t)v;
+    }
     L.stream_cap = cap;
     L.stream_cnt = o; o += rc_align_up((size_t)IVFS_MAX_BLOCKS * IVFS_WAVES * sizeof(unsigned), 256);
     L.stream = o;     o += rc_align_up((size_t)IVFS_MAX_BLOCKS * IVFS_WAVES * cap * 8, 256);

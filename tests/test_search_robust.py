@@ -169,3 +169,52 @@ def test_ivf_search_never_raises_on_degenerate_cells(method):
         ws, wi = pq_oracle.ivf_search(q, C, codes, cells, coarse, k, nprobe)
         assert np.array_equal(i.cpu().numpy(), wi), (method, nprobe)
         assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("M", [32, 48, 96])
+def test_ivf_pipelined_screen_on_cells_of_several_rounds(M):
+    """Cells far larger than the 2048 rows a block screens per round (several rounds per task, ragged last chunk, first row
+    of a cell in the middle of a chunk), cells smaller than one chunk, empty cells, fewer queries than a task holds and
+    queries that keep every row: the list-centric search (persistent pipelined screen, survivor streams, bucket pass)
+    equals the oracle's brute force over the probed cells."""
+    from oracle import pq_oracle
+    from repconc_amd.ivf import IVFPQIndex
+    nlist, N, k = 12, 70001, 300
+    rng = np.random.default_rng(4100 + M)
+    codes = synth.uniform_codes(4101 + M, N, M)
+    cells = rng.choice(nlist, N, p=[0.45, 0.3, 0.15, 0.05, 0.03, 0.0199, 0.0001, 0, 0, 0, 0, 0])   # 31 k-row cell ... 7 rows, empty
+    C = synth.gaussian(4102 + M, (M, 256, 768 // M))
+    coarse = synth.gaussian(4103 + M, (nlist, 768))
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(_t(C))
+    ivf.coarse = _t(coarse)
+    ivf.set_lists(_t(codes), _t(cells))
+    for nq, nprobe in ((3, 2), (19, 5), (70, nlist)):
+        q = synth.gaussian(4104 + M + nq, (nq, 768))
+        s, i = ivf.search(_t(q), k, nprobe, method="lists")
+        ws, wi = pq_oracle.ivf_search(q, C, codes, cells, coarse, k, nprobe)
+        assert np.array_equal(i.cpu().numpy(), wi), (M, nq, nprobe)
+        assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+def test_ivf_survivor_stream_overflow_is_answered_not_raised(monkeypatch):
+    """A wave's survivor stream too small for what it keeps (RC_IVF_STREAM_CAP: a test knob of the workspace layout): the
+    screen drops the overflow and raises status bit 1, the search narrows the slack and finally takes the per-query scan —
+    the answer is still the oracle's."""
+    from oracle import pq_oracle
+    from repconc_amd.ivf import IVFPQIndex
+    M, nlist, N, nq, k, nprobe = 48, 40, 120000, 24, 500, 10
+    rng = np.random.default_rng(77)
+    codes = synth.uniform_codes(78, N, M)
+    cells = rng.integers(0, nlist, N)
+    C = synth.gaussian(79, (M, 256, 768 // M))
+    coarse = synth.gaussian(80, (nlist, 768))
+    q = synth.gaussian(81, (nq, 768))
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(_t(C))
+    ivf.coarse = _t(coarse)
+    ivf.set_lists(_t(codes), _t(cells))
+    monkeypatch.setenv("RC_IVF_STREAM_CAP", "16")
+    s, i = ivf.search(_t(q), k, nprobe, method="lists")
+    ws, wi = pq_oracle.ivf_search(q, C, codes, cells, coarse, k, nprobe)
+    assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
