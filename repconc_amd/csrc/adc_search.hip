@@ -1560,6 +1560,12 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     };
     auto run_step = [&](int it, const adc_u32x4v (&w)[NV], adc_u32x4v (&wn)[NV]) {
         if (it > 0 && phase_of(it) != phase_of(it - 1)) {
+            if constexpr (NPH <= 2) {
+                // both phases' tables stay in the two buffers (M = 32): a phase change is an address offset, nothing else
+                buf ^= 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) offb[j] = off[j] + (unsigned)buf * (unsigned)BUF;
+            } else {
             // phase change: this phase's tables were requested into the other buffer one segment ago
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces have landed
             __syncthreads();                                 // everybody's have, and everybody is done with the old buffer
@@ -1568,6 +1574,7 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             for (int j = 0; j < 4; ++j) offb[j] = off[j] + (unsigned)buf * (unsigned)BUF;
             const int nx = next_change(it);
             if (nx < nsteps) stage(phase_of(nx), buf ^ 1);   // the buffer just vacated
+            }
         }
         if (it + 1 < nsteps) load_step(it + 1, wn);
         // Software pipeline over the chunks: the 4 gathers of chunk c + 1 are ISSUED before the 4 MFMAs of chunk c (the
@@ -1648,11 +1655,12 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     };
     // prologue: first phase into buffer 0, the next distinct phase into buffer 1
     stage(phase_of(0), 0);
+    if constexpr (NPH == 2) stage(1, 1);                     // phase p lives in buffer p for the whole block (phase_of(0) = 0)
     adc_u32x4v wa[NV], wb[NV];
     load_step(0, wa);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    {
+    if constexpr (NPH > 2) {
         const int nx = next_change(0);
         if (nx < nsteps) stage(phase_of(nx), 1);
     }

@@ -54,7 +54,29 @@ __global__ __launch_bounds__(THREADS) void k(unsigned* out, long long* cyc, unsi
         unsigned w[NG / 4];
 #pragma unroll
         for (int j = 0; j < NG / 4; ++j) { rnd = __umul24(rnd, 0x6255u) + 0x3c6ef35fu + j; w[j] = rnd; }   // 1-2 full-rate VALU per 4 gathers
-        if constexpr (KIND == 2) {
+        if constexpr (KIND == 3) {
+            // ds_read_b96: dense 12-byte entries, [block of 16 sub-quantisers][code][16 slots][12 B] (192-byte rows: a code
+            // shifts the banks by 48 mod 64, so lanes with different codes can collide - what does that cost?)
+            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+            u32x3 e[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const unsigned off = base + (unsigned)(g & 1) * 49152u + (unsigned)((pos128 + g) & 15) * 12u;
+                unsigned addr;
+                asm("v_bfe_u32 %0, %1, %2, 8\n\tv_mad_u32_u24 %0, %0, %3, %4" : "=&v"(addr) : "v"(w[g >> 2]), "n"(8 * (g & 3)), "v"(192u), "v"(off));
+                e[g] = *reinterpret_cast<const u32x3 __attribute__((address_space(3)))*>(addr);
+            }
+            if constexpr (MFMA) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const i32x4 a = {(int)e[g].x, (int)e[g].y, (int)e[g].z, 0};
+                    macc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, macc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { acc0 ^= e[g].x ^ e[g].z; acc1 += e[g].y; }
+            }
+        } else if constexpr (KIND == 2) {
             uint4 e[NG];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -147,7 +169,7 @@ void run(const char* name, int blocks) {
     std::vector<long long> hc(2 * blocks); hipMemcpy(hc.data(), cyc, (size_t)blocks * 16, hipMemcpyDeviceToHost);
     double cy = 0, wl = 0; for (int i = 0; i < blocks; ++i) { cy += hc[2 * i]; wl += hc[2 * i + 1]; } cy /= blocks; wl /= blocks;
     const double instr_per_cu = (THREADS / 64.0) * ITERS * NG;    // wave-instructions per CU (one block per CU)
-    const double bytes = (KIND == 2 ? 1024.0 : 512.0);
+    const double bytes = (KIND == 2 ? 1024.0 : KIND == 3 ? 768.0 : 512.0);
     const double ghz = cy / (wl * 10.0);                          // wall_clock64 ticks are 10 ns
     const double ns = ms * 1e6 / instr_per_cu;
     printf("%-34s %s blk %3d thr %4d | launch %.3f ms (cold %.3f) | %5.2f ns = %5.2f cyc per gather per CU (wave 0 alone: %4.2f) | clock %.2f GHz (sysfs %s) | %5.1f B/clk/CU | chip %5.1f TB/s\n",
@@ -159,6 +181,13 @@ void run(const char* name, int blocks) {
 
 int main(int argc, char** argv) {
     if (argc > 1) g_warm_ms = atof(argv[1]);
+    if (argc > 2 && !strcmp(argv[2], "b96")) {               // the question of the 12-query single-phase screen only
+        run<12, 2, true, 1024>("b128 conflict-free 12 + 12 MFMA", 256);
+        run<12, 3, false, 1024>("b96 dense rows, random codes 12", 256);
+        run<12, 3, true, 1024>("b96 dense rows 12 + 12 MFMA", 256);
+        run<24, 3, true, 1024>("b96 dense rows 24 + 24 MFMA", 256);
+        return 0;
+    }
     printf("LDS gather ubench: ITERS=%d, warm-up %.0f ms per config; idle sclk now: %s\n", ITERS, g_warm_ms, sysfs_sclk().c_str());
     // the LDS alone (no address arithmetic)
     run<12, 0, false, 1024, 1>("b64 conflict-free 12", 256);
