@@ -218,3 +218,33 @@ def test_ivf_survivor_stream_overflow_is_answered_not_raised(monkeypatch):
     s, i = ivf.search(_t(q), k, nprobe, method="lists")
     ws, wi = pq_oracle.ivf_search(q, C, codes, cells, coarse, k, nprobe)
     assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+def test_round2_ivf_screen_stays_selectable(tmp_path):
+    """RC_IVF_PIPE=0 (read once per process) selects the round-2 IVF screen and its row-major image — the A/B partner of the
+    pipelined screen in DESIGN 7: a fresh process built that way returns the same ids and score bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from oracle import synth\n"
+        "from repconc_amd.ivf import IVFPQIndex\n"
+        "M, nlist, N, nq, k = 96, 50, 90000, 40, 200\n"
+        "rng = np.random.default_rng(5)\n"
+        "ivf = IVFPQIndex(768, M, nlist, device='cuda')\n"
+        "ivf.set_centroids(torch.from_numpy(synth.gaussian(1, (M, 256, 768 // M))).cuda())\n"
+        "ivf.coarse = torch.from_numpy(synth.gaussian(2, (nlist, 768))).cuda()\n"
+        "ivf.set_lists(torch.from_numpy(synth.uniform_codes(3, N, M)).cuda(), torch.from_numpy(rng.integers(0, nlist, N)).cuda())\n"
+        "s, i = ivf.search(torch.from_numpy(synth.gaussian(4, (nq, 768))).cuda(), k, 12, method='lists')\n"
+        "np.save(sys.argv[1], i.cpu().numpy()); np.save(sys.argv[2], s.cpu().numpy())\n")
+    got = {}
+    for pipe in ("1", "0"):
+        fi, fs = str(tmp_path / f"i{pipe}.npy"), str(tmp_path / f"s{pipe}.npy")
+        env = dict(os.environ, RC_IVF_PIPE=pipe)
+        r = subprocess.run([sys.executable, "-c", code, fi, fs], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[pipe] = (np.load(fi), np.load(fs))
+    assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1].view(np.uint32), got["0"][1].view(np.uint32))
