@@ -337,6 +337,35 @@ def test_adc_large_index_properties():
     assert bool(((s > kth).sum(1) <= inside).all())
 
 
+def test_ivf_baseline_size_properties():
+    """BASELINE configs[3] at its full size (8.84 M x 96 B in 5000 cells, nprobe 128, k = 1000): the list-centric search
+    (pipelined 8-bit screen, streams, bucket pass, exact rescoring) equals the per-query exact scan — an independent
+    kernel chain — in ids and score bits; scores are sorted, ids lie in probed cells, a planted best row is found."""
+    from repconc_amd import ops
+    from repconc_amd.ivf import IVFPQIndex
+    N, M, nlist, nq, k, nprobe = 8841823, 96, 5000, 40, 1000, 128
+    gen = torch.Generator(device=DEV).manual_seed(4242)
+    codes = torch.randint(0, 256, (N, M), dtype=torch.uint8, device=DEV, generator=gen)
+    cells = torch.randint(0, nlist, (N,), device=DEV, generator=gen)
+    C = _t(synth.gaussian(4243, (M, 256, 768 // M)))
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(C)
+    ivf.coarse = _t(synth.gaussian(4244, (nlist, 768)))
+    q = _t(synth.gaussian(4245, (nq, 768)))
+    probes = ivf.probe(q, nprobe, ordered=False)
+    # plant: the best possible row for query 0 inside one of ITS probed cells
+    best = ops.adc_lut(C, q[:1]).argmax(dim=2).to(torch.uint8)[0]
+    victim = int(torch.nonzero(cells == probes[0, 5])[3])
+    codes[victim] = best
+    ivf.set_lists(codes, cells)
+    s1, i1 = ivf.search(q, k, nprobe, method="lists")
+    s2, i2 = ivf.search(q, k, nprobe, method="scan")
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+    assert bool((s1[:, :-1] >= s1[:, 1:]).all()) and int(i1[0, 0]) == victim
+    hit_cells = cells[i1.reshape(-1)].reshape(nq, k)
+    assert bool((hit_cells.unsqueeze(2) == probes.long().unsqueeze(1)).any(2).all())
+
+
 # ------------------------------------------------------------------------------------------- model API
 class _TableEncoder(torch.nn.Module):
     def __init__(self, table):
