@@ -2486,14 +2486,19 @@ struct ivfs_task {
     unsigned row_lo, nrows;   // rows [row_lo, nrows) counted from t0 are the cell's (nrows = 0: nothing to scan)
 };
 
-template <int M>
+// LW = 0: every wave gathers and takes its share of the table fills.  LW = 2 (wave specialisation): the block's last two waves
+// do nothing but fetch, transpose and store the NEXT stage's tables while the other fourteen gather — the fill runs beside
+// the gathers instead of after them (the sixteen waves of the LW = 0 form do the same thing at the same time).
+template <int M, int LW>
 __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint8_t* __restrict__ image,
                                                                       const int* __restrict__ tint,
                                                                       unsigned* __restrict__ stream_cnt,
                                                                       unsigned* __restrict__ stream, unsigned stream_cap,
                                                                       int* __restrict__ status, adc_ivf_tasks T,
                                                                       int ntasks_arg) {
-    constexpr int NPH = ivfs_phases(M), R = IVFS_R, ROUND = IVFS_WAVES * R * 16;
+    constexpr int GW = IVFS_WAVES - LW;                       // gathering waves
+    constexpr int R = (LW == 4) ? 10 : IVFS_R;              // twelve gathering waves: ten chunks each cover a 1920-row round
+    constexpr int NPH = ivfs_phases(M), ROUND = GW * R * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
     const int l = (int)(tid & 63u), wv = __builtin_amdgcn_readfirstlane((int)(tid >> 6)), r = l & 15, g = l >> 4;
@@ -2560,36 +2565,63 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
             }
         }
     };
+    // byte transpose of dword i of the eight queries' phase tables -> the 32 bytes of LDS entries 4 u .. 4 u + 3 of its code
+    auto emit_entry = [&](auto PMc, const unsigned (&d)[8], unsigned i, unsigned bufoff) {
+        constexpr int PM = decltype(PMc)::value;
+        unsigned o[8];                                       // o[2 t] = queries 0-3 of entry t, o[2 t + 1] = queries 4-7
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+            const unsigned a0 = d[4 * hq], a1 = d[4 * hq + 1], a2 = d[4 * hq + 2], a3 = d[4 * hq + 3];
+            const unsigned t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+            const unsigned u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+            o[0 + hq] = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+            o[2 + hq] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+            o[4 + hq] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+            o[6 + hq] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+        }
+        const uint4 lo4 = make_uint4(o[0], o[1], o[2], o[3]), hi4 = make_uint4(o[4], o[5], o[6], o[7]);
+        if constexpr (PM == 32) {
+            uint4* e = reinterpret_cast<uint4*>(smem + (bufoff + i * 32u));
+            e[0] = lo4;
+            e[1] = hi4;
+        } else {
+            uint4* e = reinterpret_cast<uint4*>(smem + (bufoff + (i >> 2) * 256u + (i & 3u) * 32u));
+            e[0] = lo4;
+            e[1] = hi4;
+            e[8] = lo4;                                      // second copy, 16 slots further
+            e[9] = hi4;
+        }
+    };
     auto write_tables = [&](auto PMc, const unsigned (&dd)[DD][8], unsigned bufoff) {
         constexpr int PM = decltype(PMc)::value;
         constexpr int FI = RC_K * PM / 4 / IVFS_THREADS;
 #pragma unroll
-        for (int f = 0; f < FI; ++f) {
-            const unsigned i = FI == 2 ? 2u * tid + (unsigned)f : tid;
-            const unsigned (&d)[8] = dd[f];
-            unsigned o[8];                                   // o[2 t] = queries 0-3 of entry t, o[2 t + 1] = queries 4-7
+        for (int f = 0; f < FI; ++f) emit_entry(PMc, dd[f], FI == 2 ? 2u * tid + (unsigned)f : tid, bufoff);
+    };
+    // loader waves (LW > 0): the whole phase by LW * 64 threads, in batches of 4 x 8 eight-byte loads (64 registers)
+    auto loader_fill = [&](auto PMc, int p, const ivfs_task& d, unsigned bufoff) {
+        constexpr int PM = decltype(PMc)::value;
+        constexpr int LT = (LW > 0 ? LW : 1) * 64, NPAIR = RC_K * PM / 8, ITER = NPAIR / LT, BATCH = ITER < 4 ? ITER : 4;
+        static_assert(NPAIR % LT == 0 && ITER % BATCH == 0, "whole batches");
+        const unsigned lt = tid - (unsigned)(GW * 64);
+        unsigned so[8];
 #pragma unroll
-            for (int hq = 0; hq < 2; ++hq) {
-                const unsigned a0 = d[4 * hq], a1 = d[4 * hq + 1], a2 = d[4 * hq + 2], a3 = d[4 * hq + 3];
-                const unsigned t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
-                const unsigned u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
-                o[0 + hq] = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
-                o[2 + hq] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
-                o[4 + hq] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
-                o[6 + hq] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
-            }
-            const uint4 lo4 = make_uint4(o[0], o[1], o[2], o[3]), hi4 = make_uint4(o[4], o[5], o[6], o[7]);
-            if constexpr (PM == 32) {
-                uint4* e = reinterpret_cast<uint4*>(smem + (bufoff + i * 32u));
-                e[0] = lo4;
-                e[1] = hi4;
-            } else {
-                uint4* e = reinterpret_cast<uint4*>(smem + (bufoff + (i >> 2) * 256u + (i & 3u) * 32u));
-                e[0] = lo4;
-                e[1] = hi4;
-                e[8] = lo4;                                  // second copy, 16 slots further
-                e[9] = hi4;
-            }
+        for (int j = 0; j < 8; ++j) so[j] = (unsigned)(d.qid[j] < 0 ? 0 : d.qid[j]) * (unsigned)(M * RC_K) + (unsigned)(RC_K * 32 * p);
+#pragma unroll
+        for (int b0 = 0; b0 < ITER; b0 += BATCH) {
+            unsigned dq[BATCH][2][8];
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(qrsrc, ((unsigned)((b0 + it) * LT) + lt) * 8u, so[j], 0);
+                    dq[it][0][j] = v.x; dq[it][1][j] = v.y;
+                }
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) emit_entry(PMc, dq[it][f], 2u * ((unsigned)((b0 + it) * LT) + lt) + (unsigned)f, bufoff);
         }
     };
     // ---- codes of one stage: chunk c of wave wv is chunk 16 c + wv of the round (the waves share a short cell evenly:
@@ -2599,7 +2631,8 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
         if (nrows <= done) return 0;
         unsigned nc = (nrows - done + 15u) / 16u;             // chunks of the round that hold rows of the cell
         if (nc > (unsigned)(ROUND / 16)) nc = ROUND / 16;
-        const int mine = ((int)nc - wv + IVFS_WAVES - 1) / IVFS_WAVES;
+        if (wv >= GW) return 0;                                // a loader wave
+        const int mine = ((int)nc - wv + GW - 1) / GW;
         return mine < 0 ? 0 : mine;
     };
     auto load_codes = [&](auto PMc, int p, unsigned t0, unsigned nrows, int rd, unsigned (&w)[R][2]) {
@@ -2615,7 +2648,7 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
 #pragma unroll
         for (int c = 0; c < R; ++c) {
             if (c < reff) {                                    // wave-uniform
-                const unsigned so = first + (unsigned)(c * IVFS_WAVES * 16 * M);
+                const unsigned so = first + (unsigned)(c * GW * 16 * M);
                 if constexpr (NW == 2) {
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_at, so, 0);
@@ -2713,31 +2746,32 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
         (void*)(stream + (size_t)(blockIdx.x * IVFS_WAVES + (unsigned)wv) * stream_cap * 2u), 0, -1, 0x00020000);
     unsigned woff = 0;                                        // wave-uniform: pairs in the wave's stream
     typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
-    static_assert(R * 4 <= 32, "one mask bit per sum");
+    static_assert(R * 4 <= 64, "one mask bit per sum");
+    typedef typename std::conditional<(R * 4 <= 32), unsigned, unsigned long long>::type mask_t;
     auto epilogue = [&](unsigned t0, unsigned row_lo, unsigned nrows, int rd, int tq, int myq, int reff) {
         if (reff <= 0) return;                                // wave-uniform: no rows of the cell in this wave's share
         const unsigned rb = (unsigned)rd * ROUND + (unsigned)(wv * 16);      // first row of the wave's chunk 0
-        unsigned m = 0;                                       // bit 4 c + e: D[row 4 g + e of chunk c][column r] survives
+        mask_t m = 0;                                         // bit 4 c + e: D[row 4 g + e of chunk c][column r] survives
 #pragma unroll
         for (int c = 0; c < R; ++c) {
             if (c < reff) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) m |= (acc[c][e] >= tq) ? (1u << (4 * c + e)) : 0u;
+                for (int e = 0; e < 4; ++e) m |= (acc[c][e] >= tq) ? ((mask_t)1 << (4 * c + e)) : (mask_t)0;
             }
         }
         // rows outside the cell (before its first row in the first chunk, after its last in the last): never survivors
 #pragma unroll
         for (int c = 0; c < R; ++c) {
-            const unsigned cb = rb + (unsigned)(16 * IVFS_WAVES * c);
+            const unsigned cb = rb + (unsigned)(16 * GW * c);
             if (c < reff && (cb < row_lo || cb + 16u > nrows)) {           // wave-uniform, rare
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned n = cb + 4u * g + e;
-                    if (n < row_lo || n >= nrows) m &= ~(1u << (4 * c + e));
+                    if (n < row_lo || n >= nrows) m &= ~((mask_t)1 << (4 * c + e));
                 }
             }
         }
-        const unsigned cnt = (unsigned)__popc(m);
+        const unsigned cnt = (unsigned)__popcll((unsigned long long)m);
         if (!__ballot(cnt != 0)) return;
         const unsigned c0 = __shfl(cnt, r), c1 = __shfl(cnt, r + 16), c2 = __shfl(cnt, r + 32), c3 = __shfl(cnt, r + 48);
         const unsigned tot = c0 + c1 + c2 + c3;
@@ -2757,9 +2791,9 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
         const unsigned row0 = t0 + rb + 4u * (unsigned)g;
         while (__ballot(m != 0)) {                             // wave-uniform
             if (m) {
-                const unsigned idx = (unsigned)__builtin_ctz(m);
-                m &= m - 1u;
-                const u32x2s v = {(unsigned)myq, row0 + (idx >> 2) * (unsigned)(16 * IVFS_WAVES) + (idx & 3u)};
+                const unsigned idx = (unsigned)__builtin_ctzll((unsigned long long)m);
+                m &= m - (mask_t)1;
+                const u32x2s v = {(unsigned)myq, row0 + (idx >> 2) * (unsigned)(16 * GW) + (idx & 3u)};
                 __builtin_amdgcn_raw_buffer_store_b64(v, strsrc, at, 0, 0);
                 at += 8u;
             }
@@ -2768,62 +2802,84 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
     };
     auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    // ---- prologue
-    ivfs_task cur = load_task(0);
-    if (!cur.valid) return;                                   // block-uniform
-    int myq = lane_q(cur), tq = lane_thr(myq);
-    unsigned dd[DD][8];
-    unsigned w[R][2];
+    // ---- prologue: every thread helps with the first tables
+    const ivfs_task first = load_task(0);
+    if (!first.valid) return;                                 // block-uniform
     using P0 = std::integral_constant<int, ivfs_pm(M, 0)>;
-    load_tables(P0{}, 0, cur, dd);
-    load_codes(P0{}, 0, cur.t0, cur.nrows, 0, w);
-    write_tables(P0{}, dd, 0u);
-    unsigned bufoff = 0;
-    unsigned k = 0;
-    for (;;) {                                                // tasks of this block
-        const ivfs_task nxt = load_task(k + 1);               // used in this task's LAST stage (and for its thresholds after)
-        const int nrounds = rounds_of(cur);
-        for (int rd = 0; rd < nrounds; ++rd) {
-            const bool more = rd + 1 < nrounds;               // block-uniform
-            auto stage = [&](auto Pc) {
-                constexpr int P = decltype(Pc)::value;
-                constexpr bool LASTP = (P == NPH - 1);
-                constexpr int PN = LASTP ? 0 : P + 1;         // phase of the next stage
-                using PMc = std::integral_constant<int, ivfs_pm(M, P)>;
-                using PMn = std::integral_constant<int, ivfs_pm(M, PN)>;
-                block_sync();
-                // the next stage: same task (next phase / next round) or the next task's first
-                const bool to_next = LASTP && !more;          // block-uniform
-                const bool has_next = !to_next || nxt.valid;
-                ivfs_task nd;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) nd.qid[j] = to_next ? nxt.qid[j] : cur.qid[j];
-                nd.t0 = to_next ? nxt.t0 : cur.t0;
-                nd.nrows = to_next ? nxt.nrows : cur.nrows;
-                const int nrd = to_next ? 0 : (LASTP ? rd + 1 : rd);
-                // its tables are requested now and transposed after this stage's gathers
-                if (has_next) load_tables(PMn{}, PN, nd, dd);
-                const int reff = chunks_of(cur.nrows, rd);
-                gathers(PMc{}, P == 0, w, bufoff, reff);
-                // the codes of the next stage go into the registers the gathers just released (last phase: after the survivor
-                // pass, whose few waits would otherwise also wait for them)
-                if constexpr (!LASTP) { if (has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w); }
-                if constexpr (LASTP) {
-                    epilogue(cur.t0, cur.row_lo, cur.nrows, rd, tq, myq, reff);
-                    if (has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w);
-                }
-                if (has_next) write_tables(PMn{}, dd, bufoff ^ (unsigned)IVFS_BUF);
-                bufoff ^= (unsigned)IVFS_BUF;
-            };
-            stage(std::integral_constant<int, 0>{});
-            if constexpr (NPH > 1) stage(std::integral_constant<int, 1>{});
-            if constexpr (NPH > 2) stage(std::integral_constant<int, 2>{});
-        }
-        if (!nxt.valid) break;
-        cur = nxt;
-        myq = lane_q(cur); tq = lane_thr(myq);
-        ++k;
+    {
+        unsigned dd[DD][8];
+        load_tables(P0{}, 0, first, dd);
+        write_tables(P0{}, dd, 0u);
     }
+    // ---- the walk over (task, round, phase) stages, once per role: a loader wave runs its own copy of the loop — it meets the
+    // gathering waves at every barrier but never holds their sums / codes (as one loop with a branch per stage, the compiler
+    // keeps those 60 registers live through the loader's branch and spills 300 bytes per lane)
+    auto walk = [&](auto ROLEc) {
+        constexpr bool LOADER = decltype(ROLEc)::value == 1;
+        ivfs_task cur = first;
+        int myq = -1, tq = INT_MAX;
+        unsigned dd[DD][8];
+        unsigned w[R][2];
+        if constexpr (!LOADER) {
+            myq = lane_q(cur); tq = lane_thr(myq);
+            load_codes(P0{}, 0, cur.t0, cur.nrows, 0, w);
+        }
+        unsigned bufoff = 0;
+        unsigned k = 0;
+        for (;;) {                                            // tasks of this block
+            const ivfs_task nxt = load_task(k + 1);           // used in this task's LAST stage (and for its thresholds after)
+            const int nrounds = rounds_of(cur);
+            for (int rd = 0; rd < nrounds; ++rd) {
+                const bool more = rd + 1 < nrounds;           // block-uniform
+                auto stage = [&](auto Pc) {
+                    constexpr int P = decltype(Pc)::value;
+                    constexpr bool LASTP = (P == NPH - 1);
+                    constexpr int PN = LASTP ? 0 : P + 1;     // phase of the next stage
+                    using PMc = std::integral_constant<int, ivfs_pm(M, P)>;
+                    using PMn = std::integral_constant<int, ivfs_pm(M, PN)>;
+                    block_sync();
+                    // the next stage: same task (next phase / next round) or the next task's first
+                    const bool to_next = LASTP && !more;      // block-uniform
+                    const bool has_next = !to_next || nxt.valid;
+                    ivfs_task nd;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) nd.qid[j] = to_next ? nxt.qid[j] : cur.qid[j];
+                    nd.t0 = to_next ? nxt.t0 : cur.t0;
+                    nd.nrows = to_next ? nxt.nrows : cur.nrows;
+                    const int nrd = to_next ? 0 : (LASTP ? rd + 1 : rd);
+                    if constexpr (LOADER) {
+                        if (has_next) loader_fill(PMn{}, PN, nd, bufoff ^ (unsigned)IVFS_BUF);
+                    } else {
+                        // (LW = 0) the next tables are requested now and transposed after this stage's gathers
+                        if (LW == 0 && has_next) load_tables(PMn{}, PN, nd, dd);
+                        const int reff = chunks_of(cur.nrows, rd);
+                        gathers(PMc{}, P == 0, w, bufoff, reff);
+                        // the codes of the next stage go into the registers the gathers just released (last phase: after the
+                        // survivor pass, whose few waits would otherwise also wait for them)
+                        if constexpr (!LASTP) { if (has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w); }
+                        if constexpr (LASTP) {
+                            epilogue(cur.t0, cur.row_lo, cur.nrows, rd, tq, myq, reff);
+                            if (has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w);
+                        }
+                        if (LW == 0 && has_next) write_tables(PMn{}, dd, bufoff ^ (unsigned)IVFS_BUF);
+                    }
+                    bufoff ^= (unsigned)IVFS_BUF;
+                };
+                stage(std::integral_constant<int, 0>{});
+                if constexpr (NPH > 1) stage(std::integral_constant<int, 1>{});
+                if constexpr (NPH > 2) stage(std::integral_constant<int, 2>{});
+            }
+            if (!nxt.valid) break;
+            cur = nxt;
+            if constexpr (!LOADER) { myq = lane_q(cur); tq = lane_thr(myq); }
+            ++k;
+        }
+    };
+    if (LW > 0 && wv >= GW) {                                 // wave-uniform
+        walk(std::integral_constant<int, 1>{});
+        return;                                               // (its stream stays empty: stream_cnt was cleared by the host)
+    }
+    walk(std::integral_constant<int, 0>{});
     if (l == 0) stream_cnt[blockIdx.x * IVFS_WAVES + (unsigned)wv] = woff;
 }
 
@@ -3011,7 +3067,8 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     RC_HIP_CHECK(h, hipMemsetAsync(idcnt, 0, (size_t)nq * sizeof(unsigned), s));
     RC_HIP_CHECK(h, hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(unsigned), s));
     if (ivf_pipe()) {
-        auto kern = ivfs_screen_kernel<M>;
+        static const int lw = [] { const char* e = getenv("RC_IVF_LW"); return e ? atoi(e) : 4; }();
+        auto kern = lw == 4 ? ivfs_screen_kernel<M, 4> : lw == 2 ? ivfs_screen_kernel<M, 2> : ivfs_screen_kernel<M, 0>;
         constexpr int sl = 2 * IVFS_BUF;
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
         adc_ivf_tasks TT = T;
