@@ -561,9 +561,9 @@ def main():
                                            "bound": "mfma", "achieved": round(2.0 * (1 << 18) * nlist * D / cdt / 1e12, 2),
                                            "peak": 157.3, "unit": "TFLOP/s",
                                            "frac": round(2.0 * (1 << 18) * nlist * D / cdt / 1e12 / 157.3, 4)}},
-            "roofline": {"kernel": "ivfs_screen_kernel<96> (list-centric: one persistent block per CU walks (cell, <= 8 probing "
-                                   "queries) tasks; 64 KiB table phases of 32 sub-quantisers in two LDS buffers, the next phase's "
-                                   "tables requested a stage ahead and byte-transposed into the other buffer; conflict-free "
+            "roofline": {"kernel": "ivfs_screen_kernel<96, 4> (list-centric: one persistent block per CU walks (cell, <= 8 probing "
+                                   "queries) tasks; 64 KiB table phases of 32 sub-quantisers in two LDS buffers, four loader waves fetch and "
+                                   "byte-transpose the next phase's tables into the other buffer while twelve waves gather; conflict-free "
                                    "ds_read_b64 gathers + i8 MFMA accumulation; survivors to per-wave streams); nprobe < 6 takes "
                                    "the per-query scan",
                          "bound": "lds-gather", "achieved": round(ivf_gather, 1), "peak": round(256 * 256 * 2.4, 1),
