@@ -17,13 +17,14 @@
 //      list of 64-bit keys.  Two implementations with IDENTICAL output:
 //        a. adc_scan_kernel<FILTER>: exact fp32 scores for every row (small indexes);
 //        b. integer screening (N >= 2^18, k <= 2048): adc_qlut_kernel quantises each query's tables to 8 bits with a
-//           common step Delta_q (l = floor((LUT - min_m)/Delta_q)); the screen kernel sums the bytes of 8 queries per
+//           common step Delta_q (l = round((LUT - min_m)/Delta_q), nearest since round 3); the screen kernel sums the bytes of 8 queries per
 //           LDS gather (one ds_read_b64 serves 8 queries instead of 2) — adc_screen_mfma_kernel on the matrix cores
 //           (v_mfma_i32_32x32x32_i8 against a selection matrix; two table phases for M > 64), adc_screen_kernel on
 //           the VALU for M % 8 != 0 — and keeps every row with S_int >= T_q, where
-//           T_q = ceil((tau_q - sum_m min_m)/Delta_q) - (M+2) is a RIGOROUS lower bound (sum of the M floor errors
-//           < M, plus float rounding), so no row with exact score >= tau_q is ever lost; adc_rescore_kernel then
-//           computes the exact fp32 score of the survivors (~1.7x the final candidates) and applies the exact test.
+//           T_q = ceil((tau_q - sum_m min_m)/Delta_q - M/2) - 2 is a RIGOROUS lower bound (each of the M entries is off by
+//           at most half a step — rounds 1/2 truncated: a whole step, slack M + 2, ~1.4x more survivors —, plus float
+//           rounding), so no row with exact score >= tau_q is ever lost; adc_rescore_kernel then
+//           computes the exact fp32 score of the survivors (~1.4x the final candidates) and applies the exact test.
 //           The candidate set, hence the result, is the same as (a).
 //   5. adc_select_kernel     per query: radix-select cut to the k best scores (+ties), bitonic sort in LDS, emit top-k
 //
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(RC_K) void adc_qlut_kernel(const float* __restrict_
         if (t == -INFINITY) {
             T = INT_MIN;
         } else {
-            const double v = ceil(((double)t - A) / (double)delta) - (double)(M + 2);
+            const double v = ceil(((double)t - A) / (double)delta - 0.5 * (double)M) - 2.0;   // entries rounded to NEAREST: |error| <= 1/2 each
             T = v < -2.0e9 ? INT_MIN : (v > 2.0e9 ? INT_MAX : (int)v);
         }
         tint[qi] = T;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(RC_K) void adc_qlut_kernel(const float* __restrict_
     uint8_t* dst = qlut + (size_t)(qi / QS) * M * RC_K * QS + (qi % QS);
     for (int m = 0; m < M; ++m) {
         const float v = (lq[m * RC_K + c] - lo_m[m]) / delta;
-        int l = (int)floorf(v);
+        int l = (int)floorf(v + 0.5f);
         l = l < 0 ? 0 : (l > 255 ? 255 : l);
         dst[((size_t)m * RC_K + c) * QS] = (uint8_t)l;
     }
@@ -862,7 +863,7 @@ __global__ __launch_bounds__(256) void adc_scan_image_kernel(const uint8_t* __re
 //   adc_qlut_cf_write_kernel byte tables of the conflict-free screen, [group of 8 queries][phase][code][slot][8], every
 //                            copy of a 16-block filled; thread = code, 16-byte stores (two slots x 8 queries)
 //   adc_qbyte_write_kernel   the IVF form: one table per QUERY, [phase][code][slot] one byte per entry
-// The arithmetic per entry is exactly adc_qlut_kernel's: floor((v - lo_m) / delta) clamped to [0, 255].
+// The arithmetic per entry is exactly adc_qlut_kernel's: floor((v - lo_m) / delta + 0.5) clamped to [0, 255].
 #define ADC_QSTAT_STRIDE 128          // floats per query: lo[0..M), delta at [127]
 __global__ __launch_bounds__(RC_K) void adc_qstats_kernel(const float* __restrict__ lut, const float* __restrict__ thr,
                                                           int M, float* __restrict__ qstat, int* __restrict__ tint) {
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(RC_K) void adc_qstats_kernel(const float* __restric
         if (t == -INFINITY) {
             T = INT_MIN;
         } else {
-            const double v = ceil(((double)t - A) / (double)delta) - (double)(M + 2);
+            const double v = ceil(((double)t - A) / (double)delta - 0.5 * (double)M) - 2.0;   // entries rounded to NEAREST: |error| <= 1/2 each
             T = v < -2.0e9 ? INT_MIN : (v > 2.0e9 ? INT_MAX : (int)v);
         }
         tint[qi] = T;
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(RC_K) void adc_qstats_kernel(const float* __restric
 }
 
 __device__ __forceinline__ unsigned adc_quant8(float v, float lo, float delta) {
-    int l = (int)floorf((v - lo) / delta);
+    int l = (int)floorf((v - lo) / delta + 0.5f);           // nearest: the screen's one-sided slack is M / 2 + 2 steps, not M + 2
     l = l < 0 ? 0 : (l > 255 ? 255 : l);
     return (unsigned)l;
 }
