@@ -148,6 +148,33 @@ def test_procrustes_rotation_equals_the_svd_solution():
     assert float((R.T @ R - torch.eye(8, dtype=torch.float64)).abs().max()) < 1e-12 and abs(float(R[0, 0])) > 0.999
 
 
+def test_procrustes_fixed_schedule_and_its_deferred_check():
+    """The optimally scaled Newton-Schulz schedule is a host-side constant (no look at the matrix): its lower bound grows
+    to 1, its last steps are the plain iteration; a matrix beyond the schedule's range is REPORTED by the deferred check
+    (what train_opq reads once, after the last round) and handled by the SVD in the checked mode."""
+    import torch
+    from repconc_amd.train.run_warmup import _polar_schedule, procrustes_rotation
+    sched = _polar_schedule(1e-12)
+    assert 30 <= len(sched) <= 40 and abs(sched[0][0] - 2.598076) < 1e-5 and sched[-1] == (1.5, -0.5)
+    ell = 1e-12
+    for a, b in sched[:-2]:
+        assert a + b <= 1.0 + 1e-12 and a > 1.0                    # p(1) = l' <= 1: nothing above 1 is ever produced
+        ell = a * ell + b * ell ** 3
+    assert 1.0 - ell < 1e-15
+    g = torch.Generator().manual_seed(9)
+    D = 48
+    U = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
+    V = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
+    good = (U * torch.logspace(0, -8, D, dtype=torch.float64)) @ V.T
+    X, err = procrustes_rotation(good, defer=True)
+    assert float(err) < 1e-12 and float((X - U @ V.T).abs().max()) < 1e-7
+    bad = (U * torch.logspace(0, -15, D, dtype=torch.float64)) @ V.T       # cond 1e15: outside [1e-12, 1]
+    _, err_bad = procrustes_rotation(bad, defer=True)
+    assert not (float(err_bad) < 1e-9)
+    R = procrustes_rotation(bad)                                            # checked mode: SVD fall-back, orthogonal
+    assert float((R.T @ R - torch.eye(D, dtype=torch.float64)).abs().max()) < 1e-12
+
+
 def test_faiss_shim_serves_the_scripts_faiss_idioms():
     """compat/faiss: with compat/ first on the path the reference's entry scripts' `import faiss` lines resolve (no edit at
     all): the names they touch exist, `import faiss.contrib.torch_utils` works, and what they do not need is absent."""
