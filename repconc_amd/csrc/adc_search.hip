@@ -2487,9 +2487,9 @@ struct ivfs_task {
     unsigned row_lo, nrows;   // rows [row_lo, nrows) counted from t0 are the cell's (nrows = 0: nothing to scan)
 };
 
-// LW = 0: every wave gathers and takes its share of the table fills.  LW = 2 (wave specialisation): the block's last two waves
-// do nothing but fetch, transpose and store the NEXT stage's tables while the other fourteen gather — the fill runs beside
-// the gathers instead of after them (the sixteen waves of the LW = 0 form do the same thing at the same time).
+// LW = 0: every wave gathers and takes its share of the table fills.  LW = 4 (wave specialisation, default): the block's last
+// four waves do nothing but fetch, transpose and store the NEXT stage's tables while the other twelve gather — the fill runs
+// beside the gathers instead of after them (the sixteen waves of the LW = 0 form do the same thing at the same time).
 template <int M, int LW>
 __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint8_t* __restrict__ image,
                                                                       const int* __restrict__ tint,
@@ -3068,8 +3068,8 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     RC_HIP_CHECK(h, hipMemsetAsync(idcnt, 0, (size_t)nq * sizeof(unsigned), s));
     RC_HIP_CHECK(h, hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(unsigned), s));
     if (ivf_pipe()) {
-        static const int lw = [] { const char* e = getenv("RC_IVF_LW"); return e ? atoi(e) : 4; }();
-        auto kern = lw == 4 ? ivfs_screen_kernel<M, 4> : lw == 2 ? ivfs_screen_kernel<M, 2> : ivfs_screen_kernel<M, 0>;
+        static const int lw = [] { const char* e = getenv("RC_IVF_LW"); return (e && e[0] == '0') ? 0 : 4; }();   // 0: no loader waves
+        auto kern = lw ? ivfs_screen_kernel<M, 4> : ivfs_screen_kernel<M, 0>;
         constexpr int sl = 2 * IVFS_BUF;
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
         adc_ivf_tasks TT = T;
