@@ -384,6 +384,16 @@ int rc_ivf_search_probes(rc_handle_t h, const uint8_t* codes, const uint8_t* ima
                          const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
                          int keep_all_rows, float* scores, int64_t* out_ids, int* status, void* ws, size_t ws_bytes,
                          rc_stream_t stream);
+/* rc_ivf_search_probes with per-query status words: qstatus [nq] int32 (zeroed by the caller, may be NULL) gets bit 0 for a
+ * query that kept fewer than min(k, rows probed) candidates and bit 1 for one whose id list overflowed; the other queries'
+ * results stand, so a caller answers only the flagged ones again (repconc_amd.ivf: by the per-query exact scan).  status bit 2
+ * (value 4, both entries): a survivor stream of the screen filled up — nobody's results are reliable, repeat with a smaller
+ * sel_slack. */
+int rc_ivf_search_probes_q(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
+                           const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
+                           const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
+                           int keep_all_rows, float* scores, int64_t* out_ids, int* status, int* qstatus, void* ws,
+                           size_t ws_bytes, rc_stream_t stream);
 size_t rc_ivf_search_ws_bytes(int nq, int64_t stride);
 int rc_ivf_search(rc_handle_t h, const uint8_t* codes, const int64_t* list_off, const int64_t* ids, int64_t N,
                   int M, int K, const float* lut, const int* probes, const int* base, const int* count, int nq,

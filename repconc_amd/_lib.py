@@ -86,6 +86,8 @@ PROTOTYPES = {
     "rc_ivf_search_probes_ws_bytes": (_sz, [_i, _i, _i, _i, _i64]),
     "rc_ivf_search_probes": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _i, _d, _i,
                                   _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rc_ivf_search_probes_q": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _i, _d, _i,
+                                    _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_ivf_search_ws_bytes": (_sz, [_i, _i64]),
     "rc_ivf_search": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_adc_lut": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -2784,8 +2784,8 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
             if (r >= o) inc += t;
         }
         const unsigned wtotal = (unsigned)__builtin_amdgcn_readlane((int)inc, 7);
-        if (woff + wtotal > stream_cap) {                     // wave-uniform; the search reports an overflowed list
-            if (l == 0) atomicOr(status, 2);
+        if (woff + wtotal > stream_cap) {                     // wave-uniform; status bit 2: a stream filled up (no query to blame)
+            if (l == 0) atomicOr(status, 4);
             return;
         }
         unsigned at = (woff + (inc - tot) + lane_first) * 8u;  // byte offset of the lane's first pair
@@ -2991,11 +2991,14 @@ __global__ __launch_bounds__(1024) void ivf_rank_select_kernel(const float* __re
 }
 
 __global__ void ivf_check_kernel(const unsigned* __restrict__ cand_count, const int* __restrict__ rows, int nq, int k,
-                                 int* __restrict__ status) {
+                                 int* __restrict__ status, int* __restrict__ qstatus) {
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
     const int want = rows[qi] < k ? rows[qi] : k;
-    if ((int)cand_count[qi] < want) atomicOr(status, 1);
+    if ((int)cand_count[qi] < want) {
+        atomicOr(status, 1);
+        if (qstatus) atomicOr(qstatus + qi, 1);
+    }
 }
 
 namespace {
@@ -3017,7 +3020,7 @@ ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
     // (query, row) streams of the pipelined screen: one per wave of its <= IVFS_MAX_BLOCKS persistent blocks
     size_t cap = (size_t)nq * (ADC_ID_CAP / 2) / (IVFS_MAX_BLOCKS * IVFS_WAVES);
     if (cap < 4096) cap = 4096;
-    if (const char* e = getenv("RC_IVF_STREAM_CAP")) {      // tests: provoke the overflow path (status bit 1 -> less slack -> scan)
+    if (const char* e = getenv("RC_IVF_STREAM_CAP")) {      // tests: provoke the overflow path (status bit 2 -> less slack -> scan)
         const long v = atol(e);
         if (v > 0) cap = (size_t)v;
     }
@@ -3032,7 +3035,8 @@ template <int M>
 int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off, const int64_t* rowmap,
                 int64_t N, const float* lut, int nq, const int* probes, const int* sbase, const int* scount,
                 const int* rows, const int* rank, int nprobe, int64_t sstride, int ss, const adc_ivf_tasks& T, int ntasks,
-                int k, float* scores, int64_t* out_ids, int* status, char* w, const ivfl_ws& L, hipStream_t s) {
+                int k, float* scores, int64_t* out_ids, int* status, char* w, const ivfl_ws& L, hipStream_t s,
+                int* qstatus = nullptr) {
     constexpr int NP = (M == 96) ? 2 : 1, PM = M / NP;
     constexpr int R = (NP > 1) ? 8 : (M == 64 ? 2 : 4);
     constexpr int TH = ADC_THREADS;
@@ -3110,13 +3114,14 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
         const size_t rl = (size_t)M * RC_K * sizeof(float);
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
         hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(ADC_RESCORE_THREADS), rl, s, codes, lut, (const float*)thr, (const unsigned*)idcnt,
-                           (const unsigned*)ids, cnt, cand, status, rowmap, (int*)nullptr);
+                           (const unsigned*)ids, cnt, cand, status, rowmap, qstatus);
         RC_LAUNCH_CHECK(h);
     }
-    hipLaunchKernelGGL(ivf_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const unsigned*)cnt, rows, nq, k, status);
+    hipLaunchKernelGGL(ivf_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const unsigned*)cnt, rows, nq, k, status,
+                       qstatus);
     RC_LAUNCH_CHECK(h);
     // N = 0: fewer than k rows is legitimate (small cells); too FEW CANDIDATES is what ivf_check_kernel reports
-    return rc_adc_launch_select(h, cand, cnt, nq, 0, k, 0, scores, out_ids, status, s);
+    return rc_adc_launch_select(h, cand, cnt, nq, 0, k, 0, scores, out_ids, status, s, qstatus);
 }
 }  // namespace
 
@@ -3409,11 +3414,28 @@ extern "C" size_t rc_ivf_search_probes_ws_bytes(int M, int nq, int nprobe, int n
 // a query's sample array, >= the largest possible number of sampled rows of nprobe cells (a cell of n rows contributes
 // 16 floor(n / 16 ss) + min(16, n mod 16 ss)); sel_slack: standard deviations of head-room in the threshold rank;
 // keep_all_rows: queries probing no more rows than this re-score every row.  Same status bits, same results.
+extern "C" int rc_ivf_search_probes_q(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
+                                      const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
+                                      const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
+                                      int keep_all_rows, float* scores, int64_t* out_ids, int* status, int* qstatus, void* ws,
+                                      size_t ws_bytes, rc_stream_t stream);
 extern "C" int rc_ivf_search_probes(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
                                     const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
                                     const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
                                     int keep_all_rows, float* scores, int64_t* out_ids, int* status, void* ws,
                                     size_t ws_bytes, rc_stream_t stream) {
+    return rc_ivf_search_probes_q(h, codes, image, list_off, rowmap, N, nlist, M, K, lut, nq, probes, nprobe, sstride, ss, k,
+                                  sel_slack, keep_all_rows, scores, out_ids, status, nullptr, ws, ws_bytes, stream);
+}
+// ... with per-query status words (qstatus [nq] int32, zeroed by the caller; may be NULL): bit 0 = the query kept fewer than
+// min(k, rows probed) candidates, bit 1 = its id list overflowed.  The other queries' results stand: a caller answers only
+// the flagged ones again (IVFPQIndex.search: by the per-query exact scan).  A survivor STREAM that filled up (status bit 2)
+// is not attributable to a query and may have dropped anybody's rows: repeat the call with less slack.
+extern "C" int rc_ivf_search_probes_q(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
+                                      const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
+                                      const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
+                                      int keep_all_rows, float* scores, int64_t* out_ids, int* status, int* qstatus, void* ws,
+                                      size_t ws_bytes, rc_stream_t stream) {
     rc_device_guard device_guard_(h);
     if (!h || !codes || !image || !list_off || !rowmap || !lut || !probes || !scores || !out_ids || !status || N <= 0 ||
         nq < 0 || nprobe <= 0 || nlist <= 0 || nprobe > nlist || sstride <= 0 || ss <= 0 || k <= 0)
@@ -3446,7 +3468,7 @@ extern "C" int rc_ivf_search_probes(rc_handle_t h, const uint8_t* codes, const u
 #define IVFP_CASE(MM)                                                                                                  \
         case MM: return ivfl_launch<MM>(h, codes, image, list_off, rowmap, N, lut, nq, probes, I(P.sbase), I(P.scount),  \
                                         I(P.rows), I(P.rank), nprobe, sstride, ss, T, (int)P.ub, k, scores, out_ids,  \
-                                        status, w, L, s);
+                                        status, w, L, s, qstatus);
         IVFP_CASE(16) IVFP_CASE(32) IVFP_CASE(48) IVFP_CASE(64) IVFP_CASE(96)
 #undef IVFP_CASE
         default: return RC_ESHAPE;

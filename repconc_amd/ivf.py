@@ -279,20 +279,31 @@ class IVFPQIndex:
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
         ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
-        status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        flags = torch.zeros((1 + nq,), dtype=torch.int32, device=dev)     # [status | per-query status]: one fill
+        status, qstatus = flags[:1], flags[1:]
         p = lambda t: C.c_void_p(t.data_ptr())
         slack = float(sel_slack)
-        for _ in range(max_retries + 1):
-            status.zero_()
-            _lib.check(lib.rc_ivf_search_probes(h, p(self.codes), p(self.image), p(self.list_off), p(self.ids), self.ntotal,
-                                                self.nlist, self.M, 256, p(lut), nq, p(probes), nprobe, sstride, ss, int(k),
-                                                slack, self.KEEP_ALL_ROWS, p(scores), p(ids), p(status), p(ws), wsb, s),
-                       "rc_ivf_search_probes", h)
+        for attempt in range(max_retries + 1):
+            if attempt:
+                flags.zero_()
+            _lib.check(lib.rc_ivf_search_probes_q(h, p(self.codes), p(self.image), p(self.list_off), p(self.ids), self.ntotal,
+                                                  self.nlist, self.M, 256, p(lut), nq, p(probes), nprobe, sstride, ss, int(k),
+                                                  slack, self.KEEP_ALL_ROWS, p(scores), p(ids), p(status), p(qstatus), p(ws),
+                                                  wsb, s), "rc_ivf_search_probes_q", h)
             st = int(status.item())
             if st == 0:
                 return scores, ids
-            slack = max(slack, 0.0) * 3.0 + 2.0 if (st & 1) else max(slack / 3.0, 0.0)
-        # no slack gives every query a usable candidate list (degenerate cells): the per-query exact scan decides
+            bad = torch.nonzero(qstatus != 0).flatten()
+            if not (st & 4) and bad.numel() > 0:
+                # per-query status: the other queries' results stand; the flagged ones (degenerate cells: thousands of equal
+                # scores around the threshold) are answered by the per-query exact scan — one bad query does not make the
+                # batch repeat
+                bs, bi = self.search(q[bad], k, nprobe, method="scan")
+                scores[bad], ids[bad] = bs, bi
+                return scores, ids
+            # status bit 2: a survivor stream of the screen filled up (it may have dropped anybody's rows) -> fewer survivors, again
+            slack = max(slack / 3.0, 0.0)
+        # no slack fits the streams: the per-query exact scan decides
         return self.search(q, k, nprobe, method="scan")
 
     def _search_lists_host_plan(self, q: torch.Tensor, probes: torch.Tensor, k: int, nprobe: int, sel_slack: float = 6.0,

@@ -248,3 +248,37 @@ def test_round2_ivf_screen_stays_selectable(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         got[pipe] = (np.load(fi), np.load(fs))
     assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1].view(np.uint32), got["0"][1].view(np.uint32))
+
+
+def test_ivf_one_degenerate_query_is_answered_alone(monkeypatch):
+    """IVF batch in which ONE query probes a cell full of identical rows (its threshold admits thousands of equal scores):
+    rc_ivf_search_probes_q flags that query only; the others keep the list-centric answer (no per-query scan for them), all
+    results equal the oracle."""
+    from oracle import pq_oracle
+    from repconc_amd.ivf import IVFPQIndex
+    M, nlist, N, nq, k, nprobe = 48, 24, 150000, 33, 300, 3
+    rng = np.random.default_rng(611)
+    codes = synth.uniform_codes(612, N, M)
+    cells = rng.integers(1, nlist, N)
+    cells[:40000] = 0
+    codes[:40000] = codes[0]                                  # cell 0: 40 000 copies of one row
+    C = synth.gaussian(613, (M, 256, 768 // M))
+    coarse = synth.gaussian(614, (nlist, 768))
+    q = synth.gaussian(615, (nq, 768))
+    coarse[0] = q[7] * 4.0                                    # query 7 (and almost only it) probes cell 0
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(_t(C))
+    ivf.coarse = _t(coarse)
+    ivf.set_lists(_t(codes), _t(cells))
+    calls = []
+    orig = IVFPQIndex.search
+
+    def spy(self, x, kk, npb, method="auto"):
+        calls.append((int(x.shape[0]), method))
+        return orig(self, x, kk, npb, method)
+    monkeypatch.setattr(IVFPQIndex, "search", spy)
+    s, i = ivf.search(_t(q), k, nprobe, method="lists")
+    ws, wi = pq_oracle.ivf_search(q, C, codes, cells, coarse, k, nprobe)
+    assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    scans = [c for c in calls if c[1] == "scan"]
+    assert len(scans) <= 1 and all(c[0] < nq // 2 for c in scans), calls      # only the flagged few went to the exact scan
