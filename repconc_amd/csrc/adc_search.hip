@@ -3003,7 +3003,7 @@ __global__ void ivf_check_kernel(const unsigned* __restrict__ cand_count, const 
 
 namespace {
 struct ivfl_ws {
-    size_t sample, thr, tint, qstat, qbyte, idcnt, ids, cnt, cand, stream_cnt, stream, stream_cap, total;
+    size_t sample, thr, tint, qstat, qbyte, idcnt, ids, cnt, cand, stream_cnt, counters_end, stream, stream_cap, total;
 };
 ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
     ivfl_ws L;
@@ -3013,9 +3013,12 @@ ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
     L.tint = o;   o += rc_align_up((size_t)nq * sizeof(int), 256);
     L.qstat = o;  o += rc_align_up((size_t)nq * ADC_QSTAT_STRIDE * sizeof(float), 256);
     L.qbyte = o;  o += rc_align_up((size_t)nq * M * RC_K, 256);                 // compact per-query byte tables
+    // the three counter arrays sit side by side: ONE memset clears them (idcnt | cnt | stream_cnt)
     L.idcnt = o;  o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
-    L.ids = o;    o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
     L.cnt = o;    o += rc_align_up((size_t)nq * sizeof(unsigned), 256);
+    L.stream_cnt = o; o += rc_align_up((size_t)IVFS_MAX_BLOCKS * IVFS_WAVES * sizeof(unsigned), 256);
+    L.counters_end = o;
+    L.ids = o;    o += rc_align_up((size_t)nq * ADC_ID_CAP * sizeof(unsigned), 256);
     L.cand = o;   o += rc_align_up((size_t)nq * ADC_CAND_CAP * sizeof(unsigned long long), 256);
     // (query, row) streams of the pipelined screen: one per wave of its <= IVFS_MAX_BLOCKS persistent blocks
     size_t cap = (size_t)nq * (ADC_ID_CAP / 2) / (IVFS_MAX_BLOCKS * IVFS_WAVES);
@@ -3025,7 +3028,6 @@ ivfl_ws ivfl_layout(int M, int nq, int64_t sstride) {
         if (v > 0) cap = (size_t)v;
     }
     L.stream_cap = cap;
-    L.stream_cnt = o; o += rc_align_up((size_t)IVFS_MAX_BLOCKS * IVFS_WAVES * sizeof(unsigned), 256);
     L.stream = o;     o += rc_align_up((size_t)IVFS_MAX_BLOCKS * IVFS_WAVES * cap * 8, 256);
     L.total = o;
     return L;
@@ -3069,8 +3071,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     else
         hipLaunchKernelGGL(adc_qbyte_write_kernel<PM>, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)qstat, M, qbyte);
     RC_LAUNCH_CHECK(h);
-    RC_HIP_CHECK(h, hipMemsetAsync(idcnt, 0, (size_t)nq * sizeof(unsigned), s));
-    RC_HIP_CHECK(h, hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(unsigned), s));
+    RC_HIP_CHECK(h, hipMemsetAsync(w + L.idcnt, 0, L.counters_end - L.idcnt, s));      // idcnt, cnt, stream_cnt
     if (ivf_pipe()) {
         static const int lw = [] { const char* e = getenv("RC_IVF_LW"); return (e && e[0] == '0') ? 0 : 4; }();   // 0: no loader waves
         auto kern = lw ? ivfs_screen_kernel<M, 4> : ivfs_screen_kernel<M, 0>;
@@ -3084,7 +3085,6 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
         unsigned* stream_cnt = (unsigned*)(w + L.stream_cnt);
         unsigned* stream = (unsigned*)(w + L.stream);
         const unsigned nstreams = (unsigned)blocks * IVFS_WAVES;
-        RC_HIP_CHECK(h, hipMemsetAsync(stream_cnt, 0, (size_t)nstreams * sizeof(unsigned), s));
         rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(IVFS_THREADS), sl, s, image, (const int*)tint, stream_cnt, stream,
                            (unsigned)L.stream_cap, status, TT, ntasks);
