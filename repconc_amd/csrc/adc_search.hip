@@ -2599,30 +2599,72 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
 #pragma unroll
         for (int f = 0; f < FI; ++f) emit_entry(PMc, dd[f], FI == 2 ? 2u * tid + (unsigned)f : tid, bufoff);
     };
-    // loader waves (LW > 0): the whole phase by LW * 64 threads, in batches of 4 x 8 eight-byte loads (64 registers)
+    // loader waves (LW > 0): the whole phase by LW * 64 threads, 64 table registers per batch.
+    // 32-phase: consecutive lanes take consecutive dwords (4-byte loads), so lane l's entry is 32 bytes at 32 i, i = l (mod 64).
+    // Written as lo half then hi half by every lane, the 16 lanes the LDS serves together ({0-3, 12-15, 20-27}, ...) hit 8
+    // bank quads twice (and with the 8-byte loads of the first version, 64 bytes per lane, four times: PMC showed 39 % of
+    // the kernel's LDS cycles as bank conflicts).  Lanes with bit 3 set write their HI half first: the two lanes of a group that
+    // share i mod 8 then differ in the half, 16 distinct quads per group.
     auto loader_fill = [&](auto PMc, int p, const ivfs_task& d, unsigned bufoff) {
         constexpr int PM = decltype(PMc)::value;
-        constexpr int LT = (LW > 0 ? LW : 1) * 64, NPAIR = RC_K * PM / 8, ITER = NPAIR / LT, BATCH = ITER < 4 ? ITER : 4;
-        static_assert(NPAIR % LT == 0 && ITER % BATCH == 0, "whole batches");
+        constexpr int LT = (LW > 0 ? LW : 1) * 64;
         const unsigned lt = tid - (unsigned)(GW * 64);
         unsigned so[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) so[j] = (unsigned)(d.qid[j] < 0 ? 0 : d.qid[j]) * (unsigned)(M * RC_K) + (unsigned)(RC_K * 32 * p);
+        if constexpr (PM == 32) {
+            constexpr int NDW = RC_K * PM / 4, ITER = NDW / LT, BATCH = ITER < 8 ? ITER : 8;
+            static_assert(NDW % LT == 0 && ITER % BATCH == 0, "whole batches");
+            const bool hi_first = ((lt >> 3) & 1u) != 0;
 #pragma unroll
-        for (int b0 = 0; b0 < ITER; b0 += BATCH) {
-            unsigned dq[BATCH][2][8];
+            for (int b0 = 0; b0 < ITER; b0 += BATCH) {
+                unsigned dq[BATCH][8];
 #pragma unroll
-            for (int it = 0; it < BATCH; ++it)
+                for (int it = 0; it < BATCH; ++it)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(qrsrc, ((unsigned)((b0 + it) * LT) + lt) * 8u, so[j], 0);
-                    dq[it][0][j] = v.x; dq[it][1][j] = v.y;
+                    for (int j = 0; j < 8; ++j)
+                        dq[it][j] = __builtin_amdgcn_raw_buffer_load_b32(qrsrc, ((unsigned)((b0 + it) * LT) + lt) * 4u, so[j], 0);
+#pragma unroll
+                for (int it = 0; it < BATCH; ++it) {
+                    const unsigned i = (unsigned)((b0 + it) * LT) + lt;
+                    const unsigned (&dv)[8] = dq[it];
+                    unsigned o[8];
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq) {
+                        const unsigned a0 = dv[4 * hq], a1 = dv[4 * hq + 1], a2 = dv[4 * hq + 2], a3 = dv[4 * hq + 3];
+                        const unsigned t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+                        const unsigned u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+                        o[0 + hq] = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+                        o[2 + hq] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+                        o[4 + hq] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+                        o[6 + hq] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+                    }
+                    const uint4 first = hi_first ? make_uint4(o[4], o[5], o[6], o[7]) : make_uint4(o[0], o[1], o[2], o[3]);
+                    const uint4 second = hi_first ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(o[4], o[5], o[6], o[7]);
+                    unsigned char* e = smem + (bufoff + i * 32u);
+                    *reinterpret_cast<uint4*>(e + (hi_first ? 16 : 0)) = first;
+                    *reinterpret_cast<uint4*>(e + (hi_first ? 0 : 16)) = second;
                 }
+            }
+        } else {
+            constexpr int NPAIR = RC_K * PM / 8, ITER = NPAIR / LT, BATCH = ITER < 4 ? ITER : 4;
+            static_assert(NPAIR % LT == 0 && ITER % BATCH == 0, "whole batches");
 #pragma unroll
-            for (int it = 0; it < BATCH; ++it)
+            for (int b0 = 0; b0 < ITER; b0 += BATCH) {
+                unsigned dq[BATCH][2][8];
 #pragma unroll
-                for (int f = 0; f < 2; ++f) emit_entry(PMc, dq[it][f], 2u * ((unsigned)((b0 + it) * LT) + lt) + (unsigned)f, bufoff);
+                for (int it = 0; it < BATCH; ++it)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(qrsrc, ((unsigned)((b0 + it) * LT) + lt) * 8u, so[j], 0);
+                        dq[it][0][j] = v.x; dq[it][1][j] = v.y;
+                    }
+#pragma unroll
+                for (int it = 0; it < BATCH; ++it)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) emit_entry(PMc, dq[it][f], 2u * ((unsigned)((b0 + it) * LT) + lt) + (unsigned)f, bufoff);
+            }
         }
     };
     // ---- codes of one stage: chunk c of wave wv is chunk 16 c + wv of the round (the waves share a short cell evenly:
