@@ -194,7 +194,7 @@ class IVFPQIndex:
             raise _lib.RepconcHipError(f"the list-centric search needs M in (16, 32, 48, 64, 96), not {self.M}")
         if method == "auto" and self.image is not None:
             # few probed rows per query: the per-query scan has less fixed work (task list, per-query byte tables)
-            method = "lists" if self.ntotal * nprobe / max(self.nlist, 1) >= self.LISTS_MIN_ROWS else "scan"
+            method = "lists" if self.ntotal * nprobe / max(self.nlist, 1) * self.M >= self.LISTS_MIN_BYTES else "scan"
         if method in ("lists", "lists_host_plan") and nq > 0:
             fn = self._search_lists if method == "lists" else self._search_lists_host_plan
             scores, ids = fn(q, probes, int(k), nprobe)
@@ -256,7 +256,7 @@ class IVFPQIndex:
     CAND_CAP = 16384                # candidate keys per query (ADC_CAND_CAP)
     KEEP_ALL_ROWS = 4096            # queries probing no more rows than this re-score every row (no threshold)
     MAX_QUERY_BATCH = 16384         # queries per C call (rc_ivf_search_lists / _probes refuse more than 32768)
-    LISTS_MIN_ROWS = 10000          # "auto": average probed rows per query from which the list-centric search pays (M = 96, 1200 queries: equal at ~8 k)
+    LISTS_MIN_BYTES = 576000        # "auto": average probed code bytes per query from which the list-centric search pays (round 3, 1200 queries: the two meet at ~6.5 k rows for M = 96, ~10.6 k for M = 48)
 
     def _sample_step(self, nprobe: int) -> int:
         """about SAMPLE_ROWS exactly scored rows per query place the candidate threshold"""
