@@ -1702,6 +1702,33 @@ def test_ivf_list_centric_search_equals_per_query_scan(M):
         assert torch.equal(i3, i2) and torch.equal(s3, s2), (M, nprobe)
 
 
+def test_opq_training_repeats_with_checked_procrustes_when_a_deferred_check_fails(monkeypatch):
+    """train_opq reads the orthogonality checks of all rounds once, after the last; if one is not below 1e-9 (here: forced in
+    round 1) it repeats the training with per-round checks (library SVD as their fall-back).  Rank-deficient training rows
+    alone do not need that: rounding noise keeps the Procrustes matrices inside the schedule's range and the result is
+    orthogonal."""
+    from repconc_amd.train import run_warmup
+    rng = np.random.default_rng(8)
+    basis = rng.standard_normal((3, 128)).astype(np.float32)
+    x = (rng.standard_normal((4096, 3)).astype(np.float32) @ basis)                  # rows in a 3-dimensional subspace
+    eye = torch.eye(128, device=DEV)
+    R = run_warmup.train_opq(_t(x), 8, n_outer=3, n_pq_first=3, n_pq=2)
+    assert float((R @ R.T - eye).abs().max()) < 1e-4 and bool(torch.isfinite(R).all())
+    modes = []
+    orig = run_warmup.procrustes_rotation
+
+    def spy(P, lower=1e-12, defer=False):
+        modes.append(bool(defer))
+        out = orig(P, lower, defer)
+        if defer and len(modes) == 2:                          # round 1 of the deferred pass "fails"
+            return out[0], out[1] + 1.0
+        return out
+    monkeypatch.setattr(run_warmup, "procrustes_rotation", spy)
+    R2 = run_warmup.train_opq(_t(x), 8, n_outer=3, n_pq_first=3, n_pq=2)
+    assert modes == [True] * 3 + [False] * 3, modes
+    assert float((R2 @ R2.T - eye).abs().max()) < 1e-4
+
+
 def test_warmup_procedure_follows_the_oracle_round_by_round():
     """a-12, procedure level: `train_pq` / `train_opq` on the HIP kernels against oracle/pq_oracle.py's restatement of
     the same published procedure (same training rows, same initial rotation and centroid sample).  One Lloyd round from a
