@@ -2490,6 +2490,21 @@ struct ivfs_task {
 // LW = 0: every wave gathers and takes its share of the table fills.  LW = 4 (wave specialisation, default): the block's last
 // four waves do nothing but fetch, transpose and store the NEXT stage's tables while the other twelve gather — the fill runs
 // beside the gathers instead of after them (the sixteen waves of the LW = 0 form do the same thing at the same time).
+// Development aid (tools/ivf_timeline.py builds a variant library with -DRC_IVF_TRACE): wall-clock stamps of every wave at the
+// stage boundaries of the first tasks of every block, read back with rc_debug_ivfs_trace.  Off in the shipped library.
+#ifdef RC_IVF_TRACE
+__device__ unsigned long long ivfs_trace[256 * 8 * 3 * 16 * 4];
+extern "C" int rc_debug_ivfs_trace(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ivfs_trace), sizeof(ivfs_trace));
+}
+#define IVFS_TSTAMP(i)                                                                                                 \
+    do {                                                                                                               \
+        if (l == 0 && k < 8u && rd == 0 && blockIdx.x < 256u)                                                          \
+            ivfs_trace[(((blockIdx.x * 8u + k) * 3u + (unsigned)P) * 16u + (unsigned)wv) * 4u + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define IVFS_TSTAMP(i) do { } while (0)
+#endif
 template <int M, int LW>
 __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint8_t* __restrict__ image,
                                                                       const int* __restrict__ tint,
@@ -2880,7 +2895,9 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
                     constexpr int PN = LASTP ? 0 : P + 1;     // phase of the next stage
                     using PMc = std::integral_constant<int, ivfs_pm(M, P)>;
                     using PMn = std::integral_constant<int, ivfs_pm(M, PN)>;
+                    IVFS_TSTAMP(3);                               // arrival at the barrier that ends the previous stage
                     block_sync();
+                    IVFS_TSTAMP(0);
                     // the next stage: same task (next phase / next round) or the next task's first
                     const bool to_next = LASTP && !more;      // block-uniform
                     const bool has_next = !to_next || nxt.valid;
@@ -2897,6 +2914,7 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
                         if (LW == 0 && has_next) load_tables(PMn{}, PN, nd, dd);
                         const int reff = chunks_of(cur.nrows, rd);
                         gathers(PMc{}, P == 0, w, bufoff, reff);
+                        IVFS_TSTAMP(1);
                         // the codes of the next stage go into the registers the gathers just released (last phase: after the
                         // survivor pass, whose few waits would otherwise also wait for them)
                         if constexpr (!LASTP) { if (has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w); }
@@ -2906,6 +2924,7 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
                         }
                         if (LW == 0 && has_next) write_tables(PMn{}, dd, bufoff ^ (unsigned)IVFS_BUF);
                     }
+                    IVFS_TSTAMP(2);
                     bufoff ^= (unsigned)IVFS_BUF;
                 };
                 stage(std::integral_constant<int, 0>{});
