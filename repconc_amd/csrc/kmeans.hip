@@ -1,0 +1,620 @@
+// Lloyd / k-means kernels of the warm-up and the index build (train/run_warmup.py:85-132, inside Faiss in the reference):
+// sufficient statistics (exact fixed-point, order-independent), centroid update, Faiss's empty-cluster rule.
+#include "rc_common.h"
+#include <string.h>
+
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------ k-means
+// Lloyd sufficient statistics sums[m][k][:] (fp64) and counts[m][k], DETERMINISTIC: every sum has a fixed order, so the
+// warm-up is reproducible run to run and rank to rank (round 1 merged LDS partials with fp64 atomics).
+//
+//  stage 1  grid (strips, M), block = 256 threads = the 256 centroids.  A block walks its strip of rows in order; the
+//           row's code is block-uniform (staged through LDS in chunks of 1024), the ONE thread k == code adds the row's
+//           sub-vector to its private fp64 registers — per (strip, m, k) the rows are added in ascending order, no two
+//           threads ever touch the same accumulator, every x element is read exactly once.  Partials go to scratch
+//           [strip][m][k][dsub].  The wave-uniform test (code >> 6 == wave) skips the three waves that do not own k.
+//  stage 2  sums[m][k][j] += partials in strip order; counts likewise.
+// At most 64 strips (100 MB of scratch at M = 48): 3072 blocks of ~138 k rows for the 8.84 M-row corpus.
+#define KM_CHUNK 1024
+#define KM_MAX_STRIPS 64
+
+template <int JN>
+__global__ __launch_bounds__(256) void kmeans_stats_det_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const uint8_t* __restrict__ codes, int64_t n, int M, int dsub,
+                                                               int j0, int64_t rows_per_strip, double* __restrict__ part,
+                                                               unsigned* __restrict__ pcnt, const unsigned* __restrict__ gate) {
+    if (gate && *gate < 0x7F800000u) return;              // finite input: the fixed-point path has done this call
+    __shared__ uint8_t cs[KM_CHUNK];
+    const int tid = threadIdx.x, m = blockIdx.y, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_strip;
+    const int64_t r1 = (r0 + rows_per_strip < n) ? r0 + rows_per_strip : n;
+    double acc[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) acc[j] = 0.0;
+    unsigned cnt = 0;
+    const float* xm = x + m * dsub + j0;
+    for (int64_t c0 = r0; c0 < r1; c0 += KM_CHUNK) {
+        const int nc = (int)((r1 - c0 < KM_CHUNK) ? r1 - c0 : KM_CHUNK);
+        __syncthreads();
+        for (int i = tid; i < nc; i += 256) cs[i] = codes[(c0 + i) * M + m];
+        __syncthreads();
+        for (int i = 0; i < nc; ++i) {
+            const int k = cs[i];                                   // block-uniform
+            if ((k >> 6) == wave) {                                // wave-uniform
+                if (k == tid) {
+                    const float* xr = xm + (c0 + i) * ldx;
+                    if constexpr (JN % 4 == 0) {
+#pragma unroll
+                        for (int j4 = 0; j4 < JN / 4; ++j4) {
+                            const float4 v = reinterpret_cast<const float4*>(xr)[j4];
+                            acc[4 * j4] += (double)v.x; acc[4 * j4 + 1] += (double)v.y;
+                            acc[4 * j4 + 2] += (double)v.z; acc[4 * j4 + 3] += (double)v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < JN; ++j) acc[j] += (double)xr[j];
+                    }
+                    ++cnt;
+                }
+            }
+        }
+    }
+    double* p = part + (((size_t)blockIdx.x * M + m) * RC_K + tid) * dsub + j0;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) p[j] = acc[j];
+    if (j0 == 0) pcnt[((size_t)blockIdx.x * M + m) * RC_K + tid] = cnt;
+}
+
+__global__ __launch_bounds__(256) void kmeans_stats_reduce_kernel(const double* __restrict__ part, const unsigned* __restrict__ pcnt,
+                                                                  int strips, int64_t per_strip, int dsub,
+                                                                  double* __restrict__ sums, unsigned long long* __restrict__ counts,
+                                                                  const unsigned* __restrict__ gate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_strip || (gate && *gate < 0x7F800000u)) return;
+    double s = 0.0;
+    for (int t = 0; t < strips; ++t) s += part[(size_t)t * per_strip + i];
+    sums[i] += s;
+    if (i % dsub == 0) {
+        unsigned long long c = 0;
+        for (int t = 0; t < strips; ++t) c += pcnt[(size_t)t * (per_strip / dsub) + i / dsub];
+        counts[i / dsub] += c;
+    }
+}
+
+// ---- exact fixed-point statistics (the default path) --------------------------------------------------------------
+// The strip kernel above is deterministic because every centroid's rows are added in row order by ONE thread — 1/256 of
+// the lanes at work, 1.3 ms for 65 536 rows.  Integer addition does not care about the order: every value is split as
+//   x 2^s = hi + r,  hi = rne(x 2^s),  lo = rne(r 2^38)
+// (s sized so that n values below the bound 2^eb cannot overflow 61 bits; both parts exact for every x down to 2^(eb-51)),
+// (hi, lo) are summed as 64-bit INTEGERS — LDS accumulators per (strip, sub-quantiser), then per-strip partials, then one
+// integer sum over the strips — and the exact 128-bit total hi 2^38 + lo is rounded to fp64 ONCE.  While every part is
+// exact the result is the correctly rounded real sum: it depends on nothing but the data — not on the order, the strips,
+// the launch geometry or the scale s.
+//
+// Round 4 (the round-3 kernel ran at 0.15 of the HBM roof): (1) the split is integer arithmetic on the fp32 bits (shift
+// of the 24-bit significand) instead of fp64 multiply / rint / 64-bit conversions, ~3x fewer VALU instructions per value;
+// (2) accumulators laid out [e][k][q] so that a row's four lanes hit four different bank pairs (5.1 -> 2.6 expected
+// passes per LDS atomic with random codes); (3) ONE round of equal blocks — (strip, m) pairs, as many as the chip has
+// slots, XCD x owns a contiguous range of pairs so that the 64-byte halves of a line and the rows' codes meet in one L2 —
+// which store their partials plainly (round 3: 24 576 blocks x 4096 memory-side 64-bit atomics = 100 M atomics per 2^20
+// rows); (4) no separate max|x| pass over the data: the scale comes from a per-handle HINT (device word, the bound of
+// the previous call + one bit), every block tracks max|x| and inexact splits while it works, and the (normally idle,
+// device-gated) second pass repeats the work with the tight bound of THIS data when the hint was exceeded or a part had
+// to be rounded.  The answer is a pure function of the data either way.
+// Non-finite input (max|x| = inf / NaN) takes the strip kernels, which propagate it as the reference would.
+#define KM_FX_LO_BITS 38
+#define KM_FX_JN 32                                     // dimensions of a sub-vector per pass: 256 x 32 x 16 B = 128 KiB of LDS
+#define KM_FX_U 4                                       // rows in flight per thread
+#define KM_FX_EB0 4                                     // first hint of a handle: |x| < 16
+
+// per-call state words in scratch: [0] max|x| bits seen by pass 0 (also the strip kernels' gate), [1] flags of pass 0
+// (bit 0: a part was rounded), hint[2] lives on the handle (parity = call number)
+struct km_decision { int sexp; bool accept0, redo, nonfinite; int tight_eb; };
+
+__device__ __forceinline__ int km_tight_eb(unsigned am) { return am == 0u ? -126 : (int)(am >> 23) - 126; }   // |x| < 2^eb
+
+template <int PASS>
+__device__ __forceinline__ km_decision km_decide(const unsigned* __restrict__ state, int hint_eb, int log2n) {
+    km_decision d;
+    if (PASS == 0) {
+        d.sexp = 61 - log2n - hint_eb; d.accept0 = d.redo = d.nonfinite = false; d.tight_eb = hint_eb;
+        return d;
+    }
+    const unsigned am = state[0], fl = state[1];
+    d.nonfinite = am >= 0x7F800000u;
+    d.tight_eb = km_tight_eb(am);
+    d.accept0 = !d.nonfinite && d.tight_eb <= hint_eb && !(fl & 1u);
+    d.redo = !d.nonfinite && !d.accept0;
+    d.sexp = 61 - log2n - (d.accept0 ? hint_eb : d.tight_eb);
+    return d;
+}
+
+// x 2^sexp = hi + lo 2^-38 on the bits of x (finite).  Returns true when lo had to be rounded.
+__device__ __forceinline__ bool km_fx_split(unsigned b, int sexp, long long& hi, long long& lo) {
+    int e = (int)((b >> 23) & 0xFFu);
+    unsigned m = b & 0x7FFFFFu;
+    m |= e ? 0x800000u : 0u;
+    e = e ? e : 1;
+    const int sh = e - 150 + sexp;                              // |x| 2^sexp = m 2^sh
+    long long h, l = 0;
+    bool inexact = false;
+    if (sh >= 0) {
+        h = (long long)((unsigned long long)m << (sh > 40 ? 40 : sh));     // > 40: above the bound, the pass is discarded
+    } else {
+        const int t = -sh;
+        if (t <= 24) {
+            unsigned h0 = m >> t;
+            const unsigned rem = m & ((1u << t) - 1u), half = 1u << (t - 1);
+            h0 += (rem > half || (rem == half && (h0 & 1u))) ? 1u : 0u;
+            const int r = (int)m - (int)(h0 << t);              // |r| <= 2^(t-1)
+            h = (long long)h0;
+            l = (long long)r << (KM_FX_LO_BITS - t);
+        } else if (t <= KM_FX_LO_BITS) {
+            h = 0;
+            l = (long long)m << (KM_FX_LO_BITS - t);
+        } else {
+            h = 0;
+            const int u = t - KM_FX_LO_BITS;                    // lo = rne(m 2^-u)
+            if (u >= 26) {
+                l = 0;
+                inexact = m != 0u;
+            } else {
+                unsigned l0 = m >> u;
+                const unsigned rem = m & ((1u << u) - 1u), half = 1u << (u - 1);
+                l0 += (rem > half || (rem == half && (l0 & 1u))) ? 1u : 0u;
+                l = (long long)l0;
+                inexact = rem != 0u;
+            }
+        }
+    }
+    const long long sm = -(long long)(b >> 31);                 // 0 or -1
+    hi = (h ^ sm) - sm;
+    lo = (l ^ sm) - sm;
+    return inexact;
+}
+
+// One row's float4 (values j = 4 q .. 4 q + 3 of sub-quantiser m) into the LDS accumulators of centroid k.
+// Fast path (every value's significand is shifted LEFT: nothing below the integer grid): per value 3 + 3 + 1 + 1 integer
+// instructions and one ds_add_u64 at an immediate offset; otherwise the general split.  emax collects the exponent fields.
+template <int TPR>
+__device__ __forceinline__ bool km_fx_row(const float4 v, int k, int q, int sexp, unsigned long long* __restrict__ hi,
+                                          unsigned long long* __restrict__ lo, unsigned& emax) {
+    constexpr int ESTRIDE = RC_K * TPR;                    // accumulator (k, j = 4 q + e) at e ESTRIDE + k TPR + q
+    const unsigned b[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    unsigned long long* a = hi + (k * TPR + q);
+    unsigned e[4];
+    int sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        e[i] = (b[i] >> 23) & 0xFFu;
+        sh[i] = (int)(e[i] ? e[i] : 1u) - 150 + sexp;       // |x| 2^sexp = significand 2^sh
+    }
+    emax = max(emax, max(max(e[0], e[1]), max(e[2], e[3])));
+    const int shmin = min(min(sh[0], sh[1]), min(sh[2], sh[3]));
+    const int shmax = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+    bool inexact = false;
+    if (shmin >= 0 && shmax <= 40) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sig = (int)((b[i] & 0x7FFFFFu) | ((e[i] ? 1u : 0u) << 23));
+            const int sg = (int)b[i] >> 31;                                  // 0 / -1
+            const long long sv = (long long)((sig ^ sg) - sg);              // signed significand
+            atomicAdd(a + i * ESTRIDE, (unsigned long long)(sv << sh[i]));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long hl, ll;
+            inexact |= km_fx_split(b[i], sexp, hl, ll);
+            atomicAdd(a + i * ESTRIDE, (unsigned long long)hl);
+            if (ll) atomicAdd(lo + (k * TPR + q) + i * ESTRIDE, (unsigned long long)ll);
+        }
+    }
+    return inexact;
+}
+
+// 1-D grid of strips x (M / G) blocks.  A block owns a strip of rows and G ADJACENT sub-quantisers whose G dsub floats
+// are one contiguous piece of a row (128 bytes where dsub allows: whole cache lines); TPR = float4 lanes per row =
+// G qpm.  dynamic LDS: hi[4][256][TPR] | lo[...] (int64) | cnt[G][256] (u32).  Sub-vectors wider than 32 floats go
+// in column passes (j0, G = 1).  The row loop is software-pipelined: the next KM_FX_U rows per thread are requested
+// before the current ones are split and added.
+template <int PASS, int TPR>
+__global__ __launch_bounds__(1024) void kmeans_stats_fx_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const uint8_t* __restrict__ codes, int64_t n, int M, int dsub,
+                                                               int j0, int qpm, int64_t rows_per_strip,
+                                                               unsigned* __restrict__ state, const int* __restrict__ hint,
+                                                               int log2n, long long* __restrict__ phi,
+                                                               long long* __restrict__ plo, unsigned* __restrict__ pcnt) {
+    constexpr int ESTRIDE = RC_K * TPR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
+    unsigned long long* hi = reinterpret_cast<unsigned long long*>(km_smem);
+    unsigned long long* lo = hi + 4 * ESTRIDE;
+    unsigned* cnt = reinterpret_cast<unsigned*>(lo + 4 * ESTRIDE);
+    const km_decision dec = km_decide<PASS>(state, *hint, log2n);
+    if (PASS == 1 && !dec.redo) return;                    // the hint held (or inf / NaN: the strip kernels take the call)
+    const int sexp = dec.sexp;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int G = TPR / qpm, groups = M / G;
+    // XCD x (blocks L = x mod 8) walks a contiguous range of (strip, group) pairs, group fastest
+    const unsigned L = blockIdx.x, T = gridDim.x, per = T / 8u;
+    const unsigned v = (L < per * 8u) ? (L % 8u) * per + L / 8u : L;
+    const int m0 = (int)(v % (unsigned)groups) * G, strip = (int)(v / (unsigned)groups);
+    for (int i = tid; i < 8 * ESTRIDE; i += nthr) hi[i] = 0ull;
+    for (int i = tid; i < G * RC_K; i += nthr) cnt[i] = 0u;
+    __syncthreads();
+    const int64_t r0 = (int64_t)strip * rows_per_strip;
+    const int64_t r1 = (r0 + rows_per_strip < n) ? r0 + rows_per_strip : n;
+    const int rpi = nthr / TPR;                            // rows per block iteration (one float4 per thread)
+    const int q = tid % TPR, mloc = q / qpm;
+    unsigned emax = 0u;
+    bool inexact = false;
+    const bool count = PASS == 0 && (q % qpm) == 0 && j0 == 0;
+    unsigned* mycnt = cnt + mloc * RC_K;
+    if (tid < rpi * TPR) {
+        int64_t r = r0 + tid / TPR;
+        const float* xp = x + r * ldx + (m0 + mloc) * dsub + j0 + 4 * (q % qpm);
+        const uint8_t* cp = codes + r * M + m0 + mloc;
+        const int64_t xstep = (int64_t)rpi * ldx, cstep = (int64_t)rpi * M;
+        int kc[KM_FX_U];
+        float4 vc[KM_FX_U];
+#pragma unroll
+        for (int u = 0; u < KM_FX_U; ++u) {
+            const bool ok = r + (int64_t)u * rpi < r1;
+            kc[u] = ok ? (int)cp[u * cstep] : -1;
+            vc[u] = ok ? *reinterpret_cast<const float4*>(xp + u * xstep) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        while (r < r1) {
+            int kn[KM_FX_U];
+            float4 vn[KM_FX_U];
+            r += (int64_t)KM_FX_U * rpi;
+            xp += KM_FX_U * xstep;
+            cp += KM_FX_U * cstep;
+#pragma unroll
+            for (int u = 0; u < KM_FX_U; ++u) {
+                const bool ok = r + (int64_t)u * rpi < r1;
+                kn[u] = ok ? (int)cp[u * cstep] : -1;
+                vn[u] = ok ? *reinterpret_cast<const float4*>(xp + u * xstep) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < KM_FX_U; ++u) {
+                if (kc[u] >= 0) {
+                    inexact |= km_fx_row<TPR>(vc[u], kc[u], q, sexp, hi, lo, emax);
+                    if (count) atomicAdd(&mycnt[kc[u]], 1u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KM_FX_U; ++u) { kc[u] = kn[u]; vc[u] = vn[u]; }
+        }
+    }
+    if (PASS == 0) {
+        unsigned amax = emax << 23;                        // ordered like max|x|: only its exponent field is used
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned t = (unsigned)__shfl_xor((int)amax, o);
+            amax = t > amax ? t : amax;
+        }
+        const unsigned long long anyx = __ballot(inexact);
+        if ((tid & 63) == 0) {
+            if (amax > __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&state[0], amax);
+            if (anyx) atomicOr(&state[1], 1u);
+        }
+    }
+    __syncthreads();
+    // partials of this (strip, group): plain stores, [strip][m][k][j]
+    const int jn = 4 * qpm;                                // columns of one sub-quantiser in this pass
+    for (int i = tid; i < G * RC_K * jn; i += nthr) {
+        const int j = i % jn, k = (i / jn) % RC_K, ml = i / (jn * RC_K);
+        const int a = (j & 3) * ESTRIDE + k * TPR + ml * qpm + (j >> 2);
+        const size_t o = (((size_t)strip * M + m0 + ml) * RC_K + k) * dsub + j0 + j;
+        phi[o] = (long long)hi[a];
+        plo[o] = (long long)lo[a];
+    }
+    if (PASS == 0 && j0 == 0)
+        for (int i = tid; i < G * RC_K; i += nthr) pcnt[((size_t)strip * M + m0) * RC_K + i] = cnt[i];
+}
+
+// (hi 2^38 + lo) 2^(-sexp-38), rounded to nearest-even once
+__device__ __forceinline__ double km_fx_to_double(long long H, long long L, int sexp) {
+    __int128 t = ((__int128)H << KM_FX_LO_BITS) + (__int128)L;
+    const bool neg = t < 0;
+    unsigned __int128 u = neg ? (unsigned __int128)(-t) : (unsigned __int128)t;
+    const unsigned long long uh = (unsigned long long)(u >> 64), ul = (unsigned long long)u;
+    if ((uh | ul) == 0ull) return 0.0;
+    const int msb = uh ? 127 - __clzll((long long)uh) : 63 - __clzll((long long)ul);
+    double r;
+    if (msb <= 52) {
+        r = (double)ul;
+    } else {
+        const int sh = msb - 52;
+        unsigned long long qq = (unsigned long long)(u >> sh);                    // 53 bits
+        const unsigned __int128 rem = u & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+        qq += (rem > half || (rem == half && (qq & 1ull))) ? 1ull : 0ull;         // <= 2^53: exact in fp64
+        r = ldexp((double)qq, sh);
+    }
+    r = ldexp(r, -sexp - KM_FX_LO_BITS);
+    return neg ? -r : r;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void kmeans_stats_fx_finish_kernel(const long long* __restrict__ phi,
+                                                                     const long long* __restrict__ plo,
+                                                                     const unsigned* __restrict__ pcnt, int strips,
+                                                                     const unsigned* __restrict__ state,
+                                                                     const int* __restrict__ hint, int* __restrict__ hint_next,
+                                                                     int log2n, int64_t total, int dsub,
+                                                                     double* __restrict__ sums,
+                                                                     unsigned long long* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const km_decision dec = km_decide<1>(state, *hint, log2n);
+    if (PASS == 0 && i == 0) {
+        // the next call's bound: this data's, plus one bit so that a slightly larger maximum does not cost a second pass
+        *hint_next = dec.nonfinite ? *hint : (dec.tight_eb + 1 > 127 ? 127 : dec.tight_eb + 1);
+    }
+    if (i >= total) return;
+    if (PASS == 0 ? !dec.accept0 : !dec.redo) return;
+    long long H = 0, L = 0;
+    for (int t = 0; t < strips; ++t) {
+        H += phi[(size_t)t * total + i];
+        L += plo[(size_t)t * total + i];
+    }
+    sums[i] += km_fx_to_double(H, L, dec.sexp);
+    if (i % dsub == 0) {
+        unsigned long long c = 0;
+        for (int t = 0; t < strips; ++t) c += pcnt[(size_t)t * (total / dsub) + i / dsub];
+        counts[i / dsub] += c;
+    }
+}
+
+template <int PASS, int TPR>
+static int km_fx_launch_tpr(rc_handle_t h, int blocks, int nthr, size_t lds, size_t lds_max, hipStream_t s, const float* x,
+                            int64_t ldx, const uint8_t* codes, int64_t n, int M, int dsub, int j0, int qpm, int64_t frps, unsigned* state,
+                            const int* hint, int log2n, long long* phi, long long* plo, unsigned* pcn) {
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmeans_stats_fx_kernel<PASS, TPR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_max));
+    hipLaunchKernelGGL((kmeans_stats_fx_kernel<PASS, TPR>), dim3((unsigned)blocks), dim3(nthr), lds, s, x, ldx, codes, n, M, dsub, j0,
+                       qpm, frps, state, hint, log2n, phi, plo, pcn);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+template <int PASS>
+static int km_fx_launch(rc_handle_t h, int tpr, int blocks, int nthr, size_t lds, size_t lds_max, hipStream_t s, const float* x,
+                        int64_t ldx, const uint8_t* codes, int64_t n, int M, int dsub, int j0, int qpm, int64_t frps, unsigned* state,
+                        const int* hint, int log2n, long long* phi, long long* plo, unsigned* pcn) {
+#define KM_FX_CASE(T) case T: return km_fx_launch_tpr<PASS, T>(h, blocks, nthr, lds, lds_max, s, x, ldx, codes, n, M, dsub, j0, qpm, frps, \
+                                                              state, hint, log2n, phi, plo, pcn)
+    switch (tpr) {
+        KM_FX_CASE(1); KM_FX_CASE(2); KM_FX_CASE(3); KM_FX_CASE(4); KM_FX_CASE(5); KM_FX_CASE(6); KM_FX_CASE(7); KM_FX_CASE(8);
+        default: return RC_ESHAPE;
+    }
+#undef KM_FX_CASE
+}
+
+extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const uint8_t* codes, int64_t n, int D,
+                               int M, int K, double* sums, int64_t* counts, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !x || !codes || !sums || !counts || n < 0 || M <= 0 || D <= 0 || ldx < D) return RC_EINVAL;
+    if (K != RC_K || D % M != 0) return RC_ESHAPE;
+    const int dsub = D / M;
+    if (dsub > 256) return RC_ESHAPE;
+    if (n == 0) return RC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0) && (dsub % 4 == 0);
+    const int64_t per_strip = (int64_t)M * RC_K * dsub;
+    // exact fixed-point path (see above): float4 rows, n < 2^24 per call, finite input (checked on the device)
+    const bool fx = vec && n < (1ll << 24) && !rc_env_set("RC_KMEANS_STRIPS");
+    const unsigned* gate = nullptr;                                // device word: strip kernels run iff it is not finite
+    // strip fall-back geometry (shares the scratch block)
+    int64_t rps = 8192;                                            // rows per strip
+    int strips = (int)((n + rps - 1) / rps);
+    if (strips > KM_MAX_STRIPS) {
+        strips = KM_MAX_STRIPS;
+        rps = (n + strips - 1) / strips;
+        rps = (rps + KM_CHUNK - 1) / KM_CHUNK * KM_CHUNK;
+        strips = (int)((n + rps - 1) / rps);
+    }
+    const size_t pbytes = rc_align_up((size_t)strips * per_strip * sizeof(double), 256);
+    const size_t cbytes = rc_align_up((size_t)strips * M * RC_K * sizeof(unsigned), 256);
+    if (fx) {
+        int log2n = 0;
+        while ((1ll << log2n) < n) ++log2n;
+        if (!h->km_hint) {                                          // hint[2] + first-call value
+            RC_HIP_CHECK(h, hipMalloc((void**)&h->km_hint, 2 * sizeof(int)));
+            const int init[2] = {KM_FX_EB0, KM_FX_EB0};
+            RC_HIP_CHECK(h, hipMemcpy(h->km_hint, init, sizeof(init), hipMemcpyHostToDevice));
+            h->km_calls = 0;
+        }
+        // G adjacent sub-quantisers per block so that a row's piece is 128 bytes where the width allows (whole lines)
+        int G = dsub <= 32 ? 32 / dsub : 1;
+        if (G > 1 && M % G != 0) G = 1;
+        const int tpr_max = dsub <= KM_FX_JN ? G * dsub / 4 : KM_FX_JN / 4;
+        const size_t lds_max = (size_t)8 * RC_K * tpr_max * sizeof(unsigned long long) + (size_t)G * RC_K * sizeof(unsigned);
+        const int nthr = lds_max > 80 * 1024 ? 1024 : 512;          // 16 waves per CU either way
+        const int slots = h->num_cus * (nthr == 1024 ? 1 : 2);
+        const int groups = M / G;
+        int fstrips = slots / groups;                               // one round of equal blocks
+        if (fstrips < 1) fstrips = 1;
+        if (fstrips > (int)((n + 255) / 256)) fstrips = (int)((n + 255) / 256);
+        const int64_t frps = (n + fstrips - 1) / fstrips;
+        fstrips = (int)((n + frps - 1) / frps);
+        const size_t lbytes = rc_align_up((size_t)fstrips * per_strip * sizeof(long long), 256);
+        const size_t cb = rc_align_up((size_t)fstrips * M * RC_K * sizeof(unsigned), 256);
+        const size_t fx_bytes = 2 * lbytes + cb;
+        const size_t body = fx_bytes > pbytes + cbytes ? fx_bytes : pbytes + cbytes;
+        char* ws = (char*)rc_scratch(h, body + 256);
+        if (!ws) return RC_EHIP;
+        long long* phi = (long long*)ws;
+        long long* plo = (long long*)(ws + lbytes);
+        unsigned* pcn = (unsigned*)(ws + 2 * lbytes);
+        unsigned* state = (unsigned*)(ws + body);                   // behind everything the strip kernels use
+        const int* hint = h->km_hint + (h->km_calls & 1);
+        int* hint_next = h->km_hint + ((h->km_calls + 1) & 1);
+        ++h->km_calls;
+        RC_HIP_CHECK(h, hipMemsetAsync(state, 0, 2 * sizeof(unsigned), s));
+        const unsigned fin_blocks = (unsigned)((per_strip + 255) / 256);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int j0 = 0; j0 < dsub; j0 += KM_FX_JN) {
+                const int jn = dsub - j0 < KM_FX_JN ? dsub - j0 : KM_FX_JN;
+                const int qpm = jn / 4, tpr = G * qpm;
+                const size_t lds = (size_t)8 * RC_K * tpr * sizeof(unsigned long long) + (size_t)G * RC_K * sizeof(unsigned);
+                const int rc = pass == 0 ? km_fx_launch<0>(h, tpr, fstrips * groups, nthr, lds, lds_max, s, x, ldx, codes, n, M, dsub, j0, qpm,
+                                                           frps, state, hint, log2n, phi, plo, pcn)
+                                         : km_fx_launch<1>(h, tpr, fstrips * groups, nthr, lds, lds_max, s, x, ldx, codes, n, M, dsub, j0, qpm,
+                                                           frps, state, hint, log2n, phi, plo, pcn);
+                if (rc != RC_OK) return rc;
+                RC_LAUNCH_CHECK(h);
+            }
+            if (pass == 0)
+                hipLaunchKernelGGL(kmeans_stats_fx_finish_kernel<0>, dim3(fin_blocks), dim3(256), 0, s, (const long long*)phi,
+                                   (const long long*)plo, (const unsigned*)pcn, fstrips, (const unsigned*)state, hint, hint_next,
+                                   log2n, per_strip, dsub, sums, reinterpret_cast<unsigned long long*>(counts));
+            else
+                hipLaunchKernelGGL(kmeans_stats_fx_finish_kernel<1>, dim3(fin_blocks), dim3(256), 0, s, (const long long*)phi,
+                                   (const long long*)plo, (const unsigned*)pcn, fstrips, (const unsigned*)state, hint, hint_next,
+                                   log2n, per_strip, dsub, sums, reinterpret_cast<unsigned long long*>(counts));
+            RC_LAUNCH_CHECK(h);
+        }
+        gate = state;             // the strip kernels below leave at once unless max|x| is inf / NaN (decided on the device)
+    }
+    char* ws = (char*)rc_scratch(h, pbytes + cbytes + (fx ? 256 : 0));
+    if (!ws) return RC_EHIP;
+    double* part = (double*)ws;
+    unsigned* pcnt = (unsigned*)(ws + pbytes);
+    dim3 grid((unsigned)strips, (unsigned)M);
+    for (int j0 = 0; j0 < dsub;) {
+        const int left = dsub - j0;
+        if (vec && left >= 16) {
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<16>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt, gate);
+            j0 += 16;
+        } else if (vec && left >= 8) {
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<8>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt, gate);
+            j0 += 8;
+        } else if (vec && left >= 4) {
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<4>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt, gate);
+            j0 += 4;
+        } else {
+            hipLaunchKernelGGL(kmeans_stats_det_kernel<1>, grid, dim3(256), 0, s, x, ldx, codes, n, M, dsub, j0, rps, part, pcnt, gate);
+            j0 += 1;
+        }
+        RC_LAUNCH_CHECK(h);
+    }
+    hipLaunchKernelGGL(kmeans_stats_reduce_kernel, dim3((unsigned)((per_strip + 255) / 256)), dim3(256), 0, s, (const double*)part,
+                       (const unsigned*)pcnt, strips, per_strip, dsub, sums, reinterpret_cast<unsigned long long*>(counts), gate);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const double* __restrict__ sums,
+                                                            const long long* __restrict__ counts,
+                                                            float* __restrict__ C, int64_t total, int dsub) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long c = counts[i / dsub];
+    if (c > 0) C[i] = (float)(sums[i] / (double)c);
+}
+
+extern "C" int rc_kmeans_update(rc_handle_t h, const double* sums, const int64_t* counts, float* C, int M, int K,
+                                int dsub, rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !sums || !counts || !C || M <= 0 || dsub <= 0) return RC_EINVAL;
+    if (K != RC_K) return RC_ESHAPE;
+    const int64_t total = (int64_t)M * K * dsub;
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       sums, reinterpret_cast<const long long*>(counts), C, total, dsub);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ empty clusters
+// Faiss 1.7.x Clustering.cpp `split_clusters` (what `index.train`, train/run_warmup.py:113, does after every centroid
+// update), restated from the published source: per clustering (= per sub-quantiser) a std::mt19937 seeded with 1234
+// drives a cyclic walk cj = 0, 1, ... that accepts cluster cj as the donor of an empty cluster ci with probability
+// (size_cj - 1) / (n - k); centroid ci <- centroid cj, then ci *= 1 +- 1/1024 and cj *= 1 -+ 1/1024 alternating over the
+// components; the donor's (float) size is halved for the following draws.  On the device so that a Lloyd iteration has no
+// host synchronisation: one block per sub-quantiser, all threads look for an empty cluster, thread 0 makes the
+// (sequential, rare) walk with its own MT19937 in LDS.
+namespace {
+struct mt19937_lds {
+    unsigned* mt;
+    int idx;
+    __device__ void seed(unsigned s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned)i;
+        idx = 624;
+    }
+    __device__ unsigned next() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; ++i) {
+                const unsigned y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        unsigned y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+};
+}  // namespace
+
+__global__ __launch_bounds__(RC_K) void kmeans_split_empty_kernel(float* __restrict__ C, const long long* __restrict__ counts,
+                                                                  int dsub, int* __restrict__ nsplit) {
+    __shared__ unsigned s_mt[624];
+    __shared__ float s_h[RC_K];
+    __shared__ int s_any;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const long long c = counts[(size_t)m * RC_K + tid];
+    s_h[tid] = (float)c;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    if (c == 0) s_any = 1;
+    __syncthreads();
+    if (!s_any || tid != 0) return;
+    long long n = 0;
+    float hmax = 0.f;
+    for (int k = 0; k < RC_K; ++k) { n += counts[(size_t)m * RC_K + k]; hmax = fmaxf(hmax, s_h[k]); }
+    const double denom = (double)(float)(n - RC_K);
+    mt19937_lds rng{s_mt, 624};
+    rng.seed(1234u);
+    float* Cm = C + (size_t)m * RC_K * dsub;
+    const float up = 1.0f + 1.0f / 1024.0f, dn = 1.0f - 1.0f / 1024.0f;
+    int splits = 0;
+    for (int ci = 0; ci < RC_K; ++ci) {
+        if (s_h[ci] != 0.f) continue;
+        int cj = 0;
+        if (!(denom > 0.0) || hmax <= 1.f) {                    // Faiss would never accept: take the biggest cluster
+            for (int k = 1; k < RC_K; ++k) cj = s_h[k] > s_h[cj] ? k : cj;
+        } else {
+            for (int draws = 0; draws < 10000000; ++draws) {
+                const float p = (float)(((double)s_h[cj] - 1.0) / denom);
+                const float r = (float)rng.next() / 4294967296.0f;     // float(mt()) / float(mt.max()): float(2^32 - 1) = 2^32
+                if (r < p) break;
+                cj = (cj + 1) % RC_K;
+            }
+        }
+        for (int j = 0; j < dsub; ++j) {
+            const float v = Cm[(size_t)cj * dsub + j];
+            Cm[(size_t)ci * dsub + j] = v * ((j & 1) ? dn : up);
+            Cm[(size_t)cj * dsub + j] = v * ((j & 1) ? up : dn);
+        }
+        s_h[ci] = s_h[cj] / 2.0f;
+        s_h[cj] = s_h[cj] - s_h[ci];
+        ++splits;
+    }
+    if (nsplit && splits) atomicAdd(nsplit, splits);
+}
+
+extern "C" int rc_kmeans_split_empty(rc_handle_t h, float* C, const int64_t* counts, int M, int K, int dsub, int* nsplit,
+                                     rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !C || !counts || M <= 0 || dsub <= 0) return RC_EINVAL;
+    if (K != RC_K) return RC_ESHAPE;
+    hipLaunchKernelGGL(kmeans_split_empty_kernel, dim3((unsigned)M), dim3(RC_K), 0, (hipStream_t)stream, C,
+                       reinterpret_cast<const long long*>(counts), dsub, nsplit);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
+}

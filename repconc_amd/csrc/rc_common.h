@@ -46,6 +46,8 @@ struct rc_handle_s {
     size_t scratch_bytes;
     int graph_broken;                                 // capture failed once on this handle: stay eager
     int capturing;                                    // inside stream capture: no event marks
+    int* km_hint;                                     // kmeans.hip: device int[2], bound exponent of the fixed-point statistics
+    unsigned long long km_calls;                      // parity picks the hint word read / written by a call
 };
 
 // comm.hip: the full constrained assignment as one or two chains of sub-quantisers (world == 1: no RCCL)

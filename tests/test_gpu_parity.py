@@ -1678,6 +1678,63 @@ def test_kmeans_statistics_are_deterministic_and_match_the_oracle():
     np.testing.assert_allclose(sb[good], ws[good], rtol=1e-12, atol=1e-9)
 
 
+def _fsum_stats(x, codes, M):
+    """sums[m, k, j] = the correctly rounded real sum (math.fsum) of the rows with code k — what exact integer parts give."""
+    import math
+    n, D = x.shape
+    dsub = D // M
+    out = np.zeros((M, 256, dsub))
+    xd = x.astype(np.float64).reshape(n, M, dsub)
+    for m in range(M):
+        order = np.argsort(codes[:, m], kind="stable")
+        ks, starts = np.unique(codes[order, m], return_index=True)
+        ends = list(starts[1:]) + [n]
+        for k, a, b in zip(ks, starts, ends):
+            blk = xd[order[a:b], m, :]
+            for j in range(dsub):
+                out[m, k, j] = math.fsum(blk[:, j])
+    return out
+
+
+def test_kmeans_statistics_are_the_correctly_rounded_sums_whatever_was_called_before():
+    """Round 4: the fixed-point statistics take their scale from a per-handle hint (no max|x| pass) and repeat the work on
+    the device when the hint was too small or a part had to be rounded.  While all parts are exact the 128-bit integer total
+    is rounded once, so the answer is math.fsum of the members bit for bit — independent of the hint (call history), of the
+    strip geometry and of the data's magnitude."""
+    from repconc_amd import ops
+    M, n = 48, 4000
+    x = synth.gaussian(170, (n, 768))
+    x[:, 7] *= np.float32(3e-5)                                       # small values: their low parts are not empty
+    codes = synth.uniform_codes(171, n, M)
+    want = _fsum_stats(x, codes, M)
+    xt, ct = _t(x), _t(codes)
+    s_a, c_a = ops.kmeans_stats(xt, ct)
+    assert np.array_equal(s_a.cpu().numpy(), want), "not the correctly rounded sums"
+    big = _t(x * np.float32(4096.0))                                  # exceeds any hint left by the call above: second pass
+    s_b, _ = ops.kmeans_stats(big, ct)
+    assert np.array_equal(s_b.cpu().numpy(), want * 4096.0)
+    s_c, c_c = ops.kmeans_stats(xt, ct)                               # now the hint is 2^12 too loose: still exact
+    assert torch.equal(s_c, s_a) and torch.equal(c_c, c_a)
+    tiny = _t(x * np.float32(2.0 ** -40))
+    s_d, _ = ops.kmeans_stats(tiny, ct)                               # far below the hint: low parts rounded -> second pass
+    assert np.array_equal(s_d.cpu().numpy(), want * 2.0 ** -40)
+    s_e, _ = ops.kmeans_stats(xt, ct)
+    assert torch.equal(s_e, s_a)
+    # a range of 2^70 inside one call: the tight-bound pass rounds what cannot be held; result within fp64 rounding
+    wide = x.copy()
+    wide[::2, 3] *= np.float32(2.0 ** 40)
+    wide[1::2, 3] *= np.float32(2.0 ** -30)
+    s_w, _ = ops.kmeans_stats(_t(wide), ct)
+    np.testing.assert_allclose(s_w.cpu().numpy(), _fsum_stats(wide, codes, M), rtol=1e-15, atol=1e-10)   # n 2^-45
+    # other widths / several column passes / ragged sizes
+    for M2, n2 in ((8, 1500), (64, 777), (24, 2049), (96, 300)):
+        x2 = synth.gaussian(180 + M2, (n2, 768)) * np.float32(0.37)
+        c2 = synth.uniform_codes(181 + M2, n2, M2)
+        s2, cnt2 = ops.kmeans_stats(_t(x2), _t(c2))
+        assert np.array_equal(s2.cpu().numpy(), _fsum_stats(x2, c2, M2)), M2
+        assert np.array_equal(cnt2.cpu().numpy(), pq_oracle.kmeans_stats(x2, c2, M2)[1])
+
+
 @pytest.mark.parametrize("M", [16, 32, 48, 64])
 def test_ivf_list_centric_search_equals_per_query_scan(M):
     """rc_ivf_search_lists (cells scanned once per group of up to 8 probing queries, 8-bit screen + exact rescoring) against
