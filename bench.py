@@ -706,6 +706,39 @@ def main():
         del xr, Pm
         del xt, Cw, Rw
 
+    # ------------------------------------------------------------------ k-means sufficient statistics (GPU leg)
+    # at the sizes the path runs it on: the 65 536 training rows of the warm-up (run_warmup.py:92-113) and a 2^20-row corpus
+    # chunk (corpus-sharded k-means, BASELINE configs[2]); the CPU port is timed beside it in the cpu_baseline block
+    if world == 1:
+        ks_sizes = {}
+        gk = torch.Generator(device=dev).manual_seed(20228)
+        for rows in (1 << 16, 1 << 20):
+            xg = torch.randn((rows, D), device=dev, generator=gk)
+            cg = torch.randint(0, 256, (rows, M), dtype=torch.uint8, device=dev, generator=gk)
+            for _ in range(3):
+                ops.kmeans_stats(xg, cg)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.kmeans_stats(xg, cg)
+            e1.record()
+            torch.cuda.synchronize()
+            kg = e0.elapsed_time(e1) / 10 * 1e-3
+            ks_sizes[rows] = {"rows": rows, "ms": round(kg * 1e3, 4), "value": round(rows / kg, 1), "unit": "vectors/s",
+                              "roofline": {"kernel": "kmeans_stats_fx_kernel<0, 8> (integer split of the fp32 bits, 64-bit LDS "
+                                                     "accumulators, plain per-strip partials; the whole rc_kmeans_stats call is timed)",
+                                           "bound": "hbm", "achieved": round(rows * (D * 4 + M) / kg / 1e9, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(rows * (D * 4 + M) / kg / 1e9 / HBM_PEAK_GBS, 4),
+                                           "algorithmic_bytes_per_launch": rows * (D * 4 + M)}}
+            del xg, cg
+        big = ks_sizes[1 << 20]
+        out["kmeans_stats"] = {"metric": "kmeans_sufficient_statistics_vectors_per_sec", "value": big["value"],
+                               "unit": "vectors/s", "rows": big["rows"], "ms": big["ms"], "roofline": big["roofline"],
+                               "warmup_size_65536": ks_sizes[1 << 16],
+                               "note": "4 D + M bytes per vector (SURVEY 8d), HIP events around 10 calls"}
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     if world == 1 and not args.no_cpu:
         from oracle import c_oracle
@@ -749,36 +782,9 @@ def main():
                 "sample": f"{Bs} rows, exact fp32 nearest codes, oracle/pq_oracle.c ({nall:.2f} s); one thread: "
                           f"{512 / n1:.0f} vectors/s (512 rows, {n1:.2f} s)"}
             out["index_build"]["speedup_vs_cpu_baseline"] = round(out["index_build"]["value"] / (Bs / nall), 1)
-        # GPU side at the sizes the path runs it on: the 65 536 training rows of the warm-up (run_warmup.py:92-113) and a
-        # 2^20-row corpus chunk (corpus-sharded k-means, BASELINE configs[2]); the CPU port beside it on the 16 384-row sample
-        ks_sizes = {}
-        gk = torch.Generator(device=dev).manual_seed(20228)
-        for rows in (1 << 16, 1 << 20):
-            xg = torch.randn((rows, D), device=dev, generator=gk)
-            cg = torch.randint(0, 256, (rows, M), dtype=torch.uint8, device=dev, generator=gk)
-            ops.kmeans_stats(xg, cg)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                ops.kmeans_stats(xg, cg)
-            e1.record()
-            torch.cuda.synchronize()
-            kg = e0.elapsed_time(e1) / 10 * 1e-3
-            ks_sizes[rows] = {"rows": rows, "ms": round(kg * 1e3, 4), "value": round(rows / kg, 1), "unit": "vectors/s",
-                              "roofline": {"kernel": "kmeans_stats_fx_kernel (exact fixed-point split, 64-bit integer atomics)",
-                                           "bound": "hbm", "achieved": round(rows * (D * 4 + M) / kg / 1e9, 1),
-                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": round(rows * (D * 4 + M) / kg / 1e9 / HBM_PEAK_GBS, 4),
-                                           "algorithmic_bytes_per_launch": rows * (D * 4 + M)}}
-            del xg, cg
-        big = ks_sizes[1 << 20]
-        out["kmeans_stats"] = {"metric": "kmeans_sufficient_statistics_vectors_per_sec", "value": big["value"],
-                               "unit": "vectors/s", "rows": big["rows"], "ms": big["ms"], "roofline": big["roofline"],
-                               "warmup_size_65536": ks_sizes[1 << 16],
-                               "note": "4 D + M bytes per vector (SURVEY 8d), HIP events around 10 launches",
-                               "cpu_baseline": {"value": round(Bs / ks, 1), "unit": "vectors/s", "cores": 1, "kind": "port",
-                                                "sample": f"{Bs} rows, numpy restatement oracle/pq_oracle.py ({ks:.2f} s)"}}
+        if "kmeans_stats" in out:
+            out["kmeans_stats"]["cpu_baseline"] = {"value": round(Bs / ks, 1), "unit": "vectors/s", "cores": 1, "kind": "port",
+                                                   "sample": f"{Bs} rows, numpy restatement oracle/pq_oracle.py ({ks:.2f} s)"}
         if not args.no_adc:
             # ~8 queries per thread over the WHOLE index: about 10 s of host time whatever the core count
             nq_c = min(8 * cores, int(q_all.shape[0]))

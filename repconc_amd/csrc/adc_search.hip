@@ -33,6 +33,7 @@
 // (consecutive lanes = consecutive rows, 16-byte loads).  Blocks that share a code tile are
 // adjacent in the grid, so a tile is fetched from HBM about once per XCD and re-read from L2.
 #include "rc_common.h"
+#include <stdio.h>
 
 #include <limits.h>
 #include <string.h>
@@ -42,7 +43,6 @@
 #define ADC_THREADS 1024
 #define ADC_SAMPLE_MAX 32768
 #define ADC_CAND_CAP 16384
-#define ADC_SELECT_SMALL ADC_CAND_CAP   // lists up to this length are sorted in LDS (measured: 128 KiB, one block per CU, 0.54 ms per 1200 queries; 64 KiB / two blocks per CU 0.95 ms; the typical list at k = 1000 holds ~5 k keys)
 #define ADC_TILE_DOCS 32768
 #ifndef RC_ADC_IMG16
 #define RC_ADC_IMG16 0         // 1: the permuted code image holds 16-bit codes (one v_mad_u32_u16 per gather address instead of bfe + lshl_add)
@@ -279,23 +279,94 @@ __global__ __launch_bounds__(1024) void adc_threshold_kernel(const float* __rest
     if (tid == 0) thr[qi] = adc_unorder_key(sel_prefix);
 }
 
+// ---- bitonic sort of P keys (descending) in LDS, register-blocked ----------------------------------------------------
+// The plain network makes one LDS round trip (read 2, write 2 keys per pair) and one barrier per (size, stride) stage: 66
+// stages for 2048 keys = 4.2 MB of LDS traffic per query — at four blocks per CU the LDS pipe, not latency, was the
+// kernel's whole time (round 4 measurement: 138 us per 1200 queries with one block per CU, 150 us with four).  Here a
+// work item takes the 2^NB keys that differ in NB consecutive index bits, runs the NB stages of those strides in
+// registers and writes the keys back: ceil(c / 3) round trips for the c strides of a merge, and the merges of sizes 2, 4, 8
+// in ONE pass: 24 round trips for 2048 keys.  Keys live at padded positions i + i / 32 so that the stride-1 / 2 / 4
+// passes (a lane's keys 8, 16, 32 apart from its neighbour's) do not fall on the same banks.
+__device__ __forceinline__ int adc_sp(int i) { return i + (i >> 5); }
+__device__ __forceinline__ void adc_cmpx(unsigned long long& a, unsigned long long& b, bool desc) {
+    const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+    a = desc ? hi : lo;
+    b = desc ? lo : hi;
+}
+template <int NB>
+__device__ __forceinline__ void adc_bitonic_pass(unsigned long long* keys, int P, int size, int L, int tid, int nthr) {
+    constexpr int NK = 1 << NB;
+    const int lsh = 31 - __clz(L);
+    for (int t = tid; t < (P >> NB); t += nthr) {
+        const int base = ((t >> lsh) << (lsh + NB)) | (t & (L - 1));
+        const bool desc = (base & size) == 0;
+        unsigned long long v[NK];
+#pragma unroll
+        for (int j = 0; j < NK; ++j) v[j] = keys[adc_sp(base + j * L)];
+#pragma unroll
+        for (int b = NB - 1; b >= 0; --b)
+#pragma unroll
+            for (int j = 0; j < NK; ++j)
+                if (!(j & (1 << b))) adc_cmpx(v[j], v[j | (1 << b)], desc);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) keys[adc_sp(base + j * L)] = v[j];
+    }
+    __syncthreads();
+}
+// keys[adc_sp(0 .. P)) sorted descending; P a power of two >= 8; called by every thread of the block, ends in a barrier
+__device__ __forceinline__ void adc_bitonic_sort_lds(unsigned long long* keys, int P, int tid, int nthr) {
+    // sizes 2, 4, 8 on 8 consecutive keys
+    for (int t = tid; t < (P >> 3); t += nthr) {
+        const int base = t << 3;
+        unsigned long long v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = keys[adc_sp(base + j)];
+#pragma unroll
+        for (int sz = 2; sz <= 8; sz <<= 1)
+#pragma unroll
+            for (int st = sz >> 1; st > 0; st >>= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (!(j & st)) adc_cmpx(v[j], v[j | st], ((base + j) & sz) == 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) keys[adc_sp(base + j)] = v[j];
+    }
+    __syncthreads();
+    for (int size = 16; size <= P; size <<= 1) {
+        int c = 31 - __clz(size);                             // strides size/2 .. 1: c of them, the first chunk takes c mod 3
+        int s = size >> 1;
+        while (c > 0) {
+            const int nb = (c % 3) ? (c % 3) : 3;
+            const int L = s >> (nb - 1);
+            if (nb == 3) adc_bitonic_pass<3>(keys, P, size, L, tid, nthr);
+            else if (nb == 2) adc_bitonic_pass<2>(keys, P, size, L, tid, nthr);
+            else adc_bitonic_pass<1>(keys, P, size, L, tid, nthr);
+            c -= nb;
+            s = L >> 1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ 5. select
 // One block per query.  Sort the candidate keys descending (bitonic, LDS), emit the first k.
 // status |= 1 if fewer than min(k,N) candidates were collected, |= 2 if the list overflowed.
-// Lists of up to ADC_SELECT_SMALL keys are sorted in LDS; longer ones (only if that constant is set below ADC_CAND_CAP)
-// in place in the candidate buffer in global memory — same network, same result, slower.
+// Round 4: the block's LDS holds `cap` keys, cap = the power of two >= max(4096, 2 k) (host, adc_select_cap): lists longer
+// than max(2048, 2 k) are first cut down to the k best scores (+ every tie at the k-th score) by a radix select over the
+// list in global memory (L2), so what is sorted always fits — 32 KiB and 512 threads per block at k = 1000, four blocks
+// per CU, where round 3 reserved 128 KiB (one 1024-thread block per CU: 27 us of barrier-to-barrier latency per query with
+// nothing to overlap it; 138 -> 60 us per 1200 queries).  Only a tie group at the k-th score that does not fit takes the
+// sort in global memory (same network, same result).
 __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __restrict__ cand,
                                                           const unsigned* __restrict__ cand_count, int64_t N, int k,
                                                           int64_t id_offset, float* __restrict__ scores,
                                                           int64_t* __restrict__ ids, int* __restrict__ status,
-                                                          int* __restrict__ qstatus) {
+                                                          int* __restrict__ qstatus, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int qi = blockIdx.x, tid = threadIdx.x;
+    const int qi = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const unsigned raw = cand_count[qi];
     const int cnt = raw > ADC_CAND_CAP ? ADC_CAND_CAP : (int)raw;
-    const bool in_lds = cnt <= ADC_SELECT_SMALL;             // block-uniform
     unsigned long long* gk = cand + (size_t)qi * ADC_CAND_CAP;
-    unsigned long long* keys = in_lds ? reinterpret_cast<unsigned long long*>(smem) : gk;
+    unsigned long long* lk = reinterpret_cast<unsigned long long*>(smem);
     const int64_t want = (k < N) ? k : N;
     if (tid == 0) {
         int st = 0;
@@ -306,15 +377,13 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __
             if (qstatus) atomicOr(qstatus + qi, st);          // which query: the caller repeats only those
         }
     }
-    // Long lists (the threshold of step 3 lets ~5 k rows through for k = 1000) are first cut down to the k best scores
-    // (+ every tie at the k-th score): radix select of the k-th largest 32-bit score key, then compaction into LDS.  The
-    // sort network then runs on ~k keys instead of the whole list.
     __shared__ unsigned hist[256];
     __shared__ unsigned sel_prefix, sel_rank, survivors;
     __shared__ unsigned s_scan[4];
     int n = cnt;
-    if (in_lds && cnt > 2048 && cnt > 2 * k) {
-        if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)k; survivors = 0u; }
+    bool in_lds = cnt <= cap;                                 // block-uniform
+    if ((cnt > 2048 && cnt > 2 * k) || !in_lds) {
+        if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)(k < cnt ? k : cnt); survivors = 0u; }
         __syncthreads();
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 24 - 8 * pass;
@@ -322,7 +391,7 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __
             __syncthreads();
             const unsigned prefix = sel_prefix;
             const unsigned himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
-            for (int i = tid; i < cnt; i += 1024) {
+            for (int i = tid; i < cnt; i += nthr) {
                 const unsigned sk = (unsigned)(gk[i] >> 32);
                 if ((sk & himask) == prefix) atomicAdd(&hist[(sk >> shift) & 0xFFu], 1u);
             }
@@ -330,40 +399,48 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __
             adc_pick_bin(hist, sel_rank, prefix, shift, s_scan, &sel_prefix, &sel_rank);
         }
         const unsigned kth = sel_prefix;                      // k-th largest score key
-        for (int i = tid; i < cnt; i += 1024) {
+        for (int i = tid; i < cnt; i += nthr) {
             const unsigned long long key = gk[i];
-            if ((unsigned)(key >> 32) >= kth) keys[atomicAdd(&survivors, 1u)] = key;
+            if ((unsigned)(key >> 32) >= kth) {
+                const unsigned slot = atomicAdd(&survivors, 1u);
+                if ((int)slot < cap) lk[adc_sp((int)slot)] = key;
+            }
         }
         __syncthreads();
-        n = (int)survivors;                                   // >= k
+        in_lds = (int)survivors <= cap;
+        if (in_lds) n = (int)survivors;                       // >= min(k, cnt)
     }
     int P = 1024;
     while (P < n) P <<= 1;
-    if (n != cnt) {
-        for (int i = n + tid; i < P; i += 1024) keys[i] = 0ull;
-    } else if (in_lds) {
-        for (int i = tid; i < P; i += 1024) keys[i] = (i < cnt) ? gk[i] : 0ull;
-    } else {
-        for (int i = cnt + tid; i < P; i += 1024) gk[i] = 0ull;       // P <= ADC_CAND_CAP
-    }
-    __syncthreads();
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (P >> 1); t += 1024) {
-                const int lo = ((t / stride) * (stride << 1)) + (t % stride);
-                const int hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long a = keys[lo], b = keys[hi];
-                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+    if (!in_lds) {
+        for (int i = cnt + tid; i < P; i += nthr) gk[i] = 0ull;           // P <= ADC_CAND_CAP
+        __syncthreads();
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (P >> 1); t += nthr) {
+                    const int lo = ((t / stride) * (stride << 1)) + (t % stride);
+                    const int hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const unsigned long long a = gk[lo], b = gk[hi];
+                    if ((a < b) == desc) { gk[lo] = b; gk[hi] = a; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
+    } else {
+        if (n != cnt) {
+            for (int i = n + tid; i < P; i += nthr) lk[adc_sp(i)] = 0ull;
+        } else {
+            for (int i = tid; i < P; i += nthr) lk[adc_sp(i)] = (i < cnt) ? gk[i] : 0ull;
+        }
+        __syncthreads();
+        adc_bitonic_sort_lds(lk, P, tid, nthr);
     }
-    for (int j = tid; j < k; j += 1024) {
+    for (int j = tid; j < k; j += nthr) {
         float sc = -INFINITY;
         int64_t id = -1;
         if (j < n) {
-            const unsigned long long key = keys[j];
+            const unsigned long long key = in_lds ? lk[adc_sp(j)] : gk[j];
             sc = adc_unorder_key((unsigned)(key >> 32));
             id = (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) + id_offset;
         }
@@ -1676,11 +1753,41 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
 
 // One block per query: exact fp32 score (m ascending, from 0) of every screened row; rows with score >= tau go
 // to the key list exactly as adc_scan_kernel<FILTER> would have put them.
-// 512 threads: a block's table is 4 M x 256 bytes of LDS (three blocks per CU at M = 48), and every survivor costs one
-// dependent 48-byte read from HBM - more rows in flight per CU
-#define ADC_RESCORE_THREADS 512
+// A block's table is 4 M x 256 bytes of LDS and every survivor costs one dependent M-byte read from HBM, so the kernel lives
+// on rows in flight: the block is as large as the LDS lets the CU hold 16+ waves (adc_rescore_threads), the table and the
+// codes move in 16-byte pieces, and every thread has two rows in flight (round 4; 512 threads and 4-byte loads before:
+// M = 96 ran 8 waves per CU).
 template <int M>
-__global__ __launch_bounds__(ADC_RESCORE_THREADS) void adc_rescore_kernel(const uint8_t* __restrict__ codes,
+__device__ __forceinline__ float adc_rescore_row(const uint8_t* __restrict__ cp, const float* __restrict__ tab) {
+    constexpr int W = (M % 16 == 0) ? 16 : (M % 8 == 0) ? 8 : 4;  // load width in bytes
+    unsigned w[M / 4];
+#pragma unroll
+    for (int j = 0; j < M / W; ++j) {
+        if constexpr (W == 16) {
+            const uint4 v = reinterpret_cast<const uint4*>(cp)[j];
+            w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+        } else if constexpr (W == 8) {
+            const uint2 v = reinterpret_cast<const uint2*>(cp)[j];
+            w[2 * j] = v.x; w[2 * j + 1] = v.y;
+        } else {
+            w[j] = reinterpret_cast<const unsigned*>(cp)[j];
+        }
+    }
+    float s = 0.f;
+#if defined(RC_ABL_RESCORE) && (RC_ABL_RESCORE & 2)
+#pragma unroll
+    for (int m = 0; m < M / 4; ++m) s = s + __uint_as_float(w[m]);
+#else
+#pragma unroll
+    for (int m = 0; m < M; ++m) s = s + tab[m * RC_K + ((w[m >> 2] >> (8 * (m & 3))) & 0xFFu)];
+#endif
+    return s;
+}
+
+static int adc_rescore_threads(int M) { return M * RC_K * 4 > 80 * 1024 ? 1024 : 512; }
+
+template <int M>
+__global__ __launch_bounds__(1024) void adc_rescore_kernel(const uint8_t* __restrict__ codes,
                                                           const float* __restrict__ lut,
                                                           const float* __restrict__ thr,
                                                           const unsigned* __restrict__ id_count,
@@ -1692,45 +1799,68 @@ __global__ __launch_bounds__(ADC_RESCORE_THREADS) void adc_rescore_kernel(const 
                                                           int* __restrict__ qstatus = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tab = reinterpret_cast<float*>(smem);  // [M][256]
-    const int qi = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < M * RC_K; i += ADC_RESCORE_THREADS) tab[i] = lut[(size_t)qi * M * RC_K + i];
+    const int qi = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const unsigned raw = id_count[qi];
     const unsigned cnt = raw > ADC_ID_CAP ? ADC_ID_CAP : raw;
+    const unsigned* qids = ids + (size_t)qi * ADC_ID_CAP;
+    // the first rows' ids and codes are requested before the table: their latency hides behind the staging
+    unsigned n0 = 0, n1 = 0;
+    if (tid < (int)cnt) n0 = qids[tid];
+    if (tid + nthr < (int)cnt) n1 = qids[tid + nthr];
+    {
+        const float4* l4 = reinterpret_cast<const float4*>(lut + (size_t)qi * M * RC_K);
+        float4* t4 = reinterpret_cast<float4*>(tab);
+        for (int i = tid; i < M * RC_K / 4; i += nthr) t4[i] = l4[i];
+    }
     if (tid == 0 && raw > ADC_ID_CAP) {
         atomicOr(status, 2);
         if (qstatus) atomicOr(qstatus + qi, 2);
     }
     const float tau = thr[qi];
+    // this block is the only writer of the query's key list: slots come from an LDS counter, the global count is written
+    // once at the end (round 3: one returning global atomic per wave and iteration, all on ONE address — 27 of 150 us)
+    __shared__ unsigned s_slots;
+    if (tid == 0) s_slots = 0u;
+    const unsigned base0 = cand_count[qi];
     __syncthreads();
-    for (unsigned i0 = 0; i0 < cnt; i0 += ADC_RESCORE_THREADS) {
-        const unsigned i = i0 + tid;
-        const bool live = i < cnt;
-        const unsigned n = ids[(size_t)qi * ADC_ID_CAP + (live ? i : 0)];
-        const unsigned* cp = reinterpret_cast<const unsigned*>(codes + (size_t)n * M);
-        float s = 0.f;
+    for (unsigned i0 = 0; i0 < cnt; i0 += 2 * nthr) {
+        const unsigned ia = i0 + tid, ib = ia + nthr;
+        const bool la = ia < cnt, lb = ib < cnt;
+        const unsigned na = n0, nb = n1;
+        // next pair of ids (dependent chain: id -> codes), requested before this pair is scored
+        n0 = (ia + 2 * nthr < cnt) ? qids[ia + 2 * nthr] : 0u;
+        n1 = (ib + 2 * nthr < cnt) ? qids[ib + 2 * nthr] : 0u;
+        const float sa = adc_rescore_row<M>(codes + (size_t)(la ? na : 0u) * M, tab);
+        const float sb = adc_rescore_row<M>(codes + (size_t)(lb ? nb : 0u) * M, tab);
 #pragma unroll
-        for (int j = 0; j < M / 4; ++j) {
-            const unsigned w = cp[j];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) s = s + tab[(4 * j + b) * RC_K + ((w >> (8 * b)) & 0xFFu)];
-        }
-        const bool pass = live && (s >= tau);
-        const unsigned long long mask = __ballot(pass);
-        if (mask) {
-            const int lane = tid & 63;
-            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-            unsigned base = 0;
-            if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(cand_count + qi, (unsigned)__popcll(mask));
-            base = __shfl(base, (int)__builtin_ctzll(mask));
-            const unsigned slot = base + rank;
-            if (pass && slot < ADC_CAND_CAP) {
-                // IVF: rows are stored cell-major; the key carries the row's corpus position so ties order by corpus id
-                const unsigned id = rowmap ? (unsigned)rowmap[n] : n;
-                cand[(size_t)qi * ADC_CAND_CAP + slot] =
-                    ((unsigned long long)adc_order_key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - id);
+        for (int h = 0; h < 2; ++h) {
+            const bool live = h ? lb : la;
+            const float sc = h ? sb : sa;
+            const unsigned n = h ? nb : na;
+            const bool pass = live && (sc >= tau);
+#if defined(RC_ABL_RESCORE) && (RC_ABL_RESCORE & 1)
+            const unsigned long long mask = __ballot(pass && sc == 12345.678f);
+#else
+            const unsigned long long mask = __ballot(pass);
+#endif
+            if (mask) {
+                const int lane = tid & 63;
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                unsigned base = 0;
+                if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(&s_slots, (unsigned)__popcll(mask));
+                base = __shfl(base, (int)__builtin_ctzll(mask));
+                const unsigned slot = base0 + base + rank;
+                if (pass && slot < ADC_CAND_CAP) {
+                    // IVF: rows are stored cell-major; the key carries the row's corpus position so ties order by corpus id
+                    const unsigned id = rowmap ? (unsigned)rowmap[n] : n;
+                    cand[(size_t)qi * ADC_CAND_CAP + slot] =
+                        ((unsigned long long)adc_order_key(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - id);
+                }
             }
         }
     }
+    __syncthreads();
+    if (tid == 0 && s_slots) cand_count[qi] = base0 + s_slots;
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -2099,7 +2229,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
     auto krescore = adc_rescore_kernel<M>;
     const size_t rl = (size_t)M * RC_K * sizeof(float);
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-    hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(ADC_RESCORE_THREADS), rl, s, codes, b.lut, b.thr, b.idcnt, b.ids, b.cnt, b.cand,
+    hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(adc_rescore_threads(M)), rl, s, codes, b.lut, b.thr, b.idcnt, b.ids, b.cnt, b.cand,
                        status, (const int64_t*)nullptr, qstatus);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
@@ -2134,11 +2264,15 @@ extern "C" int rc_adc_lut(rc_handle_t h, const float* C, const float* q, int nq,
 // sort + emit stage, shared with the IVF path (ivf_search.hip)
 int rc_adc_launch_select(rc_handle_t h, unsigned long long* cand, const unsigned* cnt, int nq, int64_t N, int k,
                          int64_t id_offset, float* scores, int64_t* ids, int* status, hipStream_t s, int* qstatus = nullptr) {
-    const size_t ss = (size_t)ADC_SELECT_SMALL * sizeof(unsigned long long);
+    int cap = 4096;                                            // keys held in LDS: >= max(2048, 2 k), see adc_select_kernel
+    while (cap < 2 * k && cap < ADC_CAND_CAP) cap <<= 1;
+    if (const int e = rc_env_int("RC_ADC_SELECT_CAP", 0)) cap = e;        // tests: 1024 forces the global-memory sort
+    const size_t ss = (size_t)(cap + cap / 32) * sizeof(unsigned long long);       // padded positions, adc_sp
+    const int nthr = cap <= 8192 ? 512 : 1024;
     RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)adc_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)ss));
-    hipLaunchKernelGGL(adc_select_kernel, dim3((unsigned)nq), dim3(1024), ss, s, cand, cnt, N, k, id_offset, scores, ids,
-                       status, qstatus);
+                                        (int)((ADC_CAND_CAP + ADC_CAND_CAP / 32) * sizeof(unsigned long long))));
+    hipLaunchKernelGGL(adc_select_kernel, dim3((unsigned)nq), dim3(nthr), ss, s, cand, cnt, N, k, id_offset, scores, ids,
+                       status, qstatus, cap);
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
@@ -2979,9 +3113,13 @@ __global__ __launch_bounds__(IVFS_BUCKET_THREADS) void ivfs_bucket_kernel(const 
 // grid (nq, slices): the query's sample entries 0 .. scount[qi] are dealt to the threads of its blocks; an entry finds its
 // cell by binary search over the query's sbase row (no per-cell loop: a probed cell contributes only a few dozen sampled
 // rows, and walking the cells one after the other would serialise two dependent loads per cell).
-// 1024 threads: the 4 M 256-byte table takes the CU's LDS, so the block is also the CU's whole occupancy (256 threads: 0.47 ms
-// per 1200 queries at nprobe 32, four waves per CU waiting on their row reads)
+// 1024 threads: the 4 M 256-byte table takes the CU's LDS, so the block is also the CU's whole occupancy.
+// Round 4: the query's plan (sbase, first row of every probed cell) is staged in LDS beside the table — the binary search
+// was log2(nprobe) DEPENDENT global loads per entry, most of a block's 12 us —, table and codes move in 16-byte pieces, two
+// entries per thread are in flight, and a query gets one slice (one staging of its 4 M 256 bytes) unless the grid would
+// not fill the chip.
 #define IVF_SAMPLE_THREADS 1024
+#define IVF_SAMPLE_PLAN_MAX 2048     // probes whose plan fits in LDS beside a 96 KiB table
 template <int M>
 __global__ __launch_bounds__(IVF_SAMPLE_THREADS) void ivf_sample_scan_kernel(const uint8_t* __restrict__ codes,
                                                               const int64_t* __restrict__ list_off,
@@ -2991,30 +3129,49 @@ __global__ __launch_bounds__(IVF_SAMPLE_THREADS) void ivf_sample_scan_kernel(con
                                                               float* __restrict__ sample) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tab = reinterpret_cast<float*>(smem);   // [M][256]
+    int64_t* s_lo = reinterpret_cast<int64_t*>(smem + (size_t)M * RC_K * sizeof(float));   // [nprobe] first row of the cell
+    int* s_sb = reinterpret_cast<int*>(s_lo + nprobe);                                      // [nprobe]
     const int qi = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < M * RC_K; i += IVF_SAMPLE_THREADS) tab[i] = lut[(size_t)qi * M * RC_K + i];
-    __syncthreads();
     const int n = scount[qi];
     const int* sb = sbase + (size_t)qi * nprobe;
     const int* pr = probes + (size_t)qi * nprobe;
-    for (int i = blockIdx.y * IVF_SAMPLE_THREADS + tid; i < n; i += gridDim.y * IVF_SAMPLE_THREADS) {
-        int lo = 0, hi = nprobe - 1;                              // last probe p with sbase[p] <= i
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (sb[mid] <= i) lo = mid; else hi = mid - 1;
-        }
-        const int off = i - sb[lo];
-        // the sample of a cell: runs of 16 consecutive rows (coalesced reads), one run every 16 * ss rows
-        const int64_t row = list_off[pr[lo]] + (int64_t)(off >> 4) * 16 * ss + (off & 15);
-        const unsigned* cp = reinterpret_cast<const unsigned*>(codes + row * M);
-        float s = 0.f;
+    const bool plan_lds = nprobe <= IVF_SAMPLE_PLAN_MAX;     // block-uniform
+    if (plan_lds)
+        for (int p = tid; p < nprobe; p += IVF_SAMPLE_THREADS) { s_sb[p] = sb[p]; s_lo[p] = list_off[pr[p]]; }
+    {
+        const float4* l4 = reinterpret_cast<const float4*>(lut + (size_t)qi * M * RC_K);
+        float4* t4 = reinterpret_cast<float4*>(tab);
+        for (int i = tid; i < M * RC_K / 4; i += IVF_SAMPLE_THREADS) t4[i] = l4[i];
+    }
+    __syncthreads();
+    const int step = gridDim.y * IVF_SAMPLE_THREADS;
+    for (int i = blockIdx.y * IVF_SAMPLE_THREADS + tid; i < n; i += 2 * step) {
+        int64_t row[2];
 #pragma unroll
-        for (int j = 0; j < M / 4; ++j) {
-            const unsigned w = cp[j];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) s = s + tab[(4 * j + b) * RC_K + ((w >> (8 * b)) & 0xFFu)];
+        for (int h = 0; h < 2; ++h) {
+            const int ih = (i + h * step < n) ? i + h * step : i;
+            int lo = 0, hi = nprobe - 1;                              // last probe p with sbase[p] <= ih
+            if (plan_lds) {
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_sb[mid] <= ih) lo = mid; else hi = mid - 1;
+                }
+                const int off = ih - s_sb[lo];
+                // the sample of a cell: runs of 16 consecutive rows (coalesced reads), one run every 16 * ss rows
+                row[h] = s_lo[lo] + (int64_t)(off >> 4) * 16 * ss + (off & 15);
+            } else {
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (sb[mid] <= ih) lo = mid; else hi = mid - 1;
+                }
+                const int off = ih - sb[lo];
+                row[h] = list_off[pr[lo]] + (int64_t)(off >> 4) * 16 * ss + (off & 15);
+            }
         }
-        sample[(size_t)qi * sstride + i] = s;
+        const float s0 = adc_rescore_row<M>(codes + row[0] * M, tab);
+        const float s1 = adc_rescore_row<M>(codes + row[1] * M, tab);
+        sample[(size_t)qi * sstride + i] = s0;
+        if (i + step < n) sample[(size_t)qi * sstride + i + step] = s1;
     }
 }
 
@@ -3114,10 +3271,13 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     unsigned long long* cand = (unsigned long long*)(w + L.cand);
     {
         auto kern = ivf_sample_scan_kernel<M>;
-        const size_t lds = (size_t)M * RC_K * sizeof(float);
-        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // every block stages the query's 4 M 256-byte fp32 table: as few slices per query as keep ~2048 sampled rows each
+        const size_t lds = (size_t)M * RC_K * sizeof(float) + (nprobe <= IVF_SAMPLE_PLAN_MAX ? (size_t)nprobe * 12 : 0);
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)((size_t)M * RC_K * sizeof(float) + IVF_SAMPLE_PLAN_MAX * 12)));
+        // every block stages the query's 4 M 256-byte fp32 table: one slice per query unless the grid would not fill the chip
         int64_t slices = (sstride + 2047) / 2048;
+        const int64_t fill = (2 * (int64_t)(h->num_cus > 0 ? h->num_cus : 256) + nq - 1) / nq;
+        if (slices > fill) slices = fill;
         if (slices > 16) slices = 16;
         hipLaunchKernelGGL(kern, dim3((unsigned)nq, (unsigned)(slices < 1 ? 1 : slices)), dim3(IVF_SAMPLE_THREADS), lds, s, codes, list_off, lut,
                            probes, sbase, scount, nprobe, sstride, ss, sample);
@@ -3174,13 +3334,23 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
         auto krescore = adc_rescore_kernel<M>;
         const size_t rl = (size_t)M * RC_K * sizeof(float);
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)krescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-        hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(ADC_RESCORE_THREADS), rl, s, codes, lut, (const float*)thr, (const unsigned*)idcnt,
+        hipLaunchKernelGGL(krescore, dim3((unsigned)nq), dim3(adc_rescore_threads(M)), rl, s, codes, lut, (const float*)thr, (const unsigned*)idcnt,
                            (const unsigned*)ids, cnt, cand, status, rowmap, qstatus);
         RC_LAUNCH_CHECK(h);
     }
     hipLaunchKernelGGL(ivf_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const unsigned*)cnt, rows, nq, k, status,
                        qstatus);
     RC_LAUNCH_CHECK(h);
+    if (rc_env_set("RC_IVF_DEBUG")) {                          // development: list lengths of this search (synchronises)
+        std::vector<unsigned> a(nq), b(nq);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(a.data(), idcnt, nq * sizeof(unsigned), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(b.data(), cnt, nq * sizeof(unsigned), hipMemcpyDeviceToHost);
+        double sa = 0, sb = 0; unsigned ma = 0, mb = 0;
+        for (int i = 0; i < nq; ++i) { sa += a[i]; sb += b[i]; ma = a[i] > ma ? a[i] : ma; mb = b[i] > mb ? b[i] : mb; }
+        fprintf(stderr, "[ivf debug] nq %d nprobe %d ss %d sstride %lld: screened ids mean %.0f max %u, candidates mean %.0f max %u\n",
+                nq, nprobe, ss, (long long)sstride, sa / nq, ma, sb / nq, mb);
+    }
     // N = 0: fewer than k rows is legitimate (small cells); too FEW CANDIDATES is what ivf_check_kernel reports
     return rc_adc_launch_select(h, cand, cnt, nq, 0, k, 0, scores, out_ids, status, s, qstatus);
 }
