@@ -1498,27 +1498,30 @@ __global__ __launch_bounds__(256) void adc_q16_image_kernel(const uint8_t* __res
     }
 }
 
-// byte tables [group of 16 queries][phase][code][slot][16 queries], biased by -128 (the MFMA is signed): thread = code
-__global__ __launch_bounds__(64) void adc_qlut16_write_kernel(const float* __restrict__ lut, const float* __restrict__ qstat,
-                                                              int M, int nq, uint8_t* __restrict__ qlut) {
-    const int G = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x, phase = blockIdx.z;
+// byte tables [group of 16 queries][phase][code][slot][16 queries], biased by -128 (the MFMA is signed): thread = (code,
+// slot) — 64 x 16 threads per block, one 16-byte store each (round 3: thread = code walked the 16 slots, 900 waves in all
+// for 14.7 M entries: 91 us per 1200 queries at M = 48)
+__global__ __launch_bounds__(1024) void adc_qlut16_write_kernel(const float* __restrict__ lut, const float* __restrict__ qstat,
+                                                                int M, int nq, uint8_t* __restrict__ qlut) {
+    const int G = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x, phase = blockIdx.z, sl = threadIdx.y;
     const int NPH = M / 16;
     const int nv = (nq - 16 * G) < 16 ? (nq - 16 * G) : 16;
     uint4* row = reinterpret_cast<uint4*>(qlut + (((size_t)G * NPH + phase) * RC_K + c) * 256);
-    for (int sl = 0; sl < 16; ++sl) {
-        const int m = 16 * phase + sl;
-        unsigned w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};    // absent queries: byte 0 -> -128
+    const int m = 16 * phase + sl;
+    unsigned w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};    // absent queries: byte 0 -> -128
+    float v[16];
 #pragma unroll
-        for (int qq = 0; qq < 16; ++qq) {
-            if (qq < nv) {
-                const int q = 16 * G + qq;
-                const unsigned l = adc_quant8(lut[((size_t)q * M + m) * RC_K + c], qstat[(size_t)q * ADC_QSTAT_STRIDE + m],
-                                              qstat[(size_t)q * ADC_QSTAT_STRIDE + ADC_QSTAT_STRIDE - 1]);
-                w[qq >> 2] = (w[qq >> 2] & ~(0xFFu << (8 * (qq & 3)))) | ((l ^ 0x80u) << (8 * (qq & 3)));
-            }
+    for (int qq = 0; qq < 16; ++qq) v[qq] = (qq < nv) ? lut[((size_t)(16 * G + qq) * M + m) * RC_K + c] : 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) {
+        if (qq < nv) {
+            const int q = 16 * G + qq;
+            const unsigned l = adc_quant8(v[qq], qstat[(size_t)q * ADC_QSTAT_STRIDE + m],
+                                          qstat[(size_t)q * ADC_QSTAT_STRIDE + ADC_QSTAT_STRIDE - 1]);
+            w[qq >> 2] = (w[qq >> 2] & ~(0xFFu << (8 * (qq & 3)))) | ((l ^ 0x80u) << (8 * (qq & 3)));
         }
-        row[sl] = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    row[sl] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 typedef unsigned adc_u32x4v __attribute__((ext_vector_type(4)));
@@ -1830,8 +1833,11 @@ __global__ __launch_bounds__(1024) void adc_rescore_kernel(const uint8_t* __rest
         // next pair of ids (dependent chain: id -> codes), requested before this pair is scored
         n0 = (ia + 2 * nthr < cnt) ? qids[ia + 2 * nthr] : 0u;
         n1 = (ib + 2 * nthr < cnt) ? qids[ib + 2 * nthr] : 0u;
-        const float sa = adc_rescore_row<M>(codes + (size_t)(la ? na : 0u) * M, tab);
-        const float sb = adc_rescore_row<M>(codes + (size_t)(lb ? nb : 0u) * M, tab);
+        // a wave whose 64 slots are all past the end of the list does nothing (the last iteration of a 2100-row list has
+        // 96 live slots of 2048: without the test the kernel did 1.9 x the lookups the list needs)
+        float sa = 0.f, sb = 0.f;
+        if (__ballot(la)) sa = adc_rescore_row<M>(codes + (size_t)(la ? na : 0u) * M, tab);
+        if (__ballot(lb)) sb = adc_rescore_row<M>(codes + (size_t)(lb ? nb : 0u) * M, tab);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const bool live = h ? lb : la;
@@ -2138,7 +2144,7 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             const int groups = (nq + 15) / 16;
             hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, b.lut, b.thr, M, b.qstat, b.tint);
             RC_LAUNCH_CHECK(h);
-            hipLaunchKernelGGL(adc_qlut16_write_kernel, dim3((unsigned)groups, RC_K / 64, M / 16), dim3(64), 0, s, b.lut,
+            hipLaunchKernelGGL(adc_qlut16_write_kernel, dim3((unsigned)groups, RC_K / 64, M / 16), dim3(64, 16), 0, s, b.lut,
                                (const float*)b.qstat, M, nq, b.qlut);
             RC_LAUNCH_CHECK(h);
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
@@ -2612,6 +2618,97 @@ __global__ __launch_bounds__(RC_K) void ivfs_qbyte_write_kernel(const float* __r
         *reinterpret_cast<uint4*>(qbyte + (size_t)qi * M * RC_K + (size_t)RC_K * 32 * p + (size_t)c * PM + j0) =
             make_uint4(w[0], w[1], w[2], w[3]);
     }
+}
+
+// Round 4: adc_qstats_kernel + ivfs_qbyte_write_kernel in one pass over the query's LUT.  Block (256 codes, M / 16): thread
+// (c, b) keeps lut[16 b + j][c], j < 16, in registers; lo / hi per sub-quantiser by wave reductions + LDS, delta = the
+// largest range / 255 (the arithmetic of adc_qstats_kernel), then the bytes are quantised from the registers.  The integer
+// threshold needs tau and is computed where tau is (ivf_rank_select_kernel).  One read of the LUT instead of two, one launch
+// instead of two, 6 x the threads (26 + 42 -> ~25 us per 1200 queries at M = 96).
+__global__ __launch_bounds__(1024) void ivfs_qprep_kernel(const float* __restrict__ lut, int M, float* __restrict__ qstat,
+                                                          uint8_t* __restrict__ qbyte) {
+    __shared__ float s_lo[16][ADC_QSTAT_STRIDE], s_hi[16][ADC_QSTAT_STRIDE];
+    __shared__ float s_mlo[ADC_QSTAT_STRIDE];
+    __shared__ float s_delta;
+    // block (256 codes, ceil(M / 32)): thread (c, y) holds the 16-blocks b = 2 y and 2 y + 1 (= table phase y of the screen)
+    const int qi = blockIdx.x, c = threadIdx.x, y = threadIdx.y, lane = c & 63, wc = c >> 6;
+    const float* lq = lut + (size_t)qi * M * RC_K;
+    const int nb = (M / 16 - 2 * y) < 2 ? (M / 16 - 2 * y) : 2;       // 16-blocks of this thread row: 1 or 2
+    float v[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[h][j] = (h < nb) ? lq[(32 * y + 16 * h + j) * RC_K + c] : 0.f;
+    // min / max over the 256 codes: DPP rotations inside each row of 16 lanes (plain VALU; a butterfly of __shfl_xor is 12
+    // LDS-crossbar operations per value), then 16 partials per sub-quantiser through LDS
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h < nb) {                                                  // uniform over the thread row
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float lo = v[h][j], hi = v[h][j];
+                lo = fminf(lo, __int_as_float(rc_dpp_row_ror<8>(__float_as_int(lo))));
+                hi = fmaxf(hi, __int_as_float(rc_dpp_row_ror<8>(__float_as_int(hi))));
+                lo = fminf(lo, __int_as_float(rc_dpp_row_ror<4>(__float_as_int(lo))));
+                hi = fmaxf(hi, __int_as_float(rc_dpp_row_ror<4>(__float_as_int(hi))));
+                lo = fminf(lo, __int_as_float(rc_dpp_row_ror<2>(__float_as_int(lo))));
+                hi = fmaxf(hi, __int_as_float(rc_dpp_row_ror<2>(__float_as_int(hi))));
+                lo = fminf(lo, __int_as_float(rc_dpp_row_ror<1>(__float_as_int(lo))));
+                hi = fmaxf(hi, __int_as_float(rc_dpp_row_ror<1>(__float_as_int(hi))));
+                if ((lane & 15) == 0) {
+                    s_lo[4 * wc + (lane >> 4)][32 * y + 16 * h + j] = lo;
+                    s_hi[4 * wc + (lane >> 4)][32 * y + 16 * h + j] = hi;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int t = y * RC_K + c;
+    if (t < M) {
+        float lo = s_lo[0][t], hi = s_hi[0][t];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { lo = fminf(lo, s_lo[r][t]); hi = fmaxf(hi, s_hi[r][t]); }
+        s_mlo[t] = lo;
+        qstat[(size_t)qi * ADC_QSTAT_STRIDE + t] = lo;
+        s_lo[0][t] = hi - lo;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float maxrange = 0.f;
+        double A = 0.0;
+        for (int m = 0; m < M; ++m) {
+            maxrange = fmaxf(maxrange, s_lo[0][m]);
+            A += (double)s_mlo[m];
+        }
+        float delta = maxrange / 255.0f;
+        if (!(delta > 0.f)) delta = 1.0f;
+        qstat[(size_t)qi * ADC_QSTAT_STRIDE + ADC_QSTAT_STRIDE - 1] = delta;
+        *reinterpret_cast<double*>(qstat + (size_t)qi * ADC_QSTAT_STRIDE + ADC_QSTAT_STRIDE - 4) = A;   // sum of lo, m ascending
+        s_delta = delta;
+    }
+    __syncthreads();
+    const float delta = s_delta;
+    const int PM = ivfs_pm(M, y);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h < nb) {
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                w[j >> 2] |= (adc_quant8(v[h][j], s_mlo[32 * y + 16 * h + j], delta) ^ 0x80u) << (8 * (j & 3));
+            *reinterpret_cast<uint4*>(qbyte + (size_t)qi * M * RC_K + (size_t)RC_K * 32 * y + (size_t)c * PM + 16 * h) =
+                make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
+// the integer threshold of a query from tau and the statistics of its tables (the arithmetic of adc_qstats_kernel)
+__device__ __forceinline__ int adc_tint_from(float t, const float* __restrict__ st, int M) {
+    if (t == -INFINITY) return INT_MIN;
+    const double A = *reinterpret_cast<const double*>(st + ADC_QSTAT_STRIDE - 4);     // written by ivfs_qprep_kernel
+    const double delta = (double)st[ADC_QSTAT_STRIDE - 1];
+    const double v = ceil(((double)t - A) / delta - 0.5 * (double)M) - 2.0;   // entries rounded to NEAREST: |error| <= 1/2 each
+    return v < -2.0e9 ? INT_MIN : (v > 2.0e9 ? INT_MAX : (int)v);
 }
 
 struct ivfs_task {
@@ -3179,14 +3276,18 @@ __global__ __launch_bounds__(IVF_SAMPLE_THREADS) void ivf_sample_scan_kernel(con
 // 8 bits per pass over global memory (the sample is 1/SS of the probed rows).
 __global__ __launch_bounds__(1024) void ivf_rank_select_kernel(const float* __restrict__ sample, const int* __restrict__ scount,
                                                                const int* __restrict__ rank, int64_t sstride,
-                                                               float* __restrict__ thr) {
+                                                               float* __restrict__ thr, const float* __restrict__ qstat = nullptr,
+                                                               int M = 0, int* __restrict__ tint = nullptr) {
     __shared__ unsigned hist[256];
     __shared__ unsigned sel_prefix, sel_rank;
     __shared__ unsigned s_scan[4];
     const int qi = blockIdx.x, tid = threadIdx.x;
     const int n = scount[qi], k = rank[qi];
     if (k <= 0 || k > n) {
-        if (tid == 0) thr[qi] = -INFINITY;
+        if (tid == 0) {
+            thr[qi] = -INFINITY;
+            if (tint) tint[qi] = INT_MIN;
+        }
         return;
     }
     const float* row = sample + (size_t)qi * sstride;
@@ -3205,7 +3306,11 @@ __global__ __launch_bounds__(1024) void ivf_rank_select_kernel(const float* __re
         __syncthreads();
         adc_pick_bin(hist, sel_rank, prefix, shift, s_scan, &sel_prefix, &sel_rank);
     }
-    if (tid == 0) thr[qi] = adc_unorder_key(sel_prefix);
+    if (tid == 0) {
+        const float t = adc_unorder_key(sel_prefix);
+        thr[qi] = t;
+        if (tint) tint[qi] = adc_tint_from(t, qstat + (size_t)qi * ADC_QSTAT_STRIDE, M);
+    }
 }
 
 __global__ void ivf_check_kernel(const unsigned* __restrict__ cand_count, const int* __restrict__ rows, int nq, int k,
@@ -3283,15 +3388,21 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
                            probes, sbase, scount, nprobe, sstride, ss, sample);
         RC_LAUNCH_CHECK(h);
     }
-    hipLaunchKernelGGL(ivf_rank_select_kernel, dim3((unsigned)nq), dim3(1024), 0, s, (const float*)sample, scount, rank, sstride, thr);
-    RC_LAUNCH_CHECK(h);
-    hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)thr, M, qstat, tint);
-    RC_LAUNCH_CHECK(h);
-    if (ivf_pipe())
-        hipLaunchKernelGGL(ivfs_qbyte_write_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)qstat, M, qbyte);
-    else
+    if (ivf_pipe()) {
+        // tables first (they need no threshold), then tau and the integer threshold in one kernel
+        hipLaunchKernelGGL(ivfs_qprep_kernel, dim3((unsigned)nq), dim3(RC_K, (M + 31) / 32), 0, s, lut, M, qstat, qbyte);
+        RC_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL(ivf_rank_select_kernel, dim3((unsigned)nq), dim3(1024), 0, s, (const float*)sample, scount, rank, sstride, thr,
+                           (const float*)qstat, M, tint);
+        RC_LAUNCH_CHECK(h);
+    } else {
+        hipLaunchKernelGGL(ivf_rank_select_kernel, dim3((unsigned)nq), dim3(1024), 0, s, (const float*)sample, scount, rank, sstride, thr);
+        RC_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL(adc_qstats_kernel, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)thr, M, qstat, tint);
+        RC_LAUNCH_CHECK(h);
         hipLaunchKernelGGL(adc_qbyte_write_kernel<PM>, dim3((unsigned)nq), dim3(RC_K), 0, s, lut, (const float*)qstat, M, qbyte);
-    RC_LAUNCH_CHECK(h);
+        RC_LAUNCH_CHECK(h);
+    }
     RC_HIP_CHECK(h, hipMemsetAsync(w + L.idcnt, 0, L.counters_end - L.idcnt, s));      // idcnt, cnt, stream_cnt
     if (ivf_pipe()) {
         static const int lw = [] { const char* e = getenv("RC_IVF_LW"); return (e && e[0] == '0') ? 0 : 4; }();   // 0: no loader waves
