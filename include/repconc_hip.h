@@ -16,8 +16,10 @@
  *   - return value: RC_OK (0) or a negative RC_E* code, never throws; rc_error_string() decodes;
  *   - no global mutable state outside the handle; handles are independent and re-entrant;
  *   - K (centroids per sub-quantiser) must be 256 (evaluate_repconc.py:80, run_warmup.py:90);
- *     dsub = D/M must be one of 8,12,16,24,32,48,64,96 (the sizes for which the fp32
- *     summation order of the torch-CPU oracle is pinned);
+ *     M may be any divisor of D (modeling_repconc.py:41): dsub = D/M in {8,12,16,24,32,48,64,96} (the recipes' widths)
+ *     runs on specialised kernels, any other width on run-time-width kernels with the same arithmetic — the fp32
+ *     summation order of the torch-CPU oracle, SURVEY.md §8 a-1, pinned for all 18 divisors of 768;
+ *     the ADC / IVF search entries need M in {8,12,16,24,32,48,64,96};
  *   - fp32 arithmetic follows the reference bit for bit (no FMA contraction, IEEE division);
  *     the fp64 Sinkhorn stage is evaluated with potentials and is specified
  *     on its OUTPUT, the codes.

@@ -37,21 +37,48 @@ int orc_num_threads(void) {
 #endif
 }
 
-/* torch-CPU `sum(-1)` order over a contiguous fp32 row of length dsub. */
+/* torch-CPU `sum(-1)` order over a contiguous fp32 row of length dsub (aten/native/cpu/SumKernel.cpp; SURVEY.md §8 a-1;
+   the numpy twin in pq_oracle.py spells the rule out).  dsub >= 8: 8-wide vectors, four ILP accumulators fed round by round
+   with torch's cascade (after every 16 rounds the running sums move one level up; levels merged lowest first), left-over
+   vectors to accumulator 0, 0 += 1, 2, 3, then (tail scalars from 0) + lane 0 .. lane 7.  dsub < 8: the scalar twin. */
 static float rowsum_torch_order(const float* sq, int dsub) {
+    if (dsub < 8) {
+        float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int full = dsub / 4;
+        if (full)
+            for (int j = 0; j < 4; ++j) p[j] = p[j] + sq[j];
+        for (int j = 4 * full; j < dsub; ++j) p[0] = p[0] + sq[j];
+        float r = p[0] + p[1];
+        r = r + p[2];
+        return r + p[3];
+    }
     const int nv = dsub / 8, tail = dsub % 8, full = nv / 4;
-    float acc[4][8];
+    float acc[4][4][8];                                  /* [level][ilp][lane] */
     memset(acc, 0, sizeof(acc));
-    for (int i = 0; i < full; ++i)
+    int i = 0;
+    while (i + 16 <= full) {
+        for (int t = 0; t < 16; ++t, ++i)
+            for (int j = 0; j < 4; ++j)
+                for (int l = 0; l < 8; ++l) acc[0][j][l] = acc[0][j][l] + sq[8 * (4 * i + j) + l];
+        for (int lv = 1; lv < 4; ++lv) {
+            for (int j = 0; j < 4; ++j)
+                for (int l = 0; l < 8; ++l) { acc[lv][j][l] = acc[lv][j][l] + acc[lv - 1][j][l]; acc[lv - 1][j][l] = 0.0f; }
+            if (i & (15 << (4 * lv))) break;
+        }
+    }
+    for (; i < full; ++i)
         for (int j = 0; j < 4; ++j)
-            for (int l = 0; l < 8; ++l) acc[j][l] = acc[j][l] + sq[8 * (4 * i + j) + l];
+            for (int l = 0; l < 8; ++l) acc[0][j][l] = acc[0][j][l] + sq[8 * (4 * i + j) + l];
+    for (int lv = 1; lv < 4; ++lv)
+        for (int j = 0; j < 4; ++j)
+            for (int l = 0; l < 8; ++l) acc[0][j][l] = acc[0][j][l] + acc[lv][j][l];
     for (int v = 4 * full; v < nv; ++v)
-        for (int l = 0; l < 8; ++l) acc[0][l] = acc[0][l] + sq[8 * v + l];
+        for (int l = 0; l < 8; ++l) acc[0][0][l] = acc[0][0][l] + sq[8 * v + l];
     float a[8];
     for (int l = 0; l < 8; ++l) {
-        float t = acc[0][l] + acc[1][l];
-        t = t + acc[2][l];
-        a[l] = t + acc[3][l];
+        float t = acc[0][0][l] + acc[0][1][l];
+        t = t + acc[0][2][l];
+        a[l] = t + acc[0][3][l];
     }
     float r = 0.0f;
     for (int j = 0; j < tail; ++j) r = r + sq[nv * 8 + j];
@@ -65,7 +92,7 @@ void orc_dist_table(const float* x, int64_t ldx, const float* C, int64_t B, int 
     for (int m = 0; m < M; ++m)
         for (int64_t b = 0; b < B; ++b) {
             const float* xr = x + b * ldx + (int64_t)m * dsub;
-            float sq[512];
+            float sq[1024];
             for (int k = 0; k < K; ++k) {
                 const float* c = C + ((int64_t)m * K + k) * dsub;
                 for (int j = 0; j < dsub; ++j) {

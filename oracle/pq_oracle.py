@@ -25,25 +25,66 @@ F64 = np.float64
 
 
 # --------------------------------------------------------------------------- a-1
+def _multi_row_sum(rows):
+    """torch's cascade (aten/native/cpu/SumKernel.cpp `multi_row_sum`, 4 levels, level step 16): `rows` is the list of
+    per-round operands (each an array holding the 4 ILP partials side by side); after every 16 rounds the running sum moves
+    one level up, the levels are merged lowest first at the end.  Up to 16 rounds this is a plain running sum from 0."""
+    num_levels, power = 4, 4
+    step, mask = 1 << power, (1 << power) - 1
+    acc = [np.zeros_like(rows[0]) if rows else None for _ in range(num_levels)]
+    if not rows:
+        return None
+    size, i = len(rows), 0
+    while i + step <= size:
+        for _ in range(step):
+            acc[0] = acc[0] + rows[i]
+            i += 1
+        for j in range(1, num_levels):
+            acc[j] = acc[j] + acc[j - 1]
+            acc[j - 1] = np.zeros_like(acc[j - 1])
+            if i & (mask << (j * power)):
+                break
+    while i < size:
+        acc[0] = acc[0] + rows[i]
+        i += 1
+    for j in range(1, num_levels):
+        acc[0] = acc[0] + acc[j]
+    return acc[0]
+
+
 def _rowsum_torch_cpu_order(sq: np.ndarray) -> np.ndarray:
-    """Sum over the last axis in the order torch-CPU's vectorised `sum(-1)` uses for a
-    contiguous fp32 row of length dsub (bit-verified for dsub in {8,12,16,24,32,48,64,96};
-    SURVEY.md §8 a-1):  split the row into 8-wide vectors v0,v1,…; four accumulators
-    acc_j = sum_i v_{4i+j}; left-over vectors go to acc_0 in order; acc_0 += acc_1, acc_2,
-    acc_3; result = ((tail scalars summed from 0) + lane0) + lane1 … + lane7."""
+    """Sum over the last axis in the order torch-CPU's `sum(-1)` uses for a contiguous fp32 row of length dsub
+    (aten/native/cpu/SumKernel.cpp; bit-verified against torch 2.10 for every divisor of 768).
+    dsub >= 8 (`vectorized_inner_sum`): split the row into 8-wide vectors v0,v1,…; four ILP accumulators acc_j = sum_i
+    v_{4i+j} (a cascade: every 16 rounds — 512 floats — the running sums move to a second level, so dsub = 768 is NOT a
+    plain running sum); left-over vectors go to acc_0 in order; acc_0 += acc_1, acc_2, acc_3; result = ((tail scalars
+    summed from 0) + lane0) + lane1 … + lane7.
+    dsub < 8 (`scalar_inner_sum`): the same with scalars for vectors: p_j = x_j (j < 4) when dsub >= 4, the remaining
+    scalars are added to p_0 in order, then p_0 += p_1, p_2, p_3."""
     dsub = sq.shape[-1]
-    nv, tail = dsub // 8, dsub % 8
     lead = sq.shape[:-1]
-    acc = [np.zeros(lead + (8,), F32) for _ in range(4)]
+    if dsub < 8:
+        p = [np.zeros(lead, F32) for _ in range(4)]
+        full = dsub // 4
+        if full:
+            for j in range(4):
+                p[j] = p[j] + sq[..., j]
+        for j in range(4 * full, dsub):
+            p[0] = p[0] + sq[..., j]
+        r = p[0] + p[1]
+        r = r + p[2]
+        return r + p[3]
+    nv, tail = dsub // 8, dsub % 8
     full = nv // 4
-    for i in range(full):
-        for j in range(4):
-            acc[j] = acc[j] + sq[..., 8 * (4 * i + j): 8 * (4 * i + j) + 8]
+    rounds = [sq[..., 32 * i: 32 * i + 32] for i in range(full)]          # [.., 4 x 8]: the four ILP partials of a round
+    acc = _multi_row_sum(rounds)
+    acc = np.zeros(lead + (32,), F32) if acc is None else acc
+    a0 = acc[..., 0:8]
     for v in range(4 * full, nv):
-        acc[0] = acc[0] + sq[..., 8 * v: 8 * v + 8]
-    a = acc[0] + acc[1]
-    a = a + acc[2]
-    a = a + acc[3]
+        a0 = a0 + sq[..., 8 * v: 8 * v + 8]
+    a = a0 + acc[..., 8:16]
+    a = a + acc[..., 16:24]
+    a = a + acc[..., 24:32]
     r = np.zeros(lead, F32)
     for j in range(tail):
         r = r + sq[..., nv * 8 + j]

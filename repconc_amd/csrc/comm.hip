@@ -666,7 +666,7 @@ extern "C" int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t
     if (!h || !(h->comm[0] || h->ipc.on) || !C || !flags || B < 0 || (B > 0 && !x) || M <= 0 || iters < 1 || !(eps > 0.0) ||
         (B > 0 && !codes_u8 && !codes_i64))
         return RC_EINVAL;
-    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
+    if (K != RC_K || D % M != 0) return RC_ESHAPE;             // any width: rc_pq_dist_table picks the kernel
     return rc_solve_chains(h, x, ldx, C, B, D, M, eps, iters, h->comm_world, codes_u8, codes_i64, flags, ws, ws_bytes,
                            (hipStream_t)stream);
 }

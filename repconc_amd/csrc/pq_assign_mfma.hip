@@ -534,7 +534,10 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
                                          rc_stream_t stream) {
     rc_device_guard device_guard_(h);
     if (!h || !x || !C || B < 0 || M <= 0 || D <= 0 || ldx < D || (!codes_u8 && !codes_i64)) return RC_EINVAL;
-    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M) || B * (int64_t)M > 0xFFFFFFFFll) return RC_ESHAPE;
+    if (K != RC_K || D % M != 0) return RC_ESHAPE;
+    if (!rc_dsub_supported(D / M))                         // widths without a matrix-core screen: the exact kernel at run-time width
+        return rc_pq_assign_nearest(h, x, ldx, C, B, D, M, K, codes_u8, codes_i64, stream);
+    if (B * (int64_t)M > 0xFFFFFFFFll) return RC_ESHAPE;
     if (((uintptr_t)x & 15) || (ldx % 4) != 0) return RC_EINVAL;
     if (B == 0) return RC_OK;
     if (!ws || ws_bytes < rc_pq_assign_nearest_fast_ws_bytes(B, M)) return RC_EWORKSPACE;

@@ -254,6 +254,178 @@ __global__ __launch_bounds__(256) void assign_nearest_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------ any width
+// The reference takes every divisor of hidden_size as MCQ_M (modeling_repconc.py:41).  The kernels above are specialised
+// (registers, packed arithmetic) for the widths the recipes use; these two cover every other width with the SAME fp32
+// arithmetic at run-time width: torch-CPU's `sum(-1)` order of aten/native/cpu/SumKernel.cpp —
+//   dsub >= 8: 8-wide vectors, four ILP accumulators fed round by round, and torch's CASCADE: after every 16 rounds
+//              (512 floats) the running sums move up one level and restart from 0, levels merged lowest first at the end
+//              (dsub = 768: rounds 16..23 + rounds 0..15, not a plain running sum); left-over vectors to accumulator 0;
+//              0 += 1, 2, 3; (tail scalars from 0) + lane 0 .. lane 7;
+//   dsub <  8: the scalar twin: p_j = x_j (j < 4) when dsub >= 4, the remaining scalars to p_0 in order, p_0 += p_1, p_2, p_3
+// — restated in oracle/pq_oracle.{py,c} and checked there against torch for all 18 divisors of 768; fixtures M = 1, 6, 128.
+// Two cascade levels cover 255 rounds: dsub < 8192.
+#define RC_DSUB_RT_MAX 8191
+__device__ __forceinline__ float sqdist_exact_rt(const float* __restrict__ x, const float* __restrict__ c, int dsub) {
+    if (dsub < 8) {
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        const int full = dsub >> 2;
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float t = x[j] - c[j]; p[j] = p[j] + t * t; }
+        }
+        for (int j = 4 * full; j < dsub; ++j) { const float t = x[j] - c[j]; p[0] = p[0] + t * t; }
+        float r = p[0] + p[1];
+        r = r + p[2];
+        return r + p[3];
+    }
+    const int nv = dsub >> 3, tail = dsub & 7, full = nv >> 2;
+    float a0[4][8], a1[4][8];                             // cascade levels 0 and 1: [ilp][lane]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) { a0[j][l] = 0.f; a1[j][l] = 0.f; }
+    int i = 0;
+    while (i + 16 <= full) {
+        for (int t16 = 0; t16 < 16; ++t16, ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const int e = 32 * i + 8 * j + l;
+                    const float t = x[e] - c[e];
+                    a0[j][l] = a0[j][l] + t * t;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) { a1[j][l] = a1[j][l] + a0[j][l]; a0[j][l] = 0.f; }
+    }
+    for (; i < full; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const int e = 32 * i + 8 * j + l;
+                const float t = x[e] - c[e];
+                a0[j][l] = a0[j][l] + t * t;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) a0[j][l] = a0[j][l] + a1[j][l];       // (levels 2, 3 are +0)
+    for (int v = 4 * full; v < nv; ++v) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) { const float t = x[8 * v + l] - c[8 * v + l]; a0[0][l] = a0[0][l] + t * t; }
+    }
+    float r = 0.f;
+    for (int j = 0; j < tail; ++j) { const float t = x[8 * nv + j] - c[8 * nv + j]; r = r + t * t; }
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        float t = a0[0][l] + a0[1][l];
+        t = t + a0[2][l];
+        t = t + a0[3][l];
+        r = r + t;
+    }
+    return r;
+}
+
+// grid (row strips, M) as dist_table_kernel (same mm_part layout); the strip's slices are staged in LDS RT_ROWS rows at a time
+#define DIST_RT_LDS_FLOATS 8192
+__global__ __launch_bounds__(RC_K) void dist_table_rt_kernel(const float* __restrict__ x, int64_t ldx,
+                                                             const float* __restrict__ C, int64_t B, int dsub,
+                                                             int rows_per_block, float* __restrict__ d,
+                                                             float* __restrict__ mm_part) {
+    __shared__ float xs[DIST_RT_LDS_FLOATS];
+    const int m = blockIdx.y, k = threadIdx.x;
+    const float* c = C + ((size_t)m * RC_K + k) * dsub;
+    const int64_t b0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t b1 = (b0 + rows_per_block < B) ? b0 + rows_per_block : B;
+    const int rt = DIST_RT_LDS_FLOATS / dsub;              // >= 1 for dsub <= 8192
+    float mx = -INFINITY, mn = INFINITY;
+    for (int64_t r0 = b0; r0 < b1; r0 += rt) {
+        const int rows = (int)((b1 - r0 < rt) ? b1 - r0 : rt);
+        __syncthreads();
+        for (int i = k; i < rows * dsub; i += RC_K) {
+            const int r = i / dsub, j = i - r * dsub;
+            xs[i] = x[(r0 + r) * ldx + (int64_t)m * dsub + j];
+        }
+        __syncthreads();
+        for (int r = 0; r < rows; ++r) {
+            const float s = sqdist_exact_rt(xs + r * dsub, c, dsub);
+            d[((size_t)m * B + r0 + r) * RC_K + k] = s;
+            mx = fmaxf(mx, s);
+            mn = fminf(mn, s);
+        }
+    }
+    if (mm_part) {
+        __shared__ float smx[RC_K / 64], smn[RC_K / 64];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, o));
+            mn = fminf(mn, __shfl_xor(mn, o));
+        }
+        if ((k & 63) == 0) { smx[k >> 6] = mx; smn[k >> 6] = mn; }
+        __syncthreads();
+        if (k == 0) {
+#pragma unroll
+            for (int w = 1; w < RC_K / 64; ++w) { mx = fmaxf(mx, smx[w]); mn = fminf(mn, smn[w]); }
+            float* o = mm_part + ((size_t)m * gridDim.x + blockIdx.x) * 2;
+            o[0] = mx;
+            o[1] = mn;
+        }
+    }
+}
+
+// Nearest code at any width: grid (row strips, M), thread = centroid k; per row the block reduces (distance, k) to the FIRST
+// minimum exactly as the sequential scan `if (s < best)` from best = +inf does (NaN and +inf never win: code 0).
+#define ASSIGN_RT_ROWS 8
+__global__ __launch_bounds__(RC_K) void assign_nearest_rt_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                 const float* __restrict__ C, int64_t B, int M, int dsub,
+                                                                 uint8_t* __restrict__ codes_u8, int64_t* __restrict__ codes_i64) {
+    __shared__ float xs[DIST_RT_LDS_FLOATS];
+    __shared__ float s_v[RC_K / 64];
+    __shared__ int s_k[RC_K / 64];
+    const int m = blockIdx.y, k = threadIdx.x;
+    const float* c = C + ((size_t)m * RC_K + k) * dsub;
+    const int64_t b0 = (int64_t)blockIdx.x * ASSIGN_RT_ROWS;
+    const int64_t b1 = (b0 + ASSIGN_RT_ROWS < B) ? b0 + ASSIGN_RT_ROWS : B;
+    const int rt = DIST_RT_LDS_FLOATS / dsub;
+    for (int64_t r0 = b0; r0 < b1; r0 += rt) {
+        const int rows = (int)((b1 - r0 < rt) ? b1 - r0 : rt);
+        __syncthreads();
+        for (int i = k; i < rows * dsub; i += RC_K) {
+            const int r = i / dsub, j = i - r * dsub;
+            xs[i] = x[(r0 + r) * ldx + (int64_t)m * dsub + j];
+        }
+        __syncthreads();
+        for (int r = 0; r < rows; ++r) {
+            const float s = sqdist_exact_rt(xs + r * dsub, c, dsub);
+            float bv = (s < INFINITY) ? s : INFINITY;      // NaN / +inf: never chosen
+            int bk = (s < INFINITY) ? k : RC_K;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const int ok = __shfl_xor(bk, o);
+                if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+            }
+            if ((k & 63) == 0) { s_v[k >> 6] = bv; s_k[k >> 6] = bk; }
+            __syncthreads();
+            if (k == 0) {
+#pragma unroll
+                for (int w = 1; w < RC_K / 64; ++w)
+                    if (s_v[w] < bv || (s_v[w] == bv && s_k[w] < bk)) { bv = s_v[w]; bk = s_k[w]; }
+                const int code = bk < RC_K ? bk : 0;
+                if (codes_u8) codes_u8[(r0 + r) * M + m] = (uint8_t)code;
+                if (codes_i64) codes_i64[(r0 + r) * M + m] = (int64_t)code;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 static int dist_rows_per_block(int64_t B) { return B >= 16384 ? DIST_MAX_ROWS : 32; }
 
@@ -269,8 +441,9 @@ extern "C" int rc_pq_dist_table(rc_handle_t h, const float* x, int64_t ldx, cons
                                 rc_stream_t stream) {
     rc_device_guard device_guard_(h);
     if (!h || !x || !C || !d || B < 0 || M <= 0 || D <= 0 || ldx < D) return RC_EINVAL;
-    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
-    if (((uintptr_t)x & 15) || (ldx % 4) != 0) return RC_EINVAL;  // float4 row loads
+    if (K != RC_K || D % M != 0 || D / M > RC_DSUB_RT_MAX) return RC_ESHAPE;
+    const bool special = rc_dsub_supported(D / M);
+    if (special && (((uintptr_t)x & 15) || (ldx % 4) != 0)) return RC_EINVAL;  // float4 row loads
     if (B == 0) return RC_OK;
     if (minmax && (!ws || ws_bytes < rc_pq_dist_table_ws_bytes(B, M))) return RC_EWORKSPACE;
     const int rpb = dist_rows_per_block(B);
@@ -279,7 +452,11 @@ extern "C" int rc_pq_dist_table(rc_handle_t h, const float* x, int64_t ldx, cons
     float* part = minmax ? (float*)ws : nullptr;
     dim3 grid((unsigned)nblk, (unsigned)M);
     rc_prof_mark(h, RC_PROF_DIST_TABLE, s);
-    RC_DISPATCH_DSUB(D / M, hipLaunchKernelGGL(dist_table_kernel<DSUB>, grid, dim3(RC_K), 0, s, x, ldx, C, B, rpb, d, part));
+    if (special) {
+        RC_DISPATCH_DSUB(D / M, hipLaunchKernelGGL(dist_table_kernel<DSUB>, grid, dim3(RC_K), 0, s, x, ldx, C, B, rpb, d, part));
+    } else {                                              // any other width: same arithmetic at run-time width
+        hipLaunchKernelGGL(dist_table_rt_kernel, grid, dim3(RC_K), 0, s, x, ldx, C, B, D / M, rpb, d, part);
+    }
     rc_prof_mark(h, RC_PROF_DIST_TABLE, s);
     RC_LAUNCH_CHECK(h);
     if (minmax) {
@@ -311,7 +488,14 @@ extern "C" int rc_pq_assign_nearest(rc_handle_t h, const float* x, int64_t ldx, 
                                     rc_stream_t stream) {
     rc_device_guard device_guard_(h);
     if (!h || !x || !C || B < 0 || M <= 0 || D <= 0 || ldx < D || (!codes_u8 && !codes_i64)) return RC_EINVAL;
-    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
+    if (K != RC_K || D % M != 0 || D / M > RC_DSUB_RT_MAX) return RC_ESHAPE;
+    if (!rc_dsub_supported(D / M)) {                       // any other width (the reference takes every divisor)
+        if (B == 0) return RC_OK;
+        hipLaunchKernelGGL(assign_nearest_rt_kernel, dim3((unsigned)((B + ASSIGN_RT_ROWS - 1) / ASSIGN_RT_ROWS), (unsigned)M),
+                           dim3(RC_K), 0, (hipStream_t)stream, x, ldx, C, B, M, D / M, codes_u8, codes_i64);
+        RC_LAUNCH_CHECK(h);
+        return RC_OK;
+    }
     if (((uintptr_t)x & 15) || (ldx % 4) != 0) return RC_EINVAL;  // float4 row loads
     if (B == 0) return RC_OK;
     const int64_t nblk = (B + 255) / 256;

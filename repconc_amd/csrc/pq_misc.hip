@@ -14,7 +14,7 @@ extern "C" const char* rc_error_string(int code) {
     switch (code) {
         case RC_OK: return "ok";
         case RC_EINVAL: return "invalid argument";
-        case RC_ESHAPE: return "unsupported shape (K must be 256, D/M one of 8,12,16,24,32,48,64,96)";
+        case RC_ESHAPE: return "unsupported shape (K must be 256, M a divisor of D; search: M one of 8,12,16,24,32,48,64,96)";
         case RC_EHIP: return "HIP runtime error";
         case RC_EWORKSPACE: return "workspace too small";
         case RC_ECOMM: return "RCCL unavailable or collective failed";
@@ -184,6 +184,21 @@ __global__ __launch_bounds__(256) void decode_kernel(const void* __restrict__ co
     }
 }
 
+// widths that are not a multiple of 4 floats (MCQ_M = 128, 256, 384, 768 at hidden_size 768): one thread per float
+template <typename CodeT>
+__global__ __launch_bounds__(256) void decode_scalar_kernel(const void* __restrict__ codes, const float* __restrict__ C,
+                                                            int64_t n, int M, int dsub, float* __restrict__ out) {
+    const int D = M * dsub;
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / D;
+        const int c = (int)(i - row * D);
+        const int m = c / dsub, j = c - m * dsub;
+        const int code = load_code<CodeT>(codes, row * M + m) & (RC_K - 1);
+        out[i] = C[((size_t)m * RC_K + code) * dsub + j];
+    }
+}
+
 // grad_C[m, codes[n,m], j] += grad_out[n, m*dsub + j]  (fp32 atomics; the reference's
 // index_put(accumulate) backward is equally order-free).
 template <typename CodeT>
@@ -214,10 +229,21 @@ extern "C" int rc_pq_decode(rc_handle_t h, const void* codes, int code_dtype, co
                             int K, int dsub, float* out, rc_stream_t stream) {
     rc_device_guard device_guard_(h);
     if (!h || !codes || !C || !out || n < 0 || M <= 0 || dsub <= 0) return RC_EINVAL;
-    if (K != RC_K || dsub % 4 != 0) return RC_ESHAPE;
+    if (K != RC_K) return RC_ESHAPE;
     if (n == 0) return RC_OK;
-    const unsigned g = grid_for(h, n * (M * dsub / 4));
     hipStream_t s = (hipStream_t)stream;
+    if (dsub % 4 != 0) {
+        const unsigned gs = grid_for(h, n * M * dsub);
+        if (code_dtype == RC_CODE_U8)
+            hipLaunchKernelGGL(decode_scalar_kernel<uint8_t>, dim3(gs), dim3(256), 0, s, codes, C, n, M, dsub, out);
+        else if (code_dtype == RC_CODE_I64)
+            hipLaunchKernelGGL(decode_scalar_kernel<int64_t>, dim3(gs), dim3(256), 0, s, codes, C, n, M, dsub, out);
+        else
+            return RC_EINVAL;
+        RC_LAUNCH_CHECK(h);
+        return RC_OK;
+    }
+    const unsigned g = grid_for(h, n * (M * dsub / 4));
     if (code_dtype == RC_CODE_U8)
         hipLaunchKernelGGL(decode_kernel<uint8_t>, dim3(g), dim3(256), 0, s, codes, C, n, M, dsub, out);
     else if (code_dtype == RC_CODE_I64)

@@ -799,7 +799,7 @@ extern "C" int rc_pq_assign_sinkhorn(rc_handle_t h, const float* x, int64_t ldx,
     rc_device_guard device_guard_(h);
     if (!h || !x || !C || !flags || B < 0 || M <= 0 || iters < 1 || !(eps > 0.0) || (!codes_u8 && !codes_i64))
         return RC_EINVAL;
-    if (K != RC_K || D % M != 0 || !rc_dsub_supported(D / M)) return RC_ESHAPE;
+    if (K != RC_K || D % M != 0) return RC_ESHAPE;             // any width: rc_pq_dist_table picks the kernel
     if (B == 0) return RC_OK;
     return rc_solve_chains(h, x, ldx, C, B, D, M, eps, iters, 1, codes_u8, codes_i64, flags, ws, ws_bytes,
                            (hipStream_t)stream);

@@ -54,12 +54,10 @@ class RepCONC(nn.Module):
         D = dense_encoder.config.hidden_size
         M, K = config.MCQ_M, config.MCQ_K
         assert config.hidden_size % M == 0
-        # fail at construction, not at the first kernel launch: the exact-order distance kernels exist for these
-        # sub-vector widths (each has its own torch-CPU summation pattern) and K is fixed at 256
-        if K != ops.K or (config.hidden_size // M) not in ops.SUPPORTED_DSUB:
-            raise _lib.RepconcHipError(
-                f"MCQ_K={K}, MCQ_M={M} (sub-vector width {config.hidden_size // M}) unsupported: K must be 256 and "
-                f"hidden_size / MCQ_M one of {ops.SUPPORTED_DSUB}")
+        # K is fixed at 256 as in the reference (modeling_repconc.py:40); MCQ_M may be any divisor of hidden_size (:41): the
+        # recipes' widths run on specialised kernels, the others on the run-time-width kernels with the same arithmetic
+        if K != ops.K:
+            raise _lib.RepconcHipError(f"MCQ_K={K} unsupported: the reference asserts MCQ_K == 256")
         # OPQ rotation (identity until the warm-up fills it) and the M x K sub-centroids
         self.register_buffer("rotation", torch.eye(D))
         self.centroids = nn.Parameter(torch.randn((M, K, config.hidden_size // M)))
@@ -83,10 +81,14 @@ class RepCONC(nn.Module):
             codes, flags = assign_sinkhorn_sharded(continuous_embeds, self.centroids, self.sk_epsilon,
                                                    self.sk_iters, comm)
         fl = int(flags.item())
-        if fl & _lib.RC_FLAG_RANGE:
-            raise _lib.RepconcHipError(f"sk_epsilon={self.sk_epsilon} is outside the range the Sinkhorn kernels cover "
-                                       "(the reference's own exp(1/eps) overflows fp64 below 1.4e-3)")
+        if fl & _lib.RC_FLAG_COMM:
+            # a peer never arrived at an exchange (died, or skewed by more than the time-out): the codes are not the
+            # batch's codes and the channel is out of step — stop here, as a process-group time-out would
+            raise _lib.RepconcHipError("constrained assignment: the inter-rank exchange timed out (RC_FLAG_COMM); "
+                                       "a peer rank is missing or more than RC_IPC_TIMEOUT_MS behind")
         if fl != 0:
+            # the reference logs and returns (modeling_repconc.py:64-65); RC_FLAG_RANGE = sk_epsilon below ~3e-4, where
+            # the reference's own exp(1/eps) has long overflowed fp64 (below 1.4e-3) and logs the same line
             logger.warning("Sinkhorn Algorithm returns nan/inf values.")
         return codes
 

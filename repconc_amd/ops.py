@@ -61,8 +61,8 @@ def _shape(x: torch.Tensor, c: torch.Tensor):
     M, _, dsub = c.shape
     if D != M * dsub:
         raise ValueError(f"embedding width {D} != M*dsub = {M}*{dsub}")
-    if dsub not in SUPPORTED_DSUB:
-        raise _lib.RepconcHipError(f"dsub={dsub} unsupported (one of {SUPPORTED_DSUB})")
+    # every width is served: SUPPORTED_DSUB are the widths with specialised kernels (the recipes'), any other divisor goes
+    # through the run-time-width kernels with the same arithmetic (csrc/pq_distance.hip, "any width")
     return B, D, M, dsub
 
 

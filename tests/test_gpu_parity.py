@@ -285,6 +285,51 @@ def test_forward_fixture_m96_from_the_reference():
     assert zlib.crc32(model.decode(_t(g["ip_codes"]).long()).detach().cpu().numpy().tobytes()) == int(g["ip_quantized_crc"])
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 768])
+def test_every_divisor_of_the_hidden_size_is_a_valid_mcq_m(M):
+    """modeling_repconc.py:41 asserts only hidden_size % MCQ_M == 0.  RepCONC(config) constructs for every divisor of 768;
+    nearest and constrained codes and decode() equal the oracle (whose distance order is checked against torch-CPU for all
+    18 widths in tests/test_oracle_golden.py) — the recipes' widths on the specialised kernels, the others on the
+    run-time-width kernels."""
+    from types import SimpleNamespace
+    from repconc_amd.models.repconc import RepCONC
+    B = 512
+    x = synth.clustered_embeddings(5000 + M, B)
+    C = synth.sample_centroids(6000 + M, x, M)
+    cfg = SimpleNamespace(MCQ_M=M, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_IP")
+    model = RepCONC(cfg, _TableEncoder(torch.zeros(1, 768)), False, EPS, ITERS).to(DEV)
+    with torch.no_grad():
+        model.centroids.copy_(_t(C))
+    near = model.quantize(_t(x)).cpu().numpy()
+    assert near.shape == (B, M) and np.array_equal(near.astype(np.uint8), c_oracle.quantize(x, C, False)[0])
+    model.use_constraint = True
+    got = model.quantize(_t(x)).cpu().numpy().astype(np.uint8)
+    want = c_oracle.quantize(x, C, True, EPS, ITERS)[0]
+    if not np.array_equal(got, want):              # narrow sub-vectors: a plan column tied to the last ulp of exp may differ
+        wn, inter = pq_oracle.quantize(x, C, True, EPS, ITERS, return_intermediates=True)
+        assert pq_oracle.codes_equal_up_to_fp64_ties(got, wn.astype(np.uint8), inter["Q"])
+    dec = model.decode(_t(near)).detach().cpu().numpy()
+    assert np.array_equal(dec, c_oracle.decode(near.astype(np.uint8), C))
+
+
+def test_quantize_logs_and_returns_when_the_solve_flags_a_range_problem(caplog):
+    """modeling_repconc.py:64-65: the reference logs "Sinkhorn Algorithm returns nan/inf values." and returns its codes.  An
+    sk_epsilon below the kernels' range (where the reference's exp(1/eps) has long overflowed) does the same here — no raise."""
+    import logging
+    from types import SimpleNamespace
+    from repconc_amd.models.repconc import RepCONC
+    g, x, C = load_case("m8_b300_gauss")
+    cfg = SimpleNamespace(MCQ_M=8, MCQ_K=256, hidden_size=768, similarity_metric="METRIC_IP")
+    model = RepCONC(cfg, _TableEncoder(torch.zeros(1, 768)), True, 1e-5, 5).to(DEV)
+    with torch.no_grad():
+        model.centroids.copy_(_t(C))
+    with caplog.at_level(logging.WARNING):
+        codes = model.quantize(_t(x))
+    assert codes.shape == (300, 8) and codes.dtype == torch.int64
+    assert int(codes.min()) >= 0 and int(codes.max()) < 256
+    assert any("nan/inf" in r.getMessage() for r in caplog.records)
+
+
 def test_config0_exact_shape_10000_m8_against_the_oracle():
     """BASELINE configs[0] at its exact shape: x [10 000, 768] seed 20220, M = 8, centroids = rows of x at
     rng(20221).permutation(N)[:256], ONE batch of 10 000 rows, eps 0.003, 100 iterations — constrained and nearest codes

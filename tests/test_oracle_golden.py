@@ -196,3 +196,19 @@ def test_warmup_procedure_oracle_lowers_the_error_and_keeps_the_rotation_orthogo
         j = (j + 1) % 256
     assert j == donor
     assert np.array_equal(C[[0, 1, 3]], C3[[0, 1, 3]])
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 768])
+def test_distance_order_equals_torch_cpu_for_every_divisor_of_768(M):
+    """The reference's distance expression (modeling_repconc.py:50) evaluated by torch-CPU — the machine the fixtures come
+    from — against both restatements, every bit, for every MCQ_M the reference accepts: 8-wide vectors with four ILP
+    accumulators, the 16-round cascade (dsub = 768) and the scalar path below 8 floats (dsub = 6)."""
+    import torch
+    from oracle import c_oracle, pq_oracle
+    B, dsub = 48, 768 // M
+    g = torch.Generator().manual_seed(900 + M)
+    x = torch.randn(B, 768, generator=g)
+    C = torch.randn(M, 256, dsub, generator=g)
+    d = ((x.reshape(B, M, 1, -1).transpose(0, 1) - C.unsqueeze(1)) ** 2).sum(-1).numpy()
+    assert np.array_equal(pq_oracle.dist_table(x.numpy(), C.numpy()).view(np.uint32), d.view(np.uint32))
+    assert np.array_equal(c_oracle.dist_table(x.numpy(), C.numpy()).view(np.uint32), d.view(np.uint32))
