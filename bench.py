@@ -217,14 +217,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(int(t.item()))
 
-        chosen, notes = None, {}
+        chosen, notes, measured = None, {}, {}
         if args.dist_driver == "staged":
             notes["staged"] = "--dist-driver staged"
             candidates = []
-        elif os.environ.get("RC_COMM"):
+        elif os.environ.get("RC_COMM", "auto").lower() in ("ipc", "rccl"):
             candidates = [os.environ["RC_COMM"].lower()]
         else:
             candidates = ["ipc"] if share_gpu else ["ipc", "rccl"]     # RCCL refuses two ranks on one device
+        os.environ["RC_COMM_STRICT"] = "1"                  # "ipc" means ipc here: no silent fall-back inside comm_init
         import subprocess
         for ti, transport in enumerate(candidates):
             # the probe's exchange waits give up after 8 s (RC_FLAG_COMM), the probe itself after 150 s: a transport that does
@@ -252,14 +253,46 @@ def main():
                     ok, why = False, "codes differ from the staged driver"
             except Exception as e:                           # transport set-up failure: reported, not hidden
                 ok, why = False, f"{type(e).__name__}: {e}"
-            if all_ranks(ok):
-                chosen = transport
-                break
-            notes[transport] = why or "failed on another rank"
+            if not all_ranks(ok):
+                notes[transport] = why or "failed on another rank"
+                try:
+                    ops.comm_destroy()
+                except Exception:
+                    pass
+                continue
+            # this transport works: what it costs.  (a) one exchange step alone: all-gather of a chain's [M/2, K] fp64 row
+            # sums, 200 back to back; (b) the critical path it sits on: two untimed-warm steps of THIS rank's share of
+            # the batch through the native loop (sweeps of one chain overlap the exchange of the other)
+            rows = torch.zeros((M // 2, K), dtype=torch.float64, device=dev)
+            for _ in range(20):
+                ops.comm_allgather(rows)
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                ops.comm_allgather(rows)
+            e1.record()
+            torch.cuda.synchronize()
+            us_ag = max_over_ranks(e0.elapsed_time(e1)) * 1e3 / 200
+            for _ in range(2):
+                step(0)
+            barrier()
+            tt0 = time.perf_counter()
+            for i in range(3):
+                step(i)
+            barrier()
+            ms_step = max_over_ranks(time.perf_counter() - tt0) * 1e3 / 3
+            measured[transport] = {"us_per_allgather": round(us_ag, 2), "ms_per_step": round(ms_step, 3),
+                                   "us_per_iteration": round(ms_step * 1e3 / ITERS, 2)}
+            ops.comm_check()
+            barrier()
             try:
                 ops.comm_destroy()
             except Exception:
                 pass
+        if measured:                                         # the faster one runs the timed region (same choice on every rank:
+            chosen = min(measured, key=lambda t: measured[t]["ms_per_step"])     # ms_per_step is a max over ranks)
+            os.environ["RC_DIST_NATIVE"], os.environ["RC_COMM"] = "1", chosen
         native_all = chosen is not None
         os.environ["RC_DIST_NATIVE"] = "1" if native_all else "0"
         gathered = [torch.empty_like(c_staged) for _ in range(world)]
@@ -274,22 +307,14 @@ def main():
                       "transport": chosen, "native_equals_staged": native_all if candidates else None,
                       "transport_notes": notes or None, "sharded_equals_unsharded": unsharded_equal}
         if native_all:
-            # cost of one exchange step of the solve: all-gather of a chain's [M/2, K] fp64 row sums, back to back
-            rows = torch.zeros((M // 2, K), dtype=torch.float64, device=dev)
-            for _ in range(20):
-                ops.comm_allgather(rows)
-            barrier()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(200):
-                ops.comm_allgather(rows)
-            e1.record()
-            torch.cuda.synchronize()
-            exchange = {"transport": chosen, "bytes_per_rank": rows.numel() * 8,
-                        "us_per_allgather": round(max_over_ranks(e0.elapsed_time(e1)) * 1e3 / 200, 2),
-                        "what": "200 back-to-back rc_comm_allgather calls of one chain's row sums (fused push + wait "
-                                "kernel, copy-out); inside the solve (no copy-out) the two chains overlap this with the other "
-                                "chain's sweep"}
+            exchange = {"transport": chosen, "bytes_per_rank": (M // 2) * K * 8,
+                        "us_per_allgather": measured[chosen]["us_per_allgather"],
+                        "per_transport": measured,
+                        "what": "per transport that passed the probe and reproduced the staged codes: 200 back-to-back "
+                                "rc_comm_allgather calls of one chain's row sums (fused push + wait kernel, copy-out), and three "
+                                "steps of this run's per-rank batch through the native loop (ms_per_step, us_per_iteration = one "
+                                "Sinkhorn iteration's critical path: sweep of one chain overlapping the exchange of the other); "
+                                "the transport with the shorter step runs the timed region"}
             barrier()
         del xs_loc, c_staged, gathered
 

@@ -133,7 +133,8 @@ extern "C" int rc_comm_world(rc_handle_t h) { return h ? h->comm_world : 0; }
 // needs every peer's push n + 1, which that peer issued after ITS wait n (counter re-armed) and after the kernels that
 // read region n (stream order) — so neither the region nor the counter of exchange n can still be in use.
 // No CU is held while waiting beyond one wave, so ranks that share a GPU (the one-GPU test boxes) cannot starve each
-// other; a peer that died is noticed after RC_IPC_TIMEOUT_MS (flags |= RC_FLAG_COMM) instead of hanging the queue.
+// other; a peer that died is noticed after RC_IPC_TIMEOUT_MS (default 10 min; flags |= RC_FLAG_COMM, the transport stays
+// broken: ipc_wait_one) instead of hanging the queue.
 namespace {
 constexpr size_t IPC_SLOT = 256 * 1024;     // most bytes one rank contributes per exchange ([96, 256] fp64 row sums = 192 KiB)
 constexpr int IPC_CHANNELS = 3;
@@ -177,6 +178,29 @@ __global__ __launch_bounds__(256) void ipc_push_kernel(const char* __restrict__ 
                                __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// One thread waits for `want` arrivals on the local counter of (channel, parity) and re-arms it.  A wait that times out
+// (a peer died, or is more than RC_IPC_TIMEOUT_MS behind) BREAKS the transport: the status word keeps RC_FLAG_COMM, the
+// counter is left as it is (re-arming it would count the late arrivals towards the next exchange of this parity, which
+// would then complete early on stale data), and every later wait of this handle leaves at once with the flag set — the
+// caller sees RC_FLAG_COMM on every result after the break, never a silently wrong one (round 3 re-armed and carried on).
+__device__ __forceinline__ void ipc_wait_one(unsigned long long* __restrict__ counter, unsigned long long want,
+                                             int* __restrict__ flags, int* __restrict__ status, long long timeout_ticks) {
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & RC_FLAG_COMM) {
+        if (flags) atomicOr(flags, RC_FLAG_COMM);
+        return;
+    }
+    const long long t0 = wall_clock64();                     // constant 100 MHz
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > timeout_ticks) {
+            if (flags) atomicOr(flags, RC_FLAG_COMM);
+            atomicOr(status, RC_FLAG_COMM);
+            return;
+        }
+    }
+    __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // push and wait in ONE launch (the solve's exchange: one kernel per iteration and chain instead of two): every block pushes
 // its share and signals as ipc_push_kernel does; block (0, 0) then waits for the LOCAL counter like ipc_wait_kernel.  The
 // waiting block holds one wave; all pushes of this rank are issued before it starts to wait, so two ranks cannot wait for
@@ -195,34 +219,12 @@ __global__ __launch_bounds__(256) void ipc_pushwait_kernel(const char* __restric
     if (threadIdx.x == 0)
         __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(P.p[blockIdx.y] + counter_off), 1ull, __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_SYSTEM);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
-        bool ok = true;
-        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-            __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > timeout_ticks) { ok = false; break; }
-        }
-        __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (!ok) {
-            if (flags) atomicOr(flags, RC_FLAG_COMM);
-            atomicOr(status, RC_FLAG_COMM);
-        }
-    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ipc_wait_one(counter, want, flags, status, timeout_ticks);
 }
 
 __global__ void ipc_wait_kernel(unsigned long long* __restrict__ counter, unsigned long long want, int* __restrict__ flags,
                                 int* __restrict__ status, long long timeout_ticks) {
-    const long long t0 = wall_clock64();                     // constant 100 MHz
-    bool ok = true;
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > timeout_ticks) { ok = false; break; }
-    }
-    __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!ok) {
-        if (flags) atomicOr(flags, RC_FLAG_COMM);
-        atomicOr(status, RC_FLAG_COMM);
-    }
+    ipc_wait_one(counter, want, flags, status, timeout_ticks);
 }
 
 // distance range over ranks: gathered [world][2M] (max then min per rank) -> minmax [2M]
@@ -238,7 +240,9 @@ __global__ void ipc_minmax_kernel(const float* __restrict__ gathered, int world,
     minmax[i] = v;
 }
 
-long long ipc_timeout_ticks() { return (long long)rc_env_int("RC_IPC_TIMEOUT_MS", 30000) * 100000ll; }
+// default 10 minutes, the order of torch.distributed's process-group time-out: a rank that checkpoints or evaluates while
+// its peers already wait must not break the channel (round 3: 30 s)
+long long ipc_timeout_ticks() { return (long long)rc_env_int("RC_IPC_TIMEOUT_MS", 600000) * 100000ll; }
 
 // exchange number `n` of channel `ch`: every rank contributes `bytes` from `src`; returns this rank's dense
 // [world][bytes] region in *region.  Kernels only (capturable).
@@ -273,7 +277,25 @@ int ipc_exchange(rc_handle_t h, int ch, unsigned long long n, const void* src, s
     return RC_OK;
 }
 
+// Channel 2 serves every caller stream (rc_comm_allgather on the caller's stream, the solve's range exchange on its own):
+// the two-parity argument needs the exchanges of a channel to be ordered, so each one starts after the end of the previous
+// one whatever stream that ran on (an event on the handle; same stream: a no-op).  The exchange numbering itself is host
+// state of the handle: ONE host thread drives a handle's exchanges (as with a communicator).
+int ipc_ch2_begin(rc_handle_t h, hipStream_t s) {
+    if (h->capturing) return RC_OK;                       // inside a capture the stream order of the capture is the order
+    if (h->ipc.ev_ch2_set) RC_HIP_CHECK(h, hipStreamWaitEvent(s, h->ipc.ev_ch2, 0));
+    return RC_OK;
+}
+int ipc_ch2_end(rc_handle_t h, hipStream_t s) {
+    if (h->capturing) return RC_OK;
+    if (!h->ipc.ev_ch2) RC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ipc.ev_ch2, hipEventDisableTiming));
+    RC_HIP_CHECK(h, hipEventRecord(h->ipc.ev_ch2, s));
+    h->ipc.ev_ch2_set = 1;
+    return RC_OK;
+}
+
 void ipc_release(rc_handle_t h) {
+    if (h->ipc.ev_ch2) (void)hipEventDestroy(h->ipc.ev_ch2);
     if (h->ipc.on)
         for (int r = 0; r < h->comm_world && r < RC_IPC_MAX_WORLD; ++r)
             if (r != h->comm_rank && h->ipc.peer[r]) (void)hipIpcCloseMemHandle(h->ipc.peer[r]);
@@ -358,16 +380,18 @@ extern "C" int rc_comm_allgather(rc_handle_t h, const void* src, void* dst, size
     hipStream_t s = (hipStream_t)stream;
     if (h->ipc.on) {
         const int world = h->comm_world;
+        int rc = ipc_ch2_begin(h, s);
+        if (rc != RC_OK) return rc;
         for (size_t off = 0; off < bytes; off += IPC_SLOT) {
             const size_t chunk = bytes - off < IPC_SLOT ? bytes - off : IPC_SLOT;
             const char* region = nullptr;
-            int rc = ipc_exchange(h, 2, h->ipc.seq[2]++, (const char*)src + off, chunk, &region, flags, s);
+            rc = ipc_exchange(h, 2, h->ipc.seq[2]++, (const char*)src + off, chunk, &region, flags, s);
             if (rc != RC_OK) return rc;
             // region [world][chunk] -> dst [world][bytes] at column offset off
             RC_HIP_CHECK(h, hipMemcpy2DAsync((char*)dst + off, bytes, region, chunk, chunk, (size_t)world,
                                              hipMemcpyDeviceToDevice, s));
         }
-        return RC_OK;
+        return ipc_ch2_end(h, s);
     }
     if (h->comm[0]) {
         nccl_api* n = nccl();
@@ -538,9 +562,11 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
     }
     if (coll && ipc) {   // modeling_repconc.py:79-80 as one all-gather of the [2M] ranges + a local max / min
         const char* region = nullptr;
+        if ((rc = ipc_ch2_begin(h, s0)) != RC_OK) return rc;
         if ((rc = ipc_exchange(h, 2, h->ipc.seq[2]++, minmax, (size_t)2 * M * sizeof(float), &region, own_flags, s0)) != RC_OK) return rc;
         hipLaunchKernelGGL(ipc_minmax_kernel, dim3((2 * M + 63) / 64), dim3(64), 0, s0, (const float*)region, G, M, minmax);
         RC_LAUNCH_CHECK(h);
+        if ((rc = ipc_ch2_end(h, s0)) != RC_OK) return rc;
     } else if (coll) {   // modeling_repconc.py:79-80
         RC_NCCL_CHECK(h, n->AllReduce(minmax, minmax, (size_t)M, ncclFloat, ncclMax, (ncclComm_t)h->comm[0], s0));
         RC_NCCL_CHECK(h, n->AllReduce(minmax + M, minmax + M, (size_t)M, ncclFloat, ncclMin, (ncclComm_t)h->comm[0], s0));

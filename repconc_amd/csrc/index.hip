@@ -21,6 +21,8 @@ struct rc_index_s {
     void* ws;
     size_t ws_bytes;
     int* status;         // device word
+    int* qstatus;        // per-query status words of the last search, grown on demand (no allocation on the search path)
+    int qstatus_cap;
     bool have_centroids;
 };
 
@@ -59,6 +61,7 @@ extern "C" int rc_index_destroy(rc_index_t idx) {
     if (idx->image) (void)hipFree(idx->image);
     if (idx->ws) (void)hipFree(idx->ws);
     if (idx->status) (void)hipFree(idx->status);
+    if (idx->qstatus) (void)hipFree(idx->qstatus);
     delete idx;
     return RC_OK;
 }
@@ -172,9 +175,17 @@ extern "C" int rc_index_search(rc_index_t idx, const float* q, int nq, int k, fl
     // Like Faiss's IndexPQ.search (evaluate_repconc.py:180-185) this returns for any index content: the sampled-threshold
     // search is tried twice on the whole batch; queries whose status bits are still set then go through the exact path
     // (rc_adc_search_exact: no sample, no threshold), alone — the other queries' results stand.
-    int* qstatus = nullptr;
-    RC_IDX_HIP(idx, hipMalloc((void**)&qstatus, (size_t)nq * sizeof(int)));
-    struct guard { void* p[4]; ~guard() { for (void* q_ : p) if (q_) (void)hipFree(q_); } } g = {{qstatus, nullptr, nullptr, nullptr}};
+    // kept by the index, grown on demand: hipMalloc / hipFree per search cost an allocator round trip and a device-wide
+    // synchronisation on the small-batch path (JPQ steps, validation)
+    if (nq > idx->qstatus_cap) {
+        if (idx->qstatus) (void)hipFree(idx->qstatus);
+        idx->qstatus = nullptr; idx->qstatus_cap = 0;
+        const int cap = nq < 1024 ? 1024 : nq;
+        RC_IDX_HIP(idx, hipMalloc((void**)&idx->qstatus, (size_t)cap * sizeof(int)));
+        idx->qstatus_cap = cap;
+    }
+    int* qstatus = idx->qstatus;
+    struct guard { void* p[4]; ~guard() { for (void* q_ : p) if (q_) (void)hipFree(q_); } } g = {{nullptr, nullptr, nullptr, nullptr}};
     double slack = 6.0;
     int st = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {

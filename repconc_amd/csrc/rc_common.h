@@ -41,6 +41,8 @@ struct rc_handle_s {
         char* mine;                                   // my receive buffer
         char* peer[RC_IPC_MAX_WORLD];                 // peer[r] = rank r's buffer as mapped here (peer[rank] = mine)
         unsigned long long seq[3];                    // exchanges done per channel (0/1: Sinkhorn chains, 2: everything else)
+        hipEvent_t ev_ch2;                            // end of the last channel-2 exchange: the next one (on ANY stream) waits for it
+        int ev_ch2_set;
     } ipc;
     void* scratch;                                    // handle-owned device scratch (rc_scratch), grown on demand
     size_t scratch_bytes;

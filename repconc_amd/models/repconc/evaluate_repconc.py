@@ -105,6 +105,7 @@ class RepCONCEvaluater:
             pad = torch.zeros((most, width), dtype=dt, device=dev)
             pad[: local.shape[0]] = local
             got = ops.all_gather(pad)                               # [world, most, width]: the handle's exchange layer
+            ops.comm_check(dev)
             local = torch.cat([got[r][: (n * (r + 1)) // world - (n * r) // world] for r in range(world)], 0)
         return SimpleNamespace(predictions=local.cpu().numpy(), label_ids=None, metrics={})
 

@@ -234,52 +234,133 @@ _dist_ws = {}          # device index -> persistent workspace of assign_sinkhorn
 
 
 def comm_transport() -> str:
-    """RC_COMM=ipc|rccl (default ipc): how the ranks of a node exchange the Sinkhorn row sums and k-means statistics.
+    """RC_COMM=ipc|rccl|auto (default auto): how the ranks exchange the Sinkhorn row sums and k-means statistics.
     ipc = hand-written peer stores into IPC-mapped receive buffers (csrc/comm.hip; works between processes on ONE GPU
-    too), rccl = two RCCL communicators (needs one GPU per rank)."""
+    too; all ranks on one node, at most 16), rccl = two RCCL communicators (one GPU per rank; any number of nodes).
+    auto = ipc where it can work (one node, world <= 16), else rccl; a failed IPC connect falls back to rccl on ALL ranks."""
     import os
-    v = os.environ.get("RC_COMM", "ipc").lower()
-    if v not in ("ipc", "rccl"):
-        raise ValueError("RC_COMM must be ipc or rccl")
+    v = os.environ.get("RC_COMM", "auto").lower()
+    if v not in ("ipc", "rccl", "auto"):
+        raise ValueError("RC_COMM must be ipc, rccl or auto")
     return v
 
 
-def comm_init(group=None, transport: Optional[str] = None):
-    """Set up the exchange layer of this process's handle (once per process group).  Only the set-up handshake goes
-    through torch.distributed (any backend): the IPC descriptors (128 bytes per rank, all-gathered) or the RCCL unique
-    ids (256 bytes, broadcast from rank 0); everything after that happens inside librepconc_hip.so."""
+RC_IPC_MAX_WORLD = 16
+
+
+def _all_ranks_ok(ok: bool, group) -> bool:
+    """Collective AND over the group (any backend): a set-up step either worked on every rank or is undone on every rank."""
+    import torch.distributed as dist
+    flags = [None] * dist.get_world_size(group)
+    dist.all_gather_object(flags, bool(ok), group=group)
+    return all(flags)
+
+
+def _same_node(group) -> bool:
+    import socket
+    import torch.distributed as dist
+    names = [None] * dist.get_world_size(group)
+    dist.all_gather_object(names, socket.gethostname(), group=group)
+    return len(set(names)) == 1
+
+
+def _connect_ipc(lib, h, rank, world, group) -> bool:
+    """Export + connect on every rank; False (with the handle released again) on every rank if any rank failed."""
+    import torch.distributed as dist
+    blob = (C.c_char * _lib.RC_IPC_BLOB_BYTES)()
+    ok = lib.rc_comm_ipc_export(h, rank, world, C.cast(blob, C.c_void_p)) == _lib.RC_OK
+    blobs = [None] * world
+    dist.all_gather_object(blobs, bytes(blob.raw) if ok else None, group=group)
+    if all(b is not None for b in blobs):
+        raw = (C.c_char * (_lib.RC_IPC_BLOB_BYTES * world)).from_buffer_copy(b"".join(blobs))
+        ok = lib.rc_comm_ipc_connect(h, C.cast(raw, C.c_void_p)) == _lib.RC_OK
+    else:
+        ok = False
+    ok = _all_ranks_ok(ok, group)                           # also the barrier: every rank has mapped every buffer
+    if not ok:
+        lib.rc_comm_destroy(h)                              # releases an exported-but-unconnected buffer too
+    return ok
+
+
+def _connect_rccl(lib, h, dev, rank, world, group) -> bool:
+    import torch.distributed as dist
+    ids = torch.zeros(256, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_char * 256)()
+        _lib.check(lib.rc_comm_unique_ids(C.cast(buf, C.c_void_p)), "rc_comm_unique_ids")
+        ids = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    if world > 1:
+        backend = dist.get_backend(group)
+        t = ids.to(torch.device("cuda", dev)) if backend == "nccl" else ids
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ids = t.cpu()
+    raw = (C.c_char * 256).from_buffer_copy(bytes(ids.numpy().tobytes()))
+    ok = lib.rc_comm_init(h, C.cast(raw, C.c_void_p), rank, world) == _lib.RC_OK
+    ok = _all_ranks_ok(ok, group) if world > 1 else ok
+    if not ok:
+        lib.rc_comm_destroy(h)
+    return ok
+
+
+def comm_init(group=None, transport: Optional[str] = None) -> str:
+    """Set up the exchange layer of this process's handle (once per process group); returns the transport that runs.
+    Only the set-up handshake goes through torch.distributed (any backend): the IPC descriptors (128 bytes per rank,
+    all-gathered) or the RCCL unique ids (256 bytes, broadcast from rank 0); everything after that happens inside
+    librepconc_hip.so.  COLLECTIVE: every rank of the group calls it, every step is agreed on by all ranks (a connect that
+    fails on one rank is undone on all of them), and all ranks end on the same transport or all raise — no rank is left
+    spinning in IPC waits while another has fallen back.  transport = "auto" (default, RC_COMM): ipc when all ranks share
+    a host and world <= 16, else rccl; ipc that fails to connect falls back to rccl."""
     import torch.distributed as dist
     dev = torch.cuda.current_device()
-    transport = transport or comm_transport()
-    key = (id(group) if group is not None else 0, transport)
-    if _comm_ready.get(dev) == key:
-        return
+    want = (transport or comm_transport()).lower()
+    key0 = id(group) if group is not None else 0
+    ready = _comm_ready.get(dev)
+    if ready is not None and ready[0] == key0 and (want == "auto" or ready[1] == want):
+        return ready[1]
     lib, h = _lib.load(), _lib.handle(dev)
     if dev in _comm_ready:                                  # another process group / transport: start over
         comm_destroy(group_barrier=False)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if transport == "ipc":
-        blob = (C.c_char * _lib.RC_IPC_BLOB_BYTES)()
-        _lib.check(lib.rc_comm_ipc_export(h, rank, world, C.cast(blob, C.c_void_p)), "rc_comm_ipc_export", h)
-        blobs = [None] * world
-        dist.all_gather_object(blobs, bytes(blob.raw), group=group)
-        raw = (C.c_char * (_lib.RC_IPC_BLOB_BYTES * world)).from_buffer_copy(b"".join(blobs))
-        _lib.check(lib.rc_comm_ipc_connect(h, C.cast(raw, C.c_void_p)), "rc_comm_ipc_connect", h)
-        dist.barrier(group=group)                           # every rank has mapped every buffer before the first store
-    else:
-        ids = torch.zeros(256, dtype=torch.uint8)
-        if rank == 0:
-            buf = (C.c_char * 256)()
-            _lib.check(lib.rc_comm_unique_ids(C.cast(buf, C.c_void_p)), "rc_comm_unique_ids")
-            ids = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        if world > 1:
-            backend = dist.get_backend(group)
-            t = ids.to(torch.device("cuda", dev)) if backend == "nccl" else ids
-            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            ids = t.cpu()
-        raw = (C.c_char * 256).from_buffer_copy(bytes(ids.numpy().tobytes()))
-        _lib.check(lib.rc_comm_init(h, C.cast(raw, C.c_void_p), rank, world), "rc_comm_init", h)
-    _comm_ready[dev] = key
+    tried = []
+    if want in ("ipc", "auto"):
+        ipc_possible = world <= RC_IPC_MAX_WORLD and _same_node(group)
+        if ipc_possible and _connect_ipc(lib, h, rank, world, group):
+            _comm_ready[dev] = (key0, "ipc")
+            return "ipc"
+        tried.append("ipc (world > 16 or ranks on several hosts)" if not ipc_possible else "ipc (export / connect failed on a rank)")
+        if want == "ipc" and rc_env_strict():
+            raise _lib.RepconcHipError("comm_init: the IPC transport is unavailable: " + tried[-1])
+    if _connect_rccl(lib, h, dev, rank, world, group):
+        _comm_ready[dev] = (key0, "rccl")
+        return "rccl"
+    tried.append("rccl (rc_comm_init failed on a rank)")
+    raise _lib.RepconcHipError("comm_init: no exchange transport could be set up on all ranks: " + "; ".join(tried))
+
+
+def rc_env_strict() -> bool:
+    """RC_COMM_STRICT=1: an explicitly requested transport that is unavailable raises instead of falling back (tests)."""
+    import os
+    return os.environ.get("RC_COMM_STRICT", "0") == "1"
+
+
+_comm_flags = {}       # device index -> int32 flags word passed to every rc_comm_allgather of that device
+
+
+def comm_check(device=None) -> None:
+    """Raise if an exchange of this device's handle has timed out since comm_init() (RC_FLAG_COMM: a peer rank is missing or
+    more than RC_IPC_TIMEOUT_MS behind; the transport is broken from then on and every later gather is flagged).
+    Synchronises — call where the results of the gathers are consumed (the multi-rank paths of the package do)."""
+    if not _comm_flags:                                     # no native gather has run (CPU / torch.distributed paths)
+        return
+    if isinstance(device, torch.device):
+        if device.type != "cuda":
+            return
+        device = device.index
+    dev = torch.cuda.current_device() if device is None else int(device)
+    fl = _comm_flags.get(dev)
+    if fl is not None and int(fl.item()) & _lib.RC_FLAG_COMM:
+        raise _lib.RepconcHipError("an inter-rank exchange timed out (RC_FLAG_COMM): a peer rank is missing or more than "
+                                   "RC_IPC_TIMEOUT_MS behind; the gathered data of this and every later exchange is invalid")
 
 
 def comm_destroy(group=None, group_barrier: bool = True):
@@ -296,6 +377,7 @@ def comm_destroy(group=None, group_barrier: bool = True):
     lib, h = _lib.load(), _lib.handle(dev)
     _lib.check(lib.rc_comm_destroy(h), "rc_comm_destroy", h)
     del _comm_ready[dev]
+    _comm_flags.pop(dev, None)
 
 
 def comm_allgather(t: torch.Tensor, flags: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -308,6 +390,11 @@ def comm_allgather(t: torch.Tensor, flags: Optional[torch.Tensor] = None) -> tor
     if world < 1:
         raise _lib.RepconcHipError("comm_allgather: call ops.comm_init() first")
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    if flags is None:                                       # the device's own flags word: comm_check() reads it
+        dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+        flags = _comm_flags.get(dev)
+        if flags is None:
+            flags = _comm_flags[dev] = torch.zeros((1,), dtype=torch.int32, device=t.device)
     _lib.check(lib.rc_comm_allgather(h, _p(t), _p(out), t.numel() * t.element_size(), _p(flags), s), "rc_comm_allgather", h)
     return out
 

@@ -34,7 +34,9 @@ def sharded_search(index: PQIndex, q: torch.Tensor, k: int, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return scores, ids
     from . import ops
-    return merge_topk(ops.all_gather(scores, group), ops.all_gather(ids, group), k)
+    out = merge_topk(ops.all_gather(scores, group), ops.all_gather(ids, group), k)
+    ops.comm_check(q.device)                                       # a timed-out exchange is an error, not a result
+    return out
 
 
 def search_virtual_shards(shards: Sequence[PQIndex], q: torch.Tensor, k: int):
@@ -68,4 +70,5 @@ def replicated_search(index, q: torch.Tensor, k: int, *search_args, group=None):
     all_s = ops.all_gather(pad_s, group).view(G * most, k)
     all_i = ops.all_gather(pad_i, group).view(G * most, k)
     keep = torch.cat([torch.arange(g * most, g * most + bounds[g + 1] - bounds[g], device=s.device) for g in range(G)])
+    ops.comm_check(s.device)                                       # a timed-out exchange is an error, not a result
     return all_s[keep].contiguous(), all_i[keep].contiguous()

@@ -239,15 +239,20 @@ def warmup_from_embeds(corpus_embeds: np.ndarray, repconc, opq_iters: int = 50, 
         # corpus sharded over the ranks (BASELINE configs[2]): the per-shard statistics of every Lloyd iteration and
         # the Procrustes matrices travel through the handle's own exchange layer (csrc/comm.hip: IPC peer stores over
         # xGMI, or RCCL) — torch.distributed only carries the one-time handshake
+        # comm_init is collective: all ranks end on the same transport (ipc, else rccl) or ALL raise — then all of them use
+        # torch.distributed's all-gathers (ops.all_gather picks its path from a state every rank shares)
         try:
             with torch.cuda.device(dev):
                 ops.comm_init()
-        except Exception as e:      # e.g. ranks on different nodes: torch.distributed carries the gathers instead
+        except Exception as e:
             logger.warning("native exchange layer unavailable (%s); using torch.distributed all-gathers", e)
     take = np.sort(np.random.default_rng(SEED).permutation(N)[:MAX_TRAIN_POINTS])
     xt = torch.from_numpy(np.ascontiguousarray(corpus_embeds[take], dtype=np.float32)).to(dev)
     R = train_opq(xt, M, n_outer=opq_iters) if opq_iters > 0 else torch.eye(D, device=dev)
     C, mse = train_pq((xt @ R).contiguous(), M, pq_iters)
+    if _multi():
+        with torch.cuda.device(dev):
+            ops.comm_check()                                            # a timed-out statistics gather: stop, do not save
     logger.info("PQ reconstruction mse on the training rows: %.5f", mse)
     with torch.no_grad():
         repconc.rotation.copy_(R.T.to(repconc.rotation.device))        # vt.A is [d_out, d_in]

@@ -48,6 +48,22 @@ def main() -> int:
             torch.cuda.synchronize()
             lib, h = _lib.load(), _lib.handle(local)
             ok = int(flags.item()) & _lib.RC_FLAG_COMM and lib.rc_comm_status(h) & _lib.RC_FLAG_COMM
+            # the transport is BROKEN from here on: later exchanges leave at once (no second time-out, no counter re-armed
+            # for late arrivals to corrupt) and carry the flag; the torch-facing helpers raise at their check
+            import time
+            t0 = time.perf_counter()
+            f2 = torch.zeros(1, dtype=torch.int32, device=dev)
+            for _ in range(5):
+                ops.comm_allgather(torch.ones(1024, device=dev), f2)
+            torch.cuda.synchronize()
+            fast = time.perf_counter() - t0 < 0.25                      # five exchanges, far below ONE 300 ms time-out
+            ok = ok and fast and int(f2.item()) & _lib.RC_FLAG_COMM
+            ops.all_gather(torch.ones(8, device=dev))
+            try:
+                ops.comm_check()
+                ok = False
+            except _lib.RepconcHipError:
+                pass
             rc = 0 if ok else 1
             del got
         dist.barrier()
