@@ -475,17 +475,43 @@ __global__ __launch_bounds__(256) void assign_redo_kernel(const float* __restric
     if (n > redo_cap) n = redo_cap;
     const int lane = threadIdx.x & 63;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    // A pair is a chain of dependent loads (list entry -> row slice -> distances): the NEXT pair's entry and slice are
+    // requested before this pair's 256 distances are computed (round 4; the chain was walked pair by pair: 0.21 ms for the
+    // 0.2 % doubtful pairs of 2^20 rows, most of it latency).  Wide slices keep one buffer (registers).
+    // The list entry is requested TWO pairs ahead and the slice one pair ahead, so no load is waited for in the iteration that
+    // issues it (an entry fetched and used in the same iteration stalls the wave on the in-order vmcnt at once).
+    constexpr bool DB = DSUB <= 32;
+    float4 xn[DB ? DSUB / 4 : 1];
+    unsigned e1 = wave < n ? redo[wave] : 0u;                                  // entry of the next pair to compute
+    unsigned e2 = wave + nwaves < n ? redo[wave + nwaves] : 0u;                // and of the one after
+    auto fetch_x = [&](unsigned e, bool live) {
+        if constexpr (DB) {
+            if (!live) return;
+            const float4* xp = reinterpret_cast<const float4*>(x + (int64_t)(e / (unsigned)M) * ldx + (int)(e % (unsigned)M) * DSUB);
+#pragma unroll
+            for (int j = 0; j < DSUB / 4; ++j) xn[j] = xp[j];
+        }
+    };
+    fetch_x(e1, wave < n);
     for (unsigned i = wave; i < n; i += nwaves) {
-        const unsigned e = redo[i];
+        const unsigned e = e1;
         const int64_t b = e / (unsigned)M;
         const int m = (int)(e % (unsigned)M);
         float xs[DSUB];
-        const float4* xp = reinterpret_cast<const float4*>(x + b * ldx + m * DSUB);
+        if constexpr (DB) {
 #pragma unroll
-        for (int j = 0; j < DSUB / 4; ++j) {
-            const float4 v = xp[j];
-            xs[4 * j] = v.x; xs[4 * j + 1] = v.y; xs[4 * j + 2] = v.z; xs[4 * j + 3] = v.w;
+            for (int j = 0; j < DSUB / 4; ++j) { xs[4 * j] = xn[j].x; xs[4 * j + 1] = xn[j].y; xs[4 * j + 2] = xn[j].z; xs[4 * j + 3] = xn[j].w; }
+        } else {
+            const float4* xp = reinterpret_cast<const float4*>(x + b * ldx + m * DSUB);
+#pragma unroll
+            for (int j = 0; j < DSUB / 4; ++j) {
+                const float4 v = xp[j];
+                xs[4 * j] = v.x; xs[4 * j + 1] = v.y; xs[4 * j + 2] = v.z; xs[4 * j + 3] = v.w;
+            }
         }
+        e1 = e2;
+        fetch_x(e1, i + nwaves < n);                                           // e2 arrived an iteration ago
+        e2 = (i + 2 * nwaves < n) ? redo[i + 2 * nwaves] : 0u;
         const float* cm = C + (size_t)m * RC_K * DSUB;
         float best = INFINITY;
         int bi = 0;
@@ -563,7 +589,7 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
             hipLaunchKernelGGL(assign_prep_kernel<DS>, dim3((unsigned)M), dim3(256), 0, s, C, cpre);                     \
             hipLaunchKernelGGL(kern, dim3((unsigned)nblk, nchunk), dim3(256), lds, s, x, ldx, C, B, M, codes_u8, codes_i64, \
                                redo_count, redo, cap, MC, (const unsigned char*)cpre);                                       \
-            hipLaunchKernelGGL(assign_redo_kernel<DS>, dim3((unsigned)(h->num_cus * 4)), dim3(256), 0, s, x, ldx, C, M,  \
+            hipLaunchKernelGGL(assign_redo_kernel<DS>, dim3((unsigned)(h->num_cus * (DS <= 32 ? 8 : 4))), dim3(256), 0, s, x, ldx, C, M,  \
                                redo_count, redo, cap, codes_u8, codes_i64);                                              \
         } break;
         MF_CASE(8) MF_CASE(12) MF_CASE(16) MF_CASE(24) MF_CASE(32) MF_CASE(48) MF_CASE(64) MF_CASE(96)
