@@ -1578,6 +1578,7 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     bsel[r >> 2] = 1 << (8 * (r & 3));
     const bool rc_q16_setprio = (flags & 1) != 0;
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+    if (lds0 & 0xFFFFu) __builtin_trap();                     // the one-instruction gather address needs 64 KiB-aligned table buffers
     unsigned off[4], offb[4];                                 // this lane's slot offsets (absolute LDS address): buffer 0 / current buffer
 #pragma unroll
     for (int j = 0; j < 4; ++j) off[j] = lds0 + (unsigned)adc_q16_slot(l, j) * 16u;
@@ -1665,8 +1666,10 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             const unsigned wc = w[c >> 2][c & 3];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                unsigned addr;
-                asm("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_add_u32 %0, %0, 8, %3" : "=&v"(addr) : "v"(wc), "n"(8 * j), "v"(offb[j]));
+                // LDS address = buffer base (a multiple of 64 KiB: bytes 2-3) | code << 8 (byte 1) | slot offset (byte 0), built by
+                // ONE v_perm_b32 from the code word and the lane's slot constant (round 3: v_bfe_u32 + v_lshl_add_u32).  The
+                // dynamic LDS of this kernel starts at address 0 (no static __shared__), checked once per block below.
+                const unsigned addr = __builtin_amdgcn_perm(wc, offb[j], 0x03020000u | ((4u + (unsigned)j) << 8));
                 e[j] = *reinterpret_cast<const adc_u32x4v __attribute__((address_space(3)))*>(addr);
             }
         };
