@@ -353,6 +353,16 @@ int rc_index_search(rc_index_t idx, const float* q, int nq, int k, float* scores
 size_t rc_ivf_coarse_assign_ws_bytes(int nlist);
 int rc_ivf_coarse_assign(rc_handle_t h, const float* x, int64_t ldx, const float* cent, int64_t B, int D, int nlist,
                          int* cell, void* ws, size_t ws_bytes, rc_stream_t stream);
+
+/* Centroid update of the coarse k-means (the Lloyd step after rc_ivf_coarse_assign; repconc_amd/ivf.py::coarse_kmeans —
+ * a build-side extension, BASELINE configs[3] "IVF nlist=5000"): cent[l] <- mean of the rows with assign[r] == l, summed in
+ * ascending row order in fp64 by one block per cell after a stable counting sort (deterministic, no atomics on values);
+ * an empty cell takes row splitmix64(seed, iter, l) mod n.  assign: int32 [n] (entries outside [0, nlist) are ignored);
+ * counts_out: optional uint32 [nlist].  D % 4 == 0, D <= 4096, nlist <= 16384, 16-byte aligned x / cent rows.
+ * ws: rc_ivf_coarse_update_ws_bytes(n, nlist). */
+size_t rc_ivf_coarse_update_ws_bytes(int64_t n, int nlist);
+int rc_ivf_coarse_update(rc_handle_t h, const float* x, int64_t ldx, const int* assign, int64_t n, int D, int nlist, float* cent,
+                         unsigned* counts_out, uint64_t seed, int iter, void* ws, size_t ws_bytes, rc_stream_t stream);
 /* List-centric search of the same index (M in {16,32,48,64,96}): all queries probing a cell are split into groups of up
  * to 8, one block per (cell, group) task runs the conflict-free 8-bit screen of the flat search over the cell's rows,
  * survivors are re-scored exactly — results identical to rc_ivf_search.  image: rc_adc_scan_image of the cell-major codes.

@@ -79,6 +79,8 @@ PROTOTYPES = {
     "rc_adc_search_exact": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "rc_ivf_coarse_assign_ws_bytes": (_sz, [_i]),
     "rc_ivf_coarse_assign": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp]),
+    "rc_ivf_coarse_update_ws_bytes": (_sz, [_i64, _i]),
+    "rc_ivf_coarse_update": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, C.c_uint64, _i, _vp, _sz, _vp]),
     "rc_ivf_search_lists_ws_bytes": (_sz, [_i, _i, _i64]),
     "rc_ivf_search_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i,
                                  _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

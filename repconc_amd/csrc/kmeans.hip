@@ -618,3 +618,175 @@ extern "C" int rc_kmeans_split_empty(rc_handle_t h, float* C, const int64_t* cou
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
+
+// ------------------------------------------------------------------------------------------ IVF coarse quantiser
+// Centroid update of the coarse k-means (repconc_amd/ivf.py::coarse_kmeans; BASELINE configs[3], nlist = 5000): the
+// statistics of `nlist` cells x D columns do not fit a block's LDS the way a sub-quantiser's 256 x dsub do, so the rows are
+// brought into cell order first and every cell is summed by ONE block, in ascending row order, in fp64 — deterministic
+// whatever the launch geometry (round 3: torch index_add_ — fp32 atomics — and bincount, two host synchronisations and a
+// host RNG per Lloyd iteration).  Stable counting sort, three kernels, no atomics:
+//   ivfc_tile_hist_kernel   per tile of IVFC_TILE consecutive rows: histogram of the cells            -> hist[tile][cell]
+//   ivfc_cell_scan_kernel   per cell: running sum over the tiles (hist becomes the tile's base), count; then the exclusive
+//                           scan of the counts over the cells (last block to finish)                    -> start[cell]
+//   ivfc_scatter_kernel     per tile: row r goes to start[cell] + base[tile][cell] + (number of earlier rows of the tile in
+//                           the same cell)                                                              -> perm[n]
+// then ivfc_cell_mean_kernel: cent[cell] = sum / count (fp32 of the fp64 mean); an EMPTY cell takes the row
+// splitmix64(seed, iteration, cell) mod n — counter-based, the same on every rank, nothing read back.
+#define IVFC_TILE 2048
+__device__ __forceinline__ unsigned long long ivfc_mix(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(1024) void ivfc_tile_hist_kernel(const int* __restrict__ assign, int64_t n, int nlist,
+                                                              unsigned* __restrict__ hist) {
+    extern __shared__ unsigned ivfc_h[];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < nlist; i += 1024) ivfc_h[i] = 0u;
+    __syncthreads();
+    const int64_t r0 = (int64_t)tile * IVFC_TILE;
+    for (int i = tid; i < IVFC_TILE; i += 1024) {
+        const int64_t r = r0 + i;
+        if (r < n) {
+            const int c = assign[r];
+            if (c >= 0 && c < nlist) atomicAdd(&ivfc_h[c], 1u);           // integer counts: order-free
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nlist; i += 1024) hist[(size_t)tile * nlist + i] = ivfc_h[i];
+}
+
+__global__ __launch_bounds__(256) void ivfc_cell_scan_kernel(unsigned* __restrict__ hist, int tiles, int nlist,
+                                                             unsigned* __restrict__ count, unsigned* __restrict__ start,
+                                                             unsigned* __restrict__ done) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < nlist) {
+        unsigned run = 0;
+        for (int t = 0; t < tiles; ++t) {
+            const unsigned v = hist[(size_t)t * nlist + c];
+            hist[(size_t)t * nlist + c] = run;
+            run += v;
+        }
+        count[c] = run;
+    }
+    // the last block to arrive scans the counts (one pass of 256 threads over 256-cell strips)
+    __shared__ unsigned s_last, s_w[4], s_carry;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(done, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) { s_carry = 0u; *done = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < nlist; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        const unsigned v = i < nlist ? __hip_atomic_load(&count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = (unsigned)__shfl_up((int)incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        unsigned before = s_carry;
+        for (int w = 0; w < wv; ++w) before += s_w[w];
+        if (i < nlist) start[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = before + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void ivfc_scatter_kernel(const int* __restrict__ assign, int64_t n, int nlist,
+                                                            const unsigned* __restrict__ base, const unsigned* __restrict__ start,
+                                                            unsigned* __restrict__ perm) {
+    __shared__ int s_c[IVFC_TILE];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int64_t r0 = (int64_t)tile * IVFC_TILE;
+    for (int i = tid; i < IVFC_TILE; i += 1024) s_c[i] = (r0 + i < n) ? assign[r0 + i] : -1;
+    __syncthreads();
+    for (int i = tid; i < IVFC_TILE; i += 1024) {
+        const int c = s_c[i];
+        if (c < 0 || c >= nlist) continue;
+        unsigned rank = 0;
+        for (int j = 0; j < i; ++j) rank += (s_c[j] == c) ? 1u : 0u;        // rows of the tile ahead of this one in its cell
+        perm[start[c] + base[(size_t)tile * nlist + c] + rank] = (unsigned)(r0 + i);
+    }
+}
+
+// grid nlist, block D / 4 threads (one float4 column group each; D % 4 == 0, D <= 4096)
+__global__ __launch_bounds__(1024) void ivfc_cell_mean_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int D,
+                                                              const unsigned* __restrict__ perm, const unsigned* __restrict__ start,
+                                                              const unsigned* __restrict__ count, float* __restrict__ cent,
+                                                              unsigned long long seed, int iter) {
+    const int c = blockIdx.x, j4 = threadIdx.x;
+    const unsigned cnt = count[c], s0 = start[c];
+    float4* out = reinterpret_cast<float4*>(cent + (size_t)c * D) + j4;
+    if (cnt == 0u) {                                         // empty cell: a counter-based random row
+        const int64_t r = (int64_t)(ivfc_mix(seed ^ ivfc_mix(((unsigned long long)(unsigned)iter << 32) | (unsigned)c)) % (unsigned long long)n);
+        *out = *(reinterpret_cast<const float4*>(x + r * ldx) + j4);
+        return;
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    unsigned i = 0;
+    for (; i + 4 <= cnt; i += 4) {                            // four rows in flight, added in ascending order
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(reinterpret_cast<const float4*>(x + (int64_t)perm[s0 + i + u] * ldx) + j4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
+    }
+    for (; i < cnt; ++i) {
+        const float4 v = *(reinterpret_cast<const float4*>(x + (int64_t)perm[s0 + i] * ldx) + j4);
+        a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    }
+    const double inv = (double)cnt;
+    *out = make_float4((float)(a0 / inv), (float)(a1 / inv), (float)(a2 / inv), (float)(a3 / inv));
+}
+
+extern "C" size_t rc_ivf_coarse_update_ws_bytes(int64_t n, int nlist) {
+    if (n <= 0 || nlist <= 0) return 0;
+    const size_t tiles = (size_t)((n + IVFC_TILE - 1) / IVFC_TILE);
+    return rc_align_up(tiles * nlist * sizeof(unsigned), 256) + 2 * rc_align_up((size_t)nlist * sizeof(unsigned), 256) +
+           rc_align_up((size_t)n * sizeof(unsigned), 256) + 256;
+}
+
+// cent [nlist, D] <- mean of the rows assigned to each cell (assign [n] int32, e.g. from rc_ivf_coarse_assign); rows with an
+// assignment outside [0, nlist) are ignored; counts_out (optional) receives the cell sizes.
+extern "C" int rc_ivf_coarse_update(rc_handle_t h, const float* x, int64_t ldx, const int* assign, int64_t n, int D, int nlist,
+                                    float* cent, unsigned* counts_out, uint64_t seed, int iter, void* ws, size_t ws_bytes,
+                                    rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !x || !assign || !cent || n <= 0 || D <= 0 || nlist <= 0 || ldx < D) return RC_EINVAL;
+    if (D % 4 != 0 || D > 4096 || nlist > 16384 || n > 0xFFFFFFFFll || (ldx % 4) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)cent & 15))
+        return RC_ESHAPE;
+    if (!ws || ws_bytes < rc_ivf_coarse_update_ws_bytes(n, nlist)) return RC_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = (int)((n + IVFC_TILE - 1) / IVFC_TILE);
+    char* w = (char*)ws;
+    unsigned* hist = (unsigned*)w;            w += rc_align_up((size_t)tiles * nlist * sizeof(unsigned), 256);
+    unsigned* count = (unsigned*)w;           w += rc_align_up((size_t)nlist * sizeof(unsigned), 256);
+    unsigned* start = (unsigned*)w;           w += rc_align_up((size_t)nlist * sizeof(unsigned), 256);
+    unsigned* perm = (unsigned*)w;            w += rc_align_up((size_t)n * sizeof(unsigned), 256);
+    unsigned* done = (unsigned*)w;
+    RC_HIP_CHECK(h, hipMemsetAsync(done, 0, sizeof(unsigned), s));
+    const size_t lds = (size_t)nlist * sizeof(unsigned);
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)ivfc_tile_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ivfc_tile_hist_kernel, dim3((unsigned)tiles), dim3(1024), lds, s, assign, n, nlist, hist);
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(ivfc_cell_scan_kernel, dim3((unsigned)((nlist + 255) / 256)), dim3(256), 0, s, hist, tiles, nlist, count, start, done);
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(ivfc_scatter_kernel, dim3((unsigned)tiles), dim3(1024), 0, s, assign, n, nlist, (const unsigned*)hist,
+                       (const unsigned*)start, perm);
+    RC_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(ivfc_cell_mean_kernel, dim3((unsigned)nlist), dim3((unsigned)(D / 4)), 0, s, x, ldx, n, D, (const unsigned*)perm,
+                       (const unsigned*)start, (const unsigned*)count, cent, (unsigned long long)seed, iter);
+    RC_LAUNCH_CHECK(h);
+    if (counts_out) RC_HIP_CHECK(h, hipMemcpyAsync(counts_out, count, (size_t)nlist * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+    return RC_OK;
+}

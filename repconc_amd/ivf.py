@@ -25,11 +25,27 @@ from .index import PQIndex
 
 
 def coarse_kmeans(x: torch.Tensor, nlist: int, iters: int = 10, seed: int = 1234, chunk: int = 1 << 16) -> torch.Tensor:
-    """Lloyd k-means of `nlist` centroids on x [n, D] (device).  Empty cells are re-seeded from random points."""
+    """Lloyd k-means of `nlist` centroids on x [n, D] (device): assignment by the fp32-MFMA GEMM + argmin kernel
+    (rc_ivf_coarse_assign), centroid update by rc_ivf_coarse_update (stable counting sort of the rows by cell, one block per
+    cell sums its rows in ascending order in fp64; an empty cell takes a counter-based random row) — nothing is read back
+    between the iterations and the result is the same run to run.  Initial centroids: `nlist` rows of a seeded permutation."""
     n, D = x.shape
     rng = np.random.default_rng(seed)
-    cent = x[torch.from_numpy(rng.permutation(n)[:nlist].copy()).to(x.device)].clone().float()
-    for _ in range(iters):
+    cent = x[torch.from_numpy(rng.permutation(n)[:nlist].copy()).to(x.device)].clone().float().contiguous()
+    xt = ops._rows_f32(x)
+    native = x.is_cuda and D % 16 == 0 and D <= 4096 and nlist <= 16384
+    if native:
+        lib, h, s, _ = ops._ctx(xt)
+        wsb = lib.rc_ivf_coarse_update_ws_bytes(n, nlist)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=xt.device)
+    for it in range(iters):
+        if native:
+            assign = coarse_assign(xt, cent, chunk, as_int32=True)
+            _lib.check(lib.rc_ivf_coarse_update(h, C.c_void_p(xt.data_ptr()), xt.stride(0), C.c_void_p(assign.data_ptr()), n, D,
+                                                nlist, C.c_void_p(cent.data_ptr()), None, seed, it, C.c_void_p(ws.data_ptr()), wsb,
+                                                s), "rc_ivf_coarse_update", h)
+            continue
+        # widths / list counts outside the kernels' range (toy fixtures): the same step with library calls
         assign = coarse_assign(x, cent, chunk)
         sums = torch.zeros_like(cent)
         sums.index_add_(0, assign, x.float())
@@ -42,7 +58,7 @@ def coarse_kmeans(x: torch.Tensor, nlist: int, iters: int = 10, seed: int = 1234
     return cent
 
 
-def coarse_assign(x: torch.Tensor, cent: torch.Tensor, chunk: int = 1 << 20) -> torch.Tensor:
+def coarse_assign(x: torch.Tensor, cent: torch.Tensor, chunk: int = 1 << 20, as_int32: bool = False) -> torch.Tensor:
     """L2-nearest coarse centroid of every row, argmin_l (||c_l||^2 - 2 <x, c_l>), first minimum: the fp32-MFMA
     GEMM + fused argmin of csrc/ivf_search.hip (rc_ivf_coarse_assign); the [n, nlist] scores are never materialised."""
     ops._need_cuda(x, cent)
@@ -65,7 +81,7 @@ def coarse_assign(x: torch.Tensor, cent: torch.Tensor, chunk: int = 1 << 20) -> 
         part = xt[i:i + chunk]
         _lib.check(lib.rc_ivf_coarse_assign(h, p(part), xt.stride(0), p(cent), part.shape[0], D, nlist,
                                             C.c_void_p(out.data_ptr() + 4 * i), p(ws), wsb, s), "rc_ivf_coarse_assign", h)
-    return out.to(torch.int64)
+    return out if as_int32 else out.to(torch.int64)
 
 
 class IVFPQIndex:

@@ -1780,6 +1780,56 @@ def test_kmeans_statistics_are_the_correctly_rounded_sums_whatever_was_called_be
         assert np.array_equal(cnt2.cpu().numpy(), pq_oracle.kmeans_stats(x2, c2, M2)[1])
 
 
+def test_ivf_coarse_update_is_the_fp64_mean_in_row_order_and_deterministic():
+    """rc_ivf_coarse_update (Lloyd step of the coarse quantiser, BASELINE configs[3]): every cell's centroid is the fp32 of
+    the fp64 mean of its rows added in ASCENDING row order (a numpy restatement of exactly that), the same bits on every
+    call; empty cells take a row of x; out-of-range assignments are ignored; coarse_kmeans runs on it end to end."""
+    import ctypes as C
+    from repconc_amd import _lib, ops
+    from repconc_amd.ivf import coarse_assign, coarse_kmeans
+    n, D, nlist = 30011, 768, 700
+    x = synth.gaussian(808, (n, D))
+    rng = np.random.default_rng(809)
+    assign = rng.integers(0, nlist - 40, n).astype(np.int32)              # the last 40 cells stay empty
+    assign[rng.integers(0, n, 50)] = -1                                    # ignored rows
+    assign[:5000] = 3                                                      # one big cell (several tiles)
+    xt, at = _t(x), _t(assign)
+    lib, h, s, _ = ops._ctx(xt)
+    wsb = lib.rc_ivf_coarse_update_ws_bytes(n, nlist)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        cent = torch.zeros((nlist, D), dtype=torch.float32, device=DEV)
+        cnt = torch.zeros((nlist,), dtype=torch.int32, device=DEV)
+        _lib.check(lib.rc_ivf_coarse_update(h, C.c_void_p(xt.data_ptr()), xt.stride(0), C.c_void_p(at.data_ptr()), n, D, nlist,
+                                            C.c_void_p(cent.data_ptr()), C.c_void_p(cnt.data_ptr()), 1234, 7,
+                                            C.c_void_p(ws.data_ptr()), wsb, s), "rc_ivf_coarse_update", h)
+        outs.append((cent.cpu().numpy(), cnt.cpu().numpy()))
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    got, gcnt = outs[0]
+    want_cnt = np.bincount(assign[assign >= 0], minlength=nlist)
+    assert np.array_equal(gcnt, want_cnt)
+    x64 = x.astype(np.float64)
+    for c in list(range(0, 12)) + [3, nlist - 41]:
+        rows = np.nonzero(assign == c)[0]                                  # ascending
+        acc = np.zeros(D)
+        for r in rows:
+            acc = acc + x64[r]
+        assert np.array_equal(got[c].view(np.uint32), (acc / len(rows)).astype(np.float32).view(np.uint32)), c
+    xs = {row.tobytes() for row in x}
+    for c in range(nlist - 40, nlist):                                     # empty cells: some row of x, not zeros
+        assert got[c].tobytes() in xs
+    # end to end: the k-means built on it improves the quantisation error and is reproducible
+    x2 = synth.clustered_embeddings(810, 20000)
+    c_a = coarse_kmeans(_t(x2), 256, iters=5)
+    c_b = coarse_kmeans(_t(x2), 256, iters=5)
+    assert torch.equal(c_a, c_b)
+    def err(cc):
+        a = coarse_assign(_t(x2), cc)
+        return float(((_t(x2) - cc[a]) ** 2).sum(1).mean())
+    assert err(c_a) < 0.8 * err(coarse_kmeans(_t(x2), 256, iters=0))
+
+
 @pytest.mark.parametrize("M", [16, 32, 48, 64])
 def test_ivf_list_centric_search_equals_per_query_scan(M):
     """rc_ivf_search_lists (cells scanned once per group of up to 8 probing queries, 8-bit screen + exact rescoring) against
