@@ -545,7 +545,27 @@ def main():
         cells_c = coarse_assign(xc, ivf.coarse)
         torch.cuda.synchronize()
         cdt = time.perf_counter() - t0
-        del xc
+        # the other half of a Lloyd iteration of the coarse quantiser: centroid update (rc_ivf_coarse_update)
+        import ctypes as _C
+        cu_lib, cu_h = _lib.load(), _lib.handle(dev.index)
+        cu_ws = torch.empty((cu_lib.rc_ivf_coarse_update_ws_bytes(1 << 18, nlist),), dtype=torch.uint8, device=dev)
+        cu_cent = ivf.coarse.clone()
+        cu_assign = cells_c.to(torch.int32)
+        cu_s = _C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        def _coarse_update():
+            _lib.check(cu_lib.rc_ivf_coarse_update(cu_h, _C.c_void_p(xc.data_ptr()), xc.stride(0), _C.c_void_p(cu_assign.data_ptr()),
+                                                   1 << 18, D, nlist, _C.c_void_p(cu_cent.data_ptr()), None, 1234, 0,
+                                                   _C.c_void_p(cu_ws.data_ptr()), cu_ws.numel(), cu_s), "rc_ivf_coarse_update", cu_h)
+        _coarse_update()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            _coarse_update()
+        e1.record()
+        torch.cuda.synchronize()
+        cu_ms = e0.elapsed_time(e1) / 5
+        del xc, cu_ws, cu_cent, cu_assign
         codes3 = torch.randint(0, 256, (N_CORPUS, M3), dtype=torch.uint8, device=dev, generator=g3)
         ivf.set_lists(codes3, torch.randint(0, nlist, (N_CORPUS,), device=dev, generator=g3))
         del codes3
@@ -586,6 +606,12 @@ def main():
                                            "bound": "mfma", "achieved": round(2.0 * (1 << 18) * nlist * D / cdt / 1e12, 2),
                                            "peak": 157.3, "unit": "TFLOP/s",
                                            "frac": round(2.0 * (1 << 18) * nlist * D / cdt / 1e12 / 157.3, 4)}},
+            "coarse_update": {"ms": round(cu_ms, 4), "rows": 1 << 18, "value": round((1 << 18) / cu_ms * 1e3, 1), "unit": "vectors/s",
+                              "roofline": {"kernel": "ivfc_cell_mean_kernel (+ stable counting sort: tile histograms, scan, scatter)",
+                                           "bound": "hbm", "achieved": round((1 << 18) * D * 4 / cu_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": round((1 << 18) * D * 4 / cu_ms / 1e6 / HBM_PEAK_GBS, 4)},
+                              "note": "centroid update of one Lloyd iteration of the coarse quantiser, 4 D bytes per row; the "
+                                      "whole rc_ivf_coarse_update call (4 kernels), HIP events around 5 calls"},
             "roofline": {"kernel": "ivfs_screen_kernel<96, 4> (list-centric: one persistent block per CU walks (cell, <= 8 probing "
                                    "queries) tasks; 64 KiB table phases of 32 sub-quantisers in two LDS buffers, four loader waves fetch and "
                                    "byte-transpose the next phase's tables into the other buffer while twelve waves gather; conflict-free "

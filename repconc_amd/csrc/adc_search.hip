@@ -42,6 +42,7 @@
 
 #define ADC_THREADS 1024
 #define ADC_SAMPLE_MAX 32768
+#define ADC_KTH_LIST 4096            // members of the selected value bin kept in LDS by adc_kth_largest_v
 #define ADC_CAND_CAP 16384
 #define ADC_TILE_DOCS 32768
 #ifndef RC_ADC_IMG16
@@ -97,6 +98,118 @@ __device__ __forceinline__ void adc_pick_bin(const unsigned* hist, unsigned need
         }
     }
     __syncthreads();
+}
+
+// rank-th largest of n 32-bit keys (key_at(i), i < n; rank in [1, n]) by radix select, 8 bits per pass — but only over the
+// bits in which the keys DIFFER: a block min / max first, the common leading bits are the result's.  Scores of one query's
+// candidates share their sign / exponent byte (often the next one too): a pass over such a byte sends every key to ONE
+// histogram bin, i.e. n LDS atomics on one address, one after the other (round 3: two of the four passes of the 32 768-key
+// threshold kernel, ~100 of its 130 us per 1200 queries).  Called by every thread of a block of >= 256 threads; `hist`
+// [256], `s_scan` [4], `s_sel` [2], `s_mm` [2] in LDS.
+template <typename KeyAt>
+__device__ __forceinline__ unsigned adc_kth_largest(KeyAt key_at, int64_t n, unsigned rank, unsigned* hist, unsigned* s_scan,
+                                                    unsigned* s_sel, unsigned* s_mm) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; }
+    __syncthreads();
+    unsigned mn = 0xFFFFFFFFu, mx = 0u;
+    for (int64_t i = tid; i < n; i += nthr) {
+        const unsigned k = key_at(i);
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned a = (unsigned)__shfl_xor((int)mn, o), b = (unsigned)__shfl_xor((int)mx, o);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((tid & 63) == 0) { atomicMin(&s_mm[0], mn); atomicMax(&s_mm[1], mx); }
+    __syncthreads();
+    const unsigned lo = s_mm[0], hi_key = s_mm[1];
+    if (lo == hi_key) return hi_key;                          // all keys equal (block-uniform)
+    const int top = 31 - __clz((int)(lo ^ hi_key));          // highest bit in which two keys differ
+    int undecided = top + 1;                                  // bits [0, undecided)
+    if (tid == 0) { s_sel[0] = hi_key & ~((2u << top) - 1u); s_sel[1] = rank; }
+    __syncthreads();
+    while (undecided > 0) {
+        const int width = undecided < 8 ? undecided : 8, shift = undecided - width;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_sel[0], need = s_sel[1];
+        const unsigned himask = undecided >= 32 ? 0u : (0xFFFFFFFFu << undecided), dmask = (1u << width) - 1u;
+        for (int64_t i = tid; i < n; i += nthr) {
+            const unsigned k = key_at(i);
+            if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        adc_pick_bin(hist, need, prefix, shift, s_scan, &s_sel[0], &s_sel[1]);
+        undecided = shift;
+    }
+    return s_sel[0];
+}
+
+// The same answer, faster on real score distributions: bit-radix passes see a float's sign / exponent structure — a
+// near-Gaussian sample puts half of its keys into one or two bins of the first pass whatever window of bits it uses
+// (measured: skipping the common leading bits alone made the kernels SLOWER, the min / max pass cost more than it saved).
+// So the first cut is made in VALUE space: 256 equal bins over [min, max] of the scores (a monotone function of the key:
+// bin(s) = min(255, int((s - smin) scale)), so "the bin that holds the rank-th largest" is well defined) — the fullest bin of
+// a Gaussian sample holds ~1.3 % of it — then the members of that one bin (a few dozen in the tail where the thresholds
+// live) are collected into `list` and the bit-radix select above runs on them.  Non-finite extremes, a degenerate range or
+// a bin longer than list_cap: the plain bit-radix select over everything.  `s_aux`: 8 words of LDS.
+// MM_READY: the caller has already reduced the keys' minimum / maximum into s_aux[2] / s_aux[3] (e.g. while loading them),
+// zeroed hist and s_aux[4], and synchronised.
+template <bool MM_READY = false, typename KeyAt>
+__device__ __forceinline__ unsigned adc_kth_largest_v(KeyAt key_at, int64_t n, unsigned rank, unsigned* hist, unsigned* s_scan,
+                                                      unsigned* s_aux, unsigned* list, int list_cap) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    unsigned* s_sel = s_aux, *s_mm = s_aux + 2, *s_cnt = s_aux + 4;
+    if constexpr (!MM_READY) {
+        if (tid == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; *s_cnt = 0u; }
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        unsigned mn = 0xFFFFFFFFu, mx = 0u;
+        for (int64_t i = tid; i < n; i += nthr) {
+            const unsigned k = key_at(i);
+            mn = k < mn ? k : mn;
+            mx = k > mx ? k : mx;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned a = (unsigned)__shfl_xor((int)mn, o), b = (unsigned)__shfl_xor((int)mx, o);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        if ((tid & 63) == 0) { atomicMin(&s_mm[0], mn); atomicMax(&s_mm[1], mx); }
+        __syncthreads();
+    }
+    const unsigned lo = s_mm[0], hi_key = s_mm[1];
+    if (lo == hi_key) return hi_key;
+    const float smin = adc_unorder_key(lo), smax = adc_unorder_key(hi_key);
+    const float scale = 256.0f / (smax - smin);
+    const bool linear = (smin - smin == 0.f) && (smax - smax == 0.f) && (scale - scale == 0.f);     // all finite (block-uniform)
+    if (!linear) {
+        __syncthreads();
+        return adc_kth_largest(key_at, n, rank, hist, s_scan, s_sel, s_mm);
+    }
+    auto bin_of = [&](unsigned k) {
+        const int b = (int)((adc_unorder_key(k) - smin) * scale);
+        return b > 255 ? 255 : b;
+    };
+    for (int64_t i = tid; i < n; i += nthr) atomicAdd(&hist[bin_of(key_at(i))], 1u);
+    __syncthreads();
+    adc_pick_bin(hist, rank, 0u, 0, s_scan, &s_sel[0], &s_sel[1]);    // s_sel[0] = bin, s_sel[1] = rank inside it (ends in a barrier)
+    const int b = (int)s_sel[0];
+    const unsigned inside = s_sel[1], members = hist[b];
+    __syncthreads();
+    if ((int)members > list_cap)
+        return adc_kth_largest(key_at, n, rank, hist, s_scan, s_sel, s_mm);
+    for (int64_t i = tid; i < n; i += nthr) {
+        const unsigned k = key_at(i);
+        if (bin_of(k) == b) list[atomicAdd(s_cnt, 1u)] = k;
+    }
+    __syncthreads();
+    return adc_kth_largest([&](int64_t i) { return list[i]; }, (int64_t)members, inside, hist, s_scan, s_sel, s_mm);
 }
 
 // ------------------------------------------------------------------------------------------ 1. LUT
@@ -253,30 +366,35 @@ __global__ __launch_bounds__(1024) void adc_threshold_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* keys = reinterpret_cast<unsigned*>(smem);  // [S]
     __shared__ unsigned hist[256];
-    __shared__ unsigned sel_prefix, sel_rank;
+    __shared__ unsigned s_aux[8];
     __shared__ unsigned s_scan[4];
+    __shared__ unsigned s_list[ADC_KTH_LIST];
     const int qi = blockIdx.x, tid = threadIdx.x;
     if (r <= 0 || r > S) {
         if (tid == 0) thr[qi] = -INFINITY;
         return;
     }
-    for (int64_t i = tid; i < S; i += 1024) keys[i] = adc_order_key(sample[(size_t)qi * S + i]);
-    if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)r; }
+    if (tid == 0) { s_aux[2] = 0xFFFFFFFFu; s_aux[3] = 0u; s_aux[4] = 0u; }
+    if (tid < 256) hist[tid] = 0u;
     __syncthreads();
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0u;
-        __syncthreads();
-        const unsigned prefix = sel_prefix;
-        const unsigned himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int64_t i = tid; i < S; i += 1024) {
-            const unsigned k = keys[i];
-            if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
-        }
-        __syncthreads();
-        adc_pick_bin(hist, sel_rank, prefix, shift, s_scan, &sel_prefix, &sel_rank);
+    unsigned mn = 0xFFFFFFFFu, mx = 0u;                       // minimum / maximum on the way into the LDS
+    for (int64_t i = tid; i < S; i += 1024) {
+        const unsigned k = adc_order_key(sample[(size_t)qi * S + i]);
+        keys[i] = k;
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
     }
-    if (tid == 0) thr[qi] = adc_unorder_key(sel_prefix);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned a = (unsigned)__shfl_xor((int)mn, o), b = (unsigned)__shfl_xor((int)mx, o);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((tid & 63) == 0) { atomicMin(&s_aux[2], mn); atomicMax(&s_aux[3], mx); }
+    __syncthreads();
+    const unsigned kth = adc_kth_largest_v<true>([&](int64_t i) { return keys[i]; }, S, (unsigned)r, hist, s_scan, s_aux, s_list,
+                                                 ADC_KTH_LIST);
+    if (tid == 0) thr[qi] = adc_unorder_key(kth);
 }
 
 // ---- bitonic sort of P keys (descending) in LDS, register-blocked ----------------------------------------------------
@@ -378,27 +496,16 @@ __global__ __launch_bounds__(1024) void adc_select_kernel(unsigned long long* __
         }
     }
     __shared__ unsigned hist[256];
-    __shared__ unsigned sel_prefix, sel_rank, survivors;
+    __shared__ unsigned s_aux[8], survivors;
     __shared__ unsigned s_scan[4];
     int n = cnt;
     bool in_lds = cnt <= cap;                                 // block-uniform
     if ((cnt > 2048 && cnt > 2 * k) || !in_lds) {
-        if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)(k < cnt ? k : cnt); survivors = 0u; }
+        if (tid == 0) survivors = 0u;
+        // k-th largest score key (barriers inside); the bin list borrows the (still unused) key buffer
+        const unsigned kth = adc_kth_largest_v([&](int64_t i) { return (unsigned)(gk[i] >> 32); }, cnt, (unsigned)(k < cnt ? k : cnt),
+                                               hist, s_scan, s_aux, reinterpret_cast<unsigned*>(lk), 2 * cap);
         __syncthreads();
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            if (tid < 256) hist[tid] = 0u;
-            __syncthreads();
-            const unsigned prefix = sel_prefix;
-            const unsigned himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
-            for (int i = tid; i < cnt; i += nthr) {
-                const unsigned sk = (unsigned)(gk[i] >> 32);
-                if ((sk & himask) == prefix) atomicAdd(&hist[(sk >> shift) & 0xFFu], 1u);
-            }
-            __syncthreads();
-            adc_pick_bin(hist, sel_rank, prefix, shift, s_scan, &sel_prefix, &sel_rank);
-        }
-        const unsigned kth = sel_prefix;                      // k-th largest score key
         for (int i = tid; i < cnt; i += nthr) {
             const unsigned long long key = gk[i];
             if ((unsigned)(key >> 32) >= kth) {
@@ -3282,7 +3389,7 @@ __global__ __launch_bounds__(1024) void ivf_rank_select_kernel(const float* __re
                                                                float* __restrict__ thr, const float* __restrict__ qstat = nullptr,
                                                                int M = 0, int* __restrict__ tint = nullptr) {
     __shared__ unsigned hist[256];
-    __shared__ unsigned sel_prefix, sel_rank;
+    __shared__ unsigned s_aux[8];
     __shared__ unsigned s_scan[4];
     const int qi = blockIdx.x, tid = threadIdx.x;
     const int n = scount[qi], k = rank[qi];
@@ -3293,24 +3400,28 @@ __global__ __launch_bounds__(1024) void ivf_rank_select_kernel(const float* __re
         }
         return;
     }
+    // a few thousand scores in global memory: four plain passes (the value-space cut of adc_kth_largest_v costs more barriers
+    // and one more pass than it saves at this length: 18 -> 26 us per 1200 queries at nprobe 8)
     const float* row = sample + (size_t)qi * sstride;
-    if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)k; }
+    unsigned* s_sel = s_aux;
+    if (tid == 0) { s_sel[0] = 0u; s_sel[1] = (unsigned)k; }
     __syncthreads();
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         if (tid < 256) hist[tid] = 0u;
         __syncthreads();
-        const unsigned prefix = sel_prefix;
+        const unsigned prefix = s_sel[0], need = s_sel[1];
         const unsigned himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
         for (int i = tid; i < n; i += 1024) {
             const unsigned key = adc_order_key(row[i]);
             if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFFu], 1u);
         }
         __syncthreads();
-        adc_pick_bin(hist, sel_rank, prefix, shift, s_scan, &sel_prefix, &sel_rank);
+        adc_pick_bin(hist, need, prefix, shift, s_scan, &s_sel[0], &s_sel[1]);
     }
+    const unsigned kth = s_sel[0];
     if (tid == 0) {
-        const float t = adc_unorder_key(sel_prefix);
+        const float t = adc_unorder_key(kth);
         thr[qi] = t;
         if (tint) tint[qi] = adc_tint_from(t, qstat + (size_t)qi * ADC_QSTAT_STRIDE, M);
     }
