@@ -3065,6 +3065,7 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
         bsel[2 + (r >> 2)] = one;
     }
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+    if (lds0 & 0xFFFFu) __builtin_trap();                    // the one-instruction gather address needs 64 KiB-aligned table buffers
     adc_i32x4v acc[R];
     // ---- gathers + folds of one stage
     auto gathers = [&](auto PMc, bool first, const unsigned (&w)[R][2], unsigned bufoff, int reff) {
@@ -3084,8 +3085,8 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
         auto gather = [&](int c, int hh, uint2 (&e)[4]) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                unsigned addr;
-                asm("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_add_u32 %0, %0, 8, %3" : "=&v"(addr) : "v"(w[c][hh]), "n"(8 * s4), "v"(off[4 * hh + s4]));
+                // buffer base (0 / 64 KiB: bytes 2-3) | code << 8 | slot offset (< 256): one v_perm_b32 (see the 16-query screen)
+                const unsigned addr = __builtin_amdgcn_perm(w[c][hh], off[4 * hh + s4], 0x03020000u | ((4u + (unsigned)s4) << 8));
                 typedef unsigned adc_u32x2 __attribute__((ext_vector_type(2)));
                 const adc_u32x2 v = *reinterpret_cast<const adc_u32x2 __attribute__((address_space(3)))*>(addr);
                 e[s4] = make_uint2(v.x, v.y);
