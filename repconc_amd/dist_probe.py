@@ -32,6 +32,55 @@ def main() -> int:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    if "--exchange" in sys.argv:
+        # first-contact mode (tools/first_contact.py): the exchange layer alone, with NAMED failure reasons as exit codes —
+        # 3 = set-up (export / IPC open / communicator) failed on some rank, 4 = a peer's data did not arrive intact,
+        # 5 = an exchange timed out (RC_FLAG_COMM) — and, on success, one JSON line from rank 0 with the time of one
+        # all-gather of a chain's [M/2, K] fp64 row sums (the solve's exchange unit)
+        import json
+        from . import _lib, ops
+        os.environ["RC_COMM_STRICT"] = "1"
+        try:
+            kind = ops.comm_init(transport=os.environ.get("RC_COMM", "ipc"))
+        except Exception as e:                                  # collective: every rank lands here together
+            if rank == 0:
+                print(json.dumps({"ok": False, "reason": f"set-up failed: {e}"}), flush=True)
+            dist.destroy_process_group()
+            return 3
+        code = 0
+        for n in (24 * 256, 7, 1 << 18):                      # a chain's row sums, an odd size, several slots
+            mine = (torch.arange(n, device=dev, dtype=torch.float64) * 1e-3 + (rank + 1) * 1000.0)
+            got = ops.comm_allgather(mine)
+            want = torch.stack([torch.arange(n, device=dev, dtype=torch.float64) * 1e-3 + (r + 1) * 1000.0 for r in range(world)])
+            if not torch.equal(got, want):
+                code = 4
+        rows_ = torch.zeros((24, 256), dtype=torch.float64, device=dev)
+        for _ in range(20):
+            ops.comm_allgather(rows_)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            ops.comm_allgather(rows_)
+        e1.record()
+        torch.cuda.synchronize()
+        try:
+            ops.comm_check()
+        except _lib.RepconcHipError:
+            code = 5
+        flag = torch.tensor([code], dtype=torch.int32, device=torch.device("cpu") if share else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        code = int(flag.item())
+        if rank == 0:
+            print(json.dumps({"ok": code == 0, "transport": kind, "alloc": os.environ.get("RC_IPC_ALLOC", "finegrained"),
+                              "world": world, "devices": 1 if share else world,
+                              "us_per_allgather": round(e0.elapsed_time(e1) * 1e3 / 200, 2),
+                              "reason": {0: None, 4: "a peer's data did not arrive intact (store visibility)",
+                                         5: "an exchange timed out (RC_FLAG_COMM)"}[code]}), flush=True)
+        ops.comm_destroy()
+        dist.destroy_process_group()
+        return code
     rng = np.random.default_rng(4242)
     M, K, D, rows = 48, 256, 768, 512
     x = rng.standard_normal((rows * world, D), dtype=np.float32)

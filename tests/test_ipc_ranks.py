@@ -111,3 +111,19 @@ def test_bench_gpus2_typed_as_is_on_a_shared_gpu():
     chk = d["multi_gpu_check"]
     assert chk["sharded_equals_unsharded"] is True and chk["transport"] in ("ipc", "rccl") and chk["native_equals_staged"] is True
     assert d["exchange"]["us_per_allgather"] > 0
+
+
+def test_first_contact_tool_walks_every_transport_on_the_shared_gpu():
+    """tools/first_contact.py — the command for the first run on a multi-GPU node — on this box: every IPC allocation kind
+    sets up, moves intact data and is timed (with >= 2 GPUs it runs one rank per GPU and RCCL too); a broken candidate is
+    named, not hung on."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "first_contact.py"), "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    table = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert table["ipc/finegrained"]["ok"] and table["ipc/finegrained"]["us_per_allgather"] > 0
+    assert all(v["ok"] or v["reason"] for v in table.values())
