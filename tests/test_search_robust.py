@@ -220,9 +220,10 @@ def test_ivf_survivor_stream_overflow_is_answered_not_raised(monkeypatch):
     assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
 
 
-def test_round2_ivf_screen_stays_selectable(tmp_path):
-    """RC_IVF_PIPE=0 (read once per process) selects the round-2 IVF screen and its row-major image — the A/B partner of the
-    pipelined screen in DESIGN 7: a fresh process built that way returns the same ids and score bits."""
+def test_ivf_list_search_equals_the_per_query_scan_in_a_fresh_process(tmp_path):
+    """The list-centric search (pipelined 8-bit screen) against the per-query exact scan — two independent code paths of the
+    library — in a fresh process: same ids and score bits.  (Round 3 compared it with the round-2 IVF screen, RC_IVF_PIPE=0,
+    which round 4 removed together with the other superseded screen generations.)"""
     import os
     import subprocess
     import sys
@@ -238,16 +239,16 @@ def test_round2_ivf_screen_stays_selectable(tmp_path):
         "ivf.set_centroids(torch.from_numpy(synth.gaussian(1, (M, 256, 768 // M))).cuda())\n"
         "ivf.coarse = torch.from_numpy(synth.gaussian(2, (nlist, 768))).cuda()\n"
         "ivf.set_lists(torch.from_numpy(synth.uniform_codes(3, N, M)).cuda(), torch.from_numpy(rng.integers(0, nlist, N)).cuda())\n"
-        "s, i = ivf.search(torch.from_numpy(synth.gaussian(4, (nq, 768))).cuda(), k, 12, method='lists')\n"
+        "s, i = ivf.search(torch.from_numpy(synth.gaussian(4, (nq, 768))).cuda(), k, 12, method=sys.argv[3])\n"
         "np.save(sys.argv[1], i.cpu().numpy()); np.save(sys.argv[2], s.cpu().numpy())\n")
     got = {}
-    for pipe in ("1", "0"):
-        fi, fs = str(tmp_path / f"i{pipe}.npy"), str(tmp_path / f"s{pipe}.npy")
-        env = dict(os.environ, RC_IVF_PIPE=pipe)
-        r = subprocess.run([sys.executable, "-c", code, fi, fs], env=env, capture_output=True, text=True, timeout=600)
+    for method in ("lists", "scan"):
+        fi, fs = str(tmp_path / f"i{method}.npy"), str(tmp_path / f"s{method}.npy")
+        r = subprocess.run([sys.executable, "-c", code, fi, fs, method], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        got[pipe] = (np.load(fi), np.load(fs))
-    assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1].view(np.uint32), got["0"][1].view(np.uint32))
+        got[method] = (np.load(fi), np.load(fs))
+    assert np.array_equal(got["lists"][0], got["scan"][0])
+    assert np.array_equal(got["lists"][1].view(np.uint32), got["scan"][1].view(np.uint32))
 
 
 def test_ivf_one_degenerate_query_is_answered_alone(monkeypatch):
