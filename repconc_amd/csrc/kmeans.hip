@@ -719,34 +719,54 @@ __global__ __launch_bounds__(1024) void ivfc_scatter_kernel(const int* __restric
     }
 }
 
-// grid nlist, block D / 4 threads (one float4 column group each; D % 4 == 0, D <= 4096)
+// grid nlist, block (D / 4, IVFC_RL): thread (j4, rl) sums the float4 column group j4 of the cell's rows i = rl, rl + RL, ...
+// (ascending) in fp64, IVFC_U of them in flight; the RL partial sums are added in the order ((p0 + p1) + p2) + p3.  The order
+// is a function of the cell's rows alone, so the result does not depend on the launch.  (One row at a time per cell made a
+// 2000-row cell a chain of 500 dependent HBM round trips: 1.3 ms for a skewed 5000-cell assignment of 2^18 rows.)
+#define IVFC_RL 4
+#define IVFC_U 8
 __global__ __launch_bounds__(1024) void ivfc_cell_mean_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int D,
                                                               const unsigned* __restrict__ perm, const unsigned* __restrict__ start,
                                                               const unsigned* __restrict__ count, float* __restrict__ cent,
                                                               unsigned long long seed, int iter) {
-    const int c = blockIdx.x, j4 = threadIdx.x;
+    extern __shared__ double ivfc_part[];                    // [RL - 1][D]
+    const int c = blockIdx.x, j4 = threadIdx.x, rl = threadIdx.y;
     const unsigned cnt = count[c], s0 = start[c];
     float4* out = reinterpret_cast<float4*>(cent + (size_t)c * D) + j4;
     if (cnt == 0u) {                                         // empty cell: a counter-based random row
-        const int64_t r = (int64_t)(ivfc_mix(seed ^ ivfc_mix(((unsigned long long)(unsigned)iter << 32) | (unsigned)c)) % (unsigned long long)n);
-        *out = *(reinterpret_cast<const float4*>(x + r * ldx) + j4);
+        if (rl == 0) {
+            const int64_t r = (int64_t)(ivfc_mix(seed ^ ivfc_mix(((unsigned long long)(unsigned)iter << 32) | (unsigned)c)) % (unsigned long long)n);
+            *out = *(reinterpret_cast<const float4*>(x + r * ldx) + j4);
+        }
         return;
     }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    unsigned i = 0;
-    for (; i + 4 <= cnt; i += 4) {                            // four rows in flight, added in ascending order
-        float4 v[4];
+    unsigned i = (unsigned)rl;
+    for (; i + (IVFC_U - 1) * IVFC_RL < cnt; i += IVFC_U * IVFC_RL) {
+        float4 v[IVFC_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(reinterpret_cast<const float4*>(x + (int64_t)perm[s0 + i + u] * ldx) + j4);
+        for (int u = 0; u < IVFC_U; ++u) v[u] = *(reinterpret_cast<const float4*>(x + (int64_t)perm[s0 + i + u * IVFC_RL] * ldx) + j4);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
+        for (int u = 0; u < IVFC_U; ++u) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
     }
-    for (; i < cnt; ++i) {
+    for (; i < cnt; i += IVFC_RL) {
         const float4 v = *(reinterpret_cast<const float4*>(x + (int64_t)perm[s0 + i] * ldx) + j4);
         a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
     }
-    const double inv = (double)cnt;
-    *out = make_float4((float)(a0 / inv), (float)(a1 / inv), (float)(a2 / inv), (float)(a3 / inv));
+    if (rl > 0) {
+        double* p = ivfc_part + ((size_t)(rl - 1) * D + 4 * j4);
+        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3;
+    }
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int r = 1; r < IVFC_RL; ++r) {
+            const double* p = ivfc_part + ((size_t)(r - 1) * D + 4 * j4);
+            a0 += p[0]; a1 += p[1]; a2 += p[2]; a3 += p[3];
+        }
+        const double inv = (double)cnt;
+        *out = make_float4((float)(a0 / inv), (float)(a1 / inv), (float)(a2 / inv), (float)(a3 / inv));
+    }
 }
 
 extern "C" size_t rc_ivf_coarse_update_ws_bytes(int64_t n, int nlist) {
@@ -763,7 +783,7 @@ extern "C" int rc_ivf_coarse_update(rc_handle_t h, const float* x, int64_t ldx, 
                                     rc_stream_t stream) {
     rc_device_guard device_guard_(h);
     if (!h || !x || !assign || !cent || n <= 0 || D <= 0 || nlist <= 0 || ldx < D) return RC_EINVAL;
-    if (D % 4 != 0 || D > 4096 || nlist > 16384 || n > 0xFFFFFFFFll || (ldx % 4) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)cent & 15))
+    if (D % 4 != 0 || D > 1024 || nlist > 16384 || n > 0xFFFFFFFFll || (ldx % 4) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)cent & 15))
         return RC_ESHAPE;
     if (!ws || ws_bytes < rc_ivf_coarse_update_ws_bytes(n, nlist)) return RC_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -784,8 +804,9 @@ extern "C" int rc_ivf_coarse_update(rc_handle_t h, const float* x, int64_t ldx, 
     hipLaunchKernelGGL(ivfc_scatter_kernel, dim3((unsigned)tiles), dim3(1024), 0, s, assign, n, nlist, (const unsigned*)hist,
                        (const unsigned*)start, perm);
     RC_LAUNCH_CHECK(h);
-    hipLaunchKernelGGL(ivfc_cell_mean_kernel, dim3((unsigned)nlist), dim3((unsigned)(D / 4)), 0, s, x, ldx, n, D, (const unsigned*)perm,
-                       (const unsigned*)start, (const unsigned*)count, cent, (unsigned long long)seed, iter);
+    hipLaunchKernelGGL(ivfc_cell_mean_kernel, dim3((unsigned)nlist), dim3((unsigned)(D / 4), IVFC_RL), (size_t)(IVFC_RL - 1) * D * sizeof(double),
+                       s, x, ldx, n, D, (const unsigned*)perm, (const unsigned*)start, (const unsigned*)count, cent, (unsigned long long)seed,
+                       iter);
     RC_LAUNCH_CHECK(h);
     if (counts_out) RC_HIP_CHECK(h, hipMemcpyAsync(counts_out, count, (size_t)nlist * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
     return RC_OK;

@@ -33,7 +33,7 @@ def coarse_kmeans(x: torch.Tensor, nlist: int, iters: int = 10, seed: int = 1234
     rng = np.random.default_rng(seed)
     cent = x[torch.from_numpy(rng.permutation(n)[:nlist].copy()).to(x.device)].clone().float().contiguous()
     xt = ops._rows_f32(x)
-    native = x.is_cuda and D % 16 == 0 and D <= 4096 and nlist <= 16384
+    native = x.is_cuda and D % 16 == 0 and D <= 1024 and nlist <= 16384
     if native:
         lib, h, s, _ = ops._ctx(xt)
         wsb = lib.rc_ivf_coarse_update_ws_bytes(n, nlist)

@@ -1782,7 +1782,7 @@ def test_kmeans_statistics_are_the_correctly_rounded_sums_whatever_was_called_be
 
 def test_ivf_coarse_update_is_the_fp64_mean_in_row_order_and_deterministic():
     """rc_ivf_coarse_update (Lloyd step of the coarse quantiser, BASELINE configs[3]): every cell's centroid is the fp32 of
-    the fp64 mean of its rows added in ASCENDING row order (a numpy restatement of exactly that), the same bits on every
+    the fp64 mean of its rows added in a fixed order (four interleaved lanes, each ascending; a numpy restatement of exactly that), the same bits on every
     call; empty cells take a row of x; out-of-range assignments are ignored; coarse_kmeans runs on it end to end."""
     import ctypes as C
     from repconc_amd import _lib, ops
@@ -1812,9 +1812,13 @@ def test_ivf_coarse_update_is_the_fp64_mean_in_row_order_and_deterministic():
     x64 = x.astype(np.float64)
     for c in list(range(0, 12)) + [3, nlist - 41]:
         rows = np.nonzero(assign == c)[0]                                  # ascending
-        acc = np.zeros(D)
-        for r in rows:
-            acc = acc + x64[r]
+        parts = []
+        for lane in range(4):                                              # four interleaved row lanes, each ascending
+            acc = np.zeros(D)
+            for r in rows[lane::4]:
+                acc = acc + x64[r]
+            parts.append(acc)
+        acc = ((parts[0] + parts[1]) + parts[2]) + parts[3]
         assert np.array_equal(got[c].view(np.uint32), (acc / len(rows)).astype(np.float32).view(np.uint32)), c
     xs = {row.tobytes() for row in x}
     for c in range(nlist - 40, nlist):                                     # empty cells: some row of x, not zeros
