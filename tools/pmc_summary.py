@@ -13,6 +13,7 @@ ALG = {  # SURVEY 8(d) per-unit bytes x units per launch
     "sk_sweep_kernel": ("sk_sweep2_kernel<2, true>", B * M * K * 4),
     "adc_screen_q16_kernel": ("adc_screen_q16_kernel<48>", NQ * NC * M),
     "assign_mfma_kernel": ("assign_mfma_kernel<16>", NB * (768 * 4 + M)),
+    "kmeans_stats_fx_kernel": ("kmeans_stats_fx_kernel<0, 8>", NB * (768 * 4 + M)),   # the 2^20-row launches (the mean also holds the 65 536-row ones)
 }
 out = {"_how": "tools/pmc_collect.sh: rocprofv3 --pmc <group> --kernel-trace, one pass per counter group, over "
                "`python bench.py --steps 1 --warmup 1 --no-cpu --no-per-rank --no-opq --adc-batches 1`; means per launch. FETCH_SIZE/WRITE_SIZE are "
