@@ -955,13 +955,9 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
                 // ONE v_perm_b32 from the code word and the lane's slot constant (round 3: v_bfe_u32 + v_lshl_add_u32).  The
                 // dynamic LDS of this kernel starts at address 0 (no static __shared__), checked once per block below.
                 const unsigned addr = __builtin_amdgcn_perm(wc, offb[j], 0x03020000u | ((4u + (unsigned)j) << 8));
-#ifdef RC_Q16_ASM_GATHER
                 // issued by hand so that the wait can be counted by hand (gather_wait): the compiler's own bookkeeping waits
                 // for lgkmcnt(0) before a chunk's first MFMA, i.e. also for the next chunk's gathers it has just issued
                 asm volatile("ds_read_b128 %0, %1" : "=v"(e[j]) : "v"(addr));
-#else
-                e[j] = *reinterpret_cast<const adc_u32x4v __attribute__((address_space(3)))*>(addr);
-#endif
             }
         };
         const bool first = (it % NPH == 0);                   // block-uniform: the round's first step starts from zero
@@ -970,24 +966,15 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
         // LDS reads return in order: with `newer` gathers issued after this chunk's four, lgkmcnt(newer) means these four have
         // landed (any other outstanding LDS / scalar operation only makes the wait longer, never shorter than needed)
         auto gather_wait = [&](adc_u32x4v (&e)[4], bool more_in_flight) {
-#ifdef RC_Q16_ASM_GATHER
             if (more_in_flight) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
-#else
-            (void)e; (void)more_in_flight;
-#endif
         };
         auto fold = [&](int c, const adc_u32x4v (&e)[4]) {
             if constexpr (!PACK) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const adc_i32x4v a = {(int)e[j][0], (int)e[j][1], (int)e[j][2], (int)e[j][3]};
-#ifdef RC_Q16_ZERO_INIT
                     acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
-#else
-                    if (j == 0 && first) acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, adc_i32x4v{0, 0, 0, 0}, 0, 0, 0);
-                    else acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
-#endif
                 }
             } else {
                 // the chunk's sums live as two int16 pairs between phases: unpacked into the first MFMA's C, packed again after
@@ -1009,14 +996,15 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
                 }
             }
         };
-#ifdef RC_Q16_ZERO_INIT
+        // A round's sums start from explicitly cleared accumulators (32 v_mov per 96 gathers): round 3 gave the round's first
+        // MFMA a literal-zero C instead, which put a scalar branch into every chunk and the MFMAs into basic blocks of their
+        // own — the loop body is straight-line now (8.62 -> 8.38 ms per 1200 queries at M = 48; with the hand-counted waits 8.26).
         if constexpr (!PACK) {
             if (first) {
 #pragma unroll
                 for (int c = 0; c < R; ++c) acc[c] = adc_i32x4v{0, 0, 0, 0};
             }
         }
-#endif
         gather(0, ea);
 #pragma unroll
         for (int c = 0; c < R; c += 2) {
