@@ -366,6 +366,10 @@ __global__ __launch_bounds__(256) void kmeans_stats_fx_finish_kernel(const long 
     }
 }
 
+__global__ void km_zero_state_kernel(unsigned* __restrict__ state) {
+    if (threadIdx.x < 2) state[threadIdx.x] = 0u;
+}
+
 template <int PASS, int TPR>
 static int km_fx_launch_tpr(rc_handle_t h, int blocks, int nthr, size_t lds, size_t lds_max, hipStream_t s, const float* x,
                             int64_t ldx, const uint8_t* codes, int64_t n, int M, int dsub, int j0, int qpm, int64_t frps, unsigned* state,
@@ -451,7 +455,10 @@ extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const
         const int* hint = h->km_hint + (h->km_calls & 1);
         int* hint_next = h->km_hint + ((h->km_calls + 1) & 1);
         ++h->km_calls;
-        RC_HIP_CHECK(h, hipMemsetAsync(state, 0, 2 * sizeof(unsigned), s));
+        // a kernel store, not hipMemsetAsync: inside a captured hipGraph (the warm-up's Lloyd block) repeated memset nodes
+        // faulted on the graph's second replay (round 4, ROCm 7.0 runtime of the torch wheel)
+        hipLaunchKernelGGL(km_zero_state_kernel, dim3(1), dim3(64), 0, s, state);
+        RC_LAUNCH_CHECK(h);
         const unsigned fin_blocks = (unsigned)((per_strip + 255) / 256);
         for (int pass = 0; pass < 2; ++pass) {
             for (int j0 = 0; j0 < dsub; j0 += KM_FX_JN) {

@@ -133,10 +133,13 @@ struct mf_geom {
 
 // Staged centroids of every sub-quantiser, in the LDS layout of assign_mfma_kernel: grid M, block 256 (thread = centroid).
 template <int DSUB>
-__global__ __launch_bounds__(256) void assign_prep_kernel(const float* __restrict__ C, unsigned char* __restrict__ cpre) {
+__global__ __launch_bounds__(256) void assign_prep_kernel(const float* __restrict__ C, unsigned char* __restrict__ cpre,
+                                                          unsigned* __restrict__ redo_count) {
     using G = mf_geom<DSUB>;
     constexpr int KP = G::KP;
     const int tid = threadIdx.x, m = blockIdx.x, wv = tid >> 6, l = tid & 63;
+    if (m == 0 && tid == 0) *redo_count = 0u;               // the doubt list starts empty (a kernel store, not a memset node: a
+                                                             // hipGraph holding several of these calls faulted on its second replay)
     unsigned char* buf = cpre + (size_t)m * G::BUF_BYTES;
     float4 cst[DSUB / 4];
     const float4* cp = reinterpret_cast<const float4*>(C + ((size_t)m * RC_K + tid) * DSUB);
@@ -572,7 +575,6 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
     unsigned* redo = (unsigned*)((char*)ws + 256);
     const unsigned cap = mf_redo_cap(B, M);
     unsigned char* cpre = (unsigned char*)ws + rc_align_up(256 + (size_t)cap * sizeof(unsigned), 256);
-    RC_HIP_CHECK(h, hipMemsetAsync(redo_count, 0, 256, s));
     const int dsub = D / M;
     const int64_t nblk = (B + MF_ROWS_PER_BLOCK - 1) / MF_ROWS_PER_BLOCK;
     int MC = M;                                     // sub-quantisers per block: split M while the grid is under ~3 blocks per CU
@@ -586,7 +588,7 @@ extern "C" int rc_pq_assign_nearest_fast(rc_handle_t h, const float* x, int64_t 
         case DS: {                                                                                                       \
             auto kern = assign_mfma_kernel<DS>;                                                                          \
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(assign_prep_kernel<DS>, dim3((unsigned)M), dim3(256), 0, s, C, cpre);                     \
+            hipLaunchKernelGGL(assign_prep_kernel<DS>, dim3((unsigned)M), dim3(256), 0, s, C, cpre, redo_count);         \
             hipLaunchKernelGGL(kern, dim3((unsigned)nblk, nchunk), dim3(256), lds, s, x, ldx, C, B, M, codes_u8, codes_i64, \
                                redo_count, redo, cap, MC, (const unsigned char*)cpre);                                       \
             hipLaunchKernelGGL(assign_redo_kernel<DS>, dim3((unsigned)(h->num_cus * (DS <= 32 ? 8 : 4))), dim3(256), 0, s, x, ldx, C, M,  \

@@ -180,6 +180,56 @@ def train_pq(x: torch.Tensor, M: int, n_iter: int, centroids: Optional[torch.Ten
     return C, (mse if mse_on_device else float(mse))
 
 
+class _LloydGraph:
+    """The Lloyd block of one OPQ round — n_iter x (assignment, statistics, update, empty-cluster rule), the final assignment,
+    decode and squared error: ~70 launches of this package's own kernels and a few element-wise ops, no library GEMM — captured
+    once into a hipGraph on static buffers and replayed every round (single rank only: a multi-rank block contains the exchange
+    layer's numbered all-gathers).  Round 3 measured a graph of the Procrustes GEMMs SLOWER than eager calls; kernel nodes are
+    what the Sinkhorn iteration graph already replays well.  The host then issues one launch instead of ~70 per round."""
+
+    def __init__(self, n: int, D: int, M: int, n_iter: int, device):
+        self.xr = torch.empty((n, D), dtype=torch.float32, device=device)
+        self.C = torch.empty((M, 256, D // M), dtype=torch.float32, device=device)
+        self.n_iter = n_iter
+        self.graph = None
+        self.codes = self.xrec = self.err = None
+
+    def _body(self):
+        xr, C = self.xr, self.C
+        for _ in range(self.n_iter):
+            codes = ops.assign_nearest(xr, C, torch.uint8)
+            sums, counts = ops.kmeans_stats(xr, codes)
+            ops.kmeans_update_(sums, counts, C)
+            _reseed_empty(C, counts)
+        self.codes = ops.assign_nearest(xr, C, torch.uint8)
+        self.xrec = ops.decode_raw(self.codes, C)
+        self.err = ((self.xrec - xr) ** 2).sum().double()
+
+    def capture(self):
+        """Warm every allocation / attribute call eagerly on the capture stream, then capture."""
+        side = torch.cuda.Stream(device=self.xr.device)
+        side.wait_stream(torch.cuda.current_stream(self.xr.device))
+        keepC = self.C.clone()
+        with torch.cuda.stream(side):
+            self._body()                                      # eager warm-up (moves C: restored below)
+            self.C.copy_(keepC)
+        torch.cuda.current_stream(self.xr.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            self._body()
+        self.C.copy_(keepC)                                   # capture does not execute, but keep the invariant explicit
+        self.graph = g
+
+    def run(self):
+        self.graph.replay()
+        return self.codes, self.xrec, self.err
+
+
+def _graph_lloyd_enabled() -> bool:
+    import os
+    return os.environ.get("RC_WARMUP_GRAPH", "1") != "0"
+
+
 def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, n_pq: int = 4, seed: int = SEED,
               R0: Optional[torch.Tensor] = None, history: Optional[list] = None, _sync_procrustes: bool = False):
     """OPQ rotation R [D,D] (x_rot = x @ R) by alternating PQ training and orthogonal Procrustes.  `R0`: starting
@@ -194,11 +244,37 @@ def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, 
     R = R0.float().to(x.device).contiguous()
     C = None
     mses, errs = [], []
+    lg = None                                                   # hipGraph of the Lloyd block (rounds >= 1, single rank)
+    use_graph = _graph_lloyd_enabled() and not _multi() and n_outer > 2 and n_pq >= 1 and x.is_cuda
     for it in range(n_outer):
-        xr = (x @ R).contiguous()
         # No host synchronisation in a round: the Lloyd iterations (assignment, statistics, update, empty-cluster rule), the
         # error and the Procrustes iteration (fixed schedule, orthogonality check left on the device) only enqueue; the
         # checks of all rounds are read once, after the last one.
+        if use_graph and it >= 1:
+            if lg is None:
+                lg = _LloydGraph(n, D, M, n_pq, x.device)
+                lg.C.copy_(C)
+                try:
+                    lg.capture()
+                except Exception as e:                          # a runtime that cannot capture: the eager rounds
+                    logger.warning("OPQ: hipGraph capture of the Lloyd block failed (%s); continuing eagerly", e)
+                    use_graph, lg = False, None
+            if lg is not None:
+                torch.matmul(x, R, out=lg.xr)
+                if C is not lg.C:
+                    lg.C.copy_(C)
+                codes, xrec, err2 = lg.run()
+                C = lg.C                                        # the centroids live in the graph's buffer from here on
+                mses.append(err2 / float(n))
+                P = (x.T @ xrec).double()
+                if _sync_procrustes:
+                    R = procrustes_rotation(P)
+                else:
+                    R, err = procrustes_rotation(P, defer=True)
+                    errs.append(err)
+                R = R.float().contiguous()
+                continue
+        xr = (x @ R).contiguous()
         C, mse = train_pq(xr, M, n_pq_first if it == 0 else n_pq, centroids=C, seed=seed, mse_on_device=True)
         mses.append(mse)
         codes = ops.assign_nearest(xr, C, torch.uint8)
