@@ -1341,7 +1341,7 @@ def test_native_rccl_collectives_inside_the_graph_single_rank(monkeypatch):
                                 device_id=torch.device(DEV))
         created = True
     try:
-        ops.comm_init()
+        ops.comm_init(transport="rccl")                              # this test is about the RCCL calls (auto would pick ipc)
         monkeypatch.setenv("RC_DIST_FORCE_COLL", "1")
         g, x, C = load_case("m48_b1024_sample")
         for split in ("0", "1"):
@@ -1368,7 +1368,7 @@ def _two_rank_worker(rank, world, port, name, ret):
         B = x.shape[0]
         cuts = [0, B // 2, B] if name != "m48_b1000_ragged" else [0, B, B]      # ragged: rank 1 holds no rows
         xl = torch.from_numpy(x[cuts[rank]:cuts[rank + 1]]).to(dev)
-        ops.comm_init()
+        ops.comm_init(transport="rccl")                              # the IPC transport has its own multi-process tests
         out = []
         for graph in ("0", "1", "1"):
             os.environ["RC_GRAPH"] = graph
