@@ -448,9 +448,10 @@ dist_ws dist_layout(int64_t B, int M, int world, bool split) {
     return L;
 }
 bool want_split(int world) {
-    // Default: two chains as soon as there is a collective to hide.  On one GPU the split only buys ~3 % (the tail
-    // of one sweep overlaps the head of the other: 53.1 -> 51.6 ms per 49152-row step) and makes per-launch timings
-    // overlap, so it stays off unless RC_DIST_SPLIT=1.
+    // Default: two chains as soon as there is a collective to hide.  On one GPU the split buys 4-5 % at 49 152 rows
+    // (the tail of one sweep overlaps the head of the other: 43.3 -> 41.5 ms per step, round 4), nothing at 6 144, and
+    // nothing on top of the rotating wave priority of the sweep (sinkhorn.hip, sk_setprio: 41.2 ms in one chain), and
+    // it makes per-launch timings overlap: it stays off unless RC_DIST_SPLIT=1.
     const char* e = getenv("RC_DIST_SPLIT");
     if (e) return atoi(e) != 0;
     return world > 1;

@@ -429,6 +429,23 @@ __device__ __forceinline__ void sk2_column(const float (&x)[SK_EPL], const doubl
 // column longer (q + 1 = B / gridDim.x + 1 columns).
 __device__ __forceinline__ unsigned sk2_range_lo(unsigned i, unsigned q, unsigned r) { return i * q + (i < r ? i : r); }
 
+// Wave priority for the main loop of the sweeps.  The four blocks that share a CU (one wave of each per SIMD) do not run
+// at the same speed: the SIMD's arbiter prefers the OLDEST wave, so the block dispatched first streams its columns in
+// ~260 us and the fourth in ~390 us (trace of a resident experimental kernel, profiles/r04e_sk_tiers.txt; a static
+// s_setprio in the opposite order reverses the ranking exactly), and a launch lasts as long as its slowest block.  The
+// priority therefore rotates: every 2^shift ticks of the 100 MHz clock the four dispatch rounds of a CU move on by one
+// level, so each of them holds each level a quarter of the time and they finish together.  49 152 x 48: 0.421 ->
+// 0.398 ms per sweep (step 43.6 -> 41.2 ms), 6 144 x 48: 59.6 -> 57.2 us; RC_SK_PRIO=0 switches it off.
+__device__ __forceinline__ void sk_setprio(int p) {     // s_setprio takes an immediate
+    switch (p & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+#define SK_PRIO_SHIFT 10                 // 2^10 ticks of 10 ns
+
 // MODE 0: first sweep on a centred table; 1: first sweep, centring fused (d holds the raw table); 2: sweep t >= 1.
 template <int MODE, bool FKLDS>
 __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_sweep2_kernel(
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
     double* __restrict__ f_out, int* __restrict__ gq, double* __restrict__ part, unsigned* __restrict__ counters,
     double* __restrict__ rows_out, unsigned B, int M, unsigned rq, unsigned rr, double nse, double scale, double lmax,
     const double* __restrict__ exp2_tab, int t, int* __restrict__ flags, const float* __restrict__ cmx,
-    const float* __restrict__ cmn) {
+    const float* __restrict__ cmn, int prio_shift, int blocks_per_round) {
     constexpr bool FIRST = MODE != 2;
     static_assert(!(FIRST && FKLDS), "the first sweep has no row potentials");
     __shared__ __attribute__((aligned(16))) double s_tab[SK2_N];      // red[16][256] aliases it after the main loop
@@ -521,7 +538,9 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
             camp = (mx - cmid) + 1e-5f;
         }
         // ---- (c) main loop, two columns per trip (ping-pong register buffers, next column always in flight)
+        const int round = (int)((blockIdx.y * gridDim.x + blockIdx.x) / (unsigned)blocks_per_round);   // dispatch round of the CU
         while (col < c1) {
+            if (prio_shift >= 0) sk_setprio(round + (int)(wall_clock64() >> prio_shift));
             const unsigned colb = col + SK_NG;
             if (colb < c1) {
                 sk_load_col(dm + (size_t)colb * RC_K, xb);
@@ -658,26 +677,30 @@ static int sk2_launch(rc_handle_t h, int mode, float* d, const double* rows_prev
     const bool fklds = rc_env_int("RC_SK_FKLDS", 1) != 0;
     const unsigned nbm = (unsigned)sk2_blocks_per_m(h, B, M, fklds ? 4 : 3);
     const dim3 grid(nbm, (unsigned)M);
+    // rotating wave priority (sk_setprio); RC_SK_PRIO=0: off, n >= 1: rotate every 2^(n-1) ticks instead of the default
+    const int prio_env = rc_env_int("RC_SK_PRIO", -1);
+    const int prio_shift = prio_env == 0 ? -1 : (prio_env > 0 ? prio_env - 1 : SK_PRIO_SHIFT);
+    const int per_round = (h && h->num_cus > 0) ? h->num_cus : 256;
     if (mode != 2) {
         RC_HIP_CHECK(h, hipMemsetAsync(counters, 0, (size_t)M * sizeof(unsigned), s));
         if (mode == 0)
             hipLaunchKernelGGL((sk_sweep2_kernel<0, false>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
                                f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
-                               flags, mx, mn);
+                               flags, mx, mn, prio_shift, per_round);
         else
             hipLaunchKernelGGL((sk_sweep2_kernel<1, false>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
                                f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
-                               flags, mx, mn);
+                               flags, mx, mn, prio_shift, per_round);
     } else {
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
         if (fklds)
             hipLaunchKernelGGL((sk_sweep2_kernel<2, true>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
                                f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
-                               flags, mx, mn);
+                               flags, mx, mn, prio_shift, per_round);
         else
             hipLaunchKernelGGL((sk_sweep2_kernel<2, false>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
                                f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
-                               flags, mx, mn);
+                               flags, mx, mn, prio_shift, per_round);
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
     }
     RC_LAUNCH_CHECK(h);
