@@ -265,6 +265,14 @@ __global__ __launch_bounds__(1024) void kmeans_stats_fx_kernel(const float* __re
             vc[u] = ok ? *reinterpret_cast<const float4*>(xp + u * xstep) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         while (r < r1) {
+            // the wave priority rotates with the 100 MHz clock (the arbiter serves the oldest wave of a SIMD first, so the
+            // sixteen waves of a block would finish their rows at different times; sinkhorn.hip, sk_setprio): -3 % at M = 48
+            switch (((tid >> 8) + (int)(wall_clock64() >> 10)) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
             int kn[KM_FX_U];
             float4 vn[KM_FX_U];
             r += (int64_t)KM_FX_U * rpi;
