@@ -354,7 +354,8 @@ def main():
     alg_bytes = bl * (M // n_chains) * K * 4
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if n_l.value else 0.0
     roofline = {"kernel": "sk_sweep2_kernel<2, true> (Sinkhorn sweep t >= 1 incl. fused row-potential update and integer "
-                          "column exponents; potentials from LDS, 4 blocks per CU, one equal column range per block)",
+                          "column exponents; potentials from LDS, 4 blocks per CU, one equal column range per block, wave "
+                          "priority rotating with the clock)",
                 "measured_in": "timed region: one HIP-event pair around each step's 98 back-to-back sweep launches (t >= 2, "
                                "replayed from the hipGraph), divided by 98 - inter-launch gaps included" if profile_timed else
                                "one extra profiled step after the timed region (the timed region replays the hipGraph)",
@@ -365,7 +366,13 @@ def main():
                                   "command), NOT measured by this run",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(sweep_ms, 4), "launches_timed": n_l.value,
-                "sub_quantisers_per_launch": M // n_chains}
+                "sub_quantisers_per_launch": M // n_chains,
+                "measured_read_ceiling": {"GBs": 6850, "with_the_sweeps_valu_load_GBs": [6290, 6490],
+                                          "note": "tools/ubench_stream_read.hip (profiles/r04e_ubench_stream_read.txt, not this "
+                                                  "run): a kernel that only reads the table with this access pattern reaches "
+                                                  "6.85 TB/s = 0.86 of the nominal peak used in `frac`; with 12-16 dependent "
+                                                  "fp64 FMAs per entry (the sweep issues ~16 VALU instructions per entry) "
+                                                  "6.3-6.5 TB/s"}}
 
     # balance sanity of the last batch (every centroid gets ~B/K of the global batch)
     hist = ops.code_hist(codes)
