@@ -737,17 +737,18 @@ def main():
             "procrustes_ms": ev_ms(lambda: procrustes_rotation(Pw), reps=3),
         }
         parts = {kk: round(v, 3) for kk, v in parts.items()}
-        # rounds >= 1 (graph-replayed Lloyd block): 4 Lloyd iterations, ONE final assignment + decode (round 3 ran them twice)
+        # rounds >= 1 (one graph replay each): 4 Lloyd iterations, ONE final assignment + decode (round 3 ran them twice)
         device_sum = (parts["rotate_gemm_ms"] + 4 * parts["lloyd_iteration_ms"] + parts["assign_nearest_ms"] + parts["decode_ms"]
                       + parts["xT_xrec_gemm_fp64cast_ms"] + parts["procrustes_ms"])
         parts["device_sum_per_round_ms"] = round(device_sum, 3)
         parts["measured_per_round_ms"] = round(t_opq / 50 * 1e3, 3)
         parts["note"] = ("a round = rotate, 4 Lloyd iterations (assignment, statistics, update, empty-cluster rule: no host "
                          "synchronisation), error, assignment, decode, x^T x_rec, Procrustes (optimally scaled Newton-Schulz on a fixed "
-                         "36-step schedule, orthogonality check left on the device): no host synchronisation in a round; the Lloyd "
-                         "block (~70 launches of the package's own kernels) is replayed from a hipGraph since round 4, the ~85 library "
-                         "GEMM launches stay eager (a graph of them replays slower); measured - device sum = what the host's launch "
-                         "rate still costs on this box; round 0 runs 40 Lloyd iterations eagerly and the graph is captured in round 1")
+                         "36-step schedule, orthogonality check left on the device): no host synchronisation in a round, and since "
+                         "round 4 the WHOLE round (~70 launches of the package's kernels, ~80 library GEMMs, ~40 element-wise ops) is "
+                         "one hipGraph replay on static buffers (run_warmup._RoundGraph; bit-identical to the eager rounds), so the "
+                         "host's launch rate no longer sets the pace; measured - device sum = gaps between the ~200 graph nodes + "
+                         "round 0 (40 Lloyd iterations, eager) + round 1 (eager, then captured)")
         del codes_w, xrec_w, Pw
         out["opq_pq_warmup"] = {
             "metric": "opq_pq_training_seconds", "value": round(t_opq + t_pq2, 3), "unit": "s", "higher_is_better": False,

@@ -180,49 +180,75 @@ def train_pq(x: torch.Tensor, M: int, n_iter: int, centroids: Optional[torch.Ten
     return C, (mse if mse_on_device else float(mse))
 
 
-class _LloydGraph:
-    """The Lloyd block of one OPQ round — n_iter x (assignment, statistics, update, empty-cluster rule), the final assignment,
-    decode and squared error: ~70 launches of this package's own kernels and a few element-wise ops, no library GEMM — captured
-    once into a hipGraph on static buffers and replayed every round (single rank only: a multi-rank block contains the exchange
-    layer's numbered all-gathers).  Round 3 measured a graph of the Procrustes GEMMs SLOWER than eager calls; kernel nodes are
-    what the Sinkhorn iteration graph already replays well.  The host then issues one launch instead of ~70 per round."""
+def _procrustes_static(P: torch.Tensor, X: list, Y: torch.Tensor, eye: torch.Tensor, sched: list):
+    """procrustes_rotation(P, defer=True) on caller-owned buffers (X: two [D,D] fp64, Y: one): the same library calls in the
+    same order, hence the same values; nothing is allocated per step, so the sequence can be captured into a hipGraph."""
+    cur, nxt = X
+    torch.div(P, torch.linalg.matrix_norm(P), out=cur)
+    for a, b in sched:
+        torch.mm(cur.T, cur, out=Y)
+        nxt.copy_(cur)
+        nxt.addmm_(cur, Y, beta=a, alpha=b)
+        cur, nxt = nxt, cur
+    return cur, (cur.T @ cur - eye).abs().max()
 
-    def __init__(self, n: int, D: int, M: int, n_iter: int, device):
-        self.xr = torch.empty((n, D), dtype=torch.float32, device=device)
-        self.C = torch.empty((M, 256, D // M), dtype=torch.float32, device=device)
-        self.n_iter = n_iter
+
+class _RoundGraph:
+    """One OPQ round r >= 1 of a single rank as ONE hipGraph on static buffers: rotate (x @ R), n_iter x (assignment,
+    statistics, update, empty-cluster rule), the final assignment, decode, squared error, x^T x_rec, the Procrustes
+    iteration on its fixed schedule with its orthogonality check, R <- the polar factor, and the round's (mse, check) pair
+    written to row `it` of a log that is read once after the last round.  ~70 launches of this package's kernels, ~80 library
+    GEMMs and ~40 element-wise ops per round become one graph launch: the host no longer sets the pace (device time 5.1 ms per
+    round; an eager round takes 6.7 - 9.7 ms depending on the host).  Round 4 first captured the Lloyd block only, because round
+    3 had measured a graph of the Procrustes GEMMs slower than eager calls; measured again (tools: 36 steps, 72 fp64 GEMMs):
+    eager 2.07 ms of device time + 0.7 ms of host time, replayed 2.08 ms — identical results.
+    `step()` replays the graph, or runs the same body eagerly when the runtime cannot capture it."""
+
+    def __init__(self, x: torch.Tensor, M: int, n_iter: int, n_outer: int, lower: float = 1e-12):
+        n, D = x.shape
+        dev = x.device
+        self.x, self.n, self.n_iter = x, n, n_iter
+        self.R = torch.empty((D, D), dtype=torch.float32, device=dev)
+        self.C = torch.empty((M, 256, D // M), dtype=torch.float32, device=dev)
+        self.xr = torch.empty((n, D), dtype=torch.float32, device=dev)
+        self.X = [torch.empty((D, D), dtype=torch.float64, device=dev) for _ in range(2)]
+        self.Y = torch.empty((D, D), dtype=torch.float64, device=dev)
+        self.eye = torch.eye(D, dtype=torch.float64, device=dev)
+        self.log = torch.zeros((n_outer, 2), dtype=torch.float64, device=dev)      # per round: mse, |R^T R - I|_max
+        self.it = torch.zeros((1,), dtype=torch.int64, device=dev)                  # the round the next step() is
+        self.sched = list(_polar_schedule(float(lower)))
         self.graph = None
-        self.codes = self.xrec = self.err = None
 
-    def _body(self):
-        xr, C = self.xr, self.C
+    def body(self):
+        x, xr, C = self.x, self.xr, self.C
+        torch.matmul(x, self.R, out=xr)
         for _ in range(self.n_iter):
             codes = ops.assign_nearest(xr, C, torch.uint8)
             sums, counts = ops.kmeans_stats(xr, codes)
             ops.kmeans_update_(sums, counts, C)
             _reseed_empty(C, counts)
-        self.codes = ops.assign_nearest(xr, C, torch.uint8)
-        self.xrec = ops.decode_raw(self.codes, C)
-        self.err = ((self.xrec - xr) ** 2).sum().double()
+        codes = ops.assign_nearest(xr, C, torch.uint8)
+        xrec = ops.decode_raw(codes, C)
+        mse = ((xrec - xr) ** 2).sum().double() / float(self.n)
+        P = (x.T @ xrec).double()
+        cur, err = _procrustes_static(P, self.X, self.Y, self.eye, self.sched)
+        self.R.copy_(cur)                                      # fp64 iteration: R stays orthogonal to ~1e-7 after the cast
+        self.log.index_copy_(0, self.it, torch.stack([mse, err])[None])
+        self.it += 1
 
     def capture(self):
-        """Warm every allocation / attribute call eagerly on the capture stream, then capture."""
-        side = torch.cuda.Stream(device=self.xr.device)
-        side.wait_stream(torch.cuda.current_stream(self.xr.device))
-        keepC = self.C.clone()
-        with torch.cuda.stream(side):
-            self._body()                                      # eager warm-up (moves C: restored below)
-            self.C.copy_(keepC)
-        torch.cuda.current_stream(self.xr.device).wait_stream(side)
+        side = torch.cuda.Stream(device=self.x.device)
+        side.wait_stream(torch.cuda.current_stream(self.x.device))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
-            self._body()
-        self.C.copy_(keepC)                                   # capture does not execute, but keep the invariant explicit
+            self.body()
         self.graph = g
 
-    def run(self):
-        self.graph.replay()
-        return self.codes, self.xrec, self.err
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.body()
 
 
 def _graph_lloyd_enabled() -> bool:
@@ -244,36 +270,28 @@ def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, 
     R = R0.float().to(x.device).contiguous()
     C = None
     mses, errs = [], []
-    lg = None                                                   # hipGraph of the Lloyd block (rounds >= 1, single rank)
-    use_graph = _graph_lloyd_enabled() and not _multi() and n_outer > 2 and n_pq >= 1 and x.is_cuda
+    rg = None                                                   # the rounds >= 1 of a single rank: one hipGraph each
+    use_graph = _graph_lloyd_enabled() and not _multi() and n_outer > 2 and n_pq >= 1 and x.is_cuda and not _sync_procrustes
     for it in range(n_outer):
         # No host synchronisation in a round: the Lloyd iterations (assignment, statistics, update, empty-cluster rule), the
         # error and the Procrustes iteration (fixed schedule, orthogonality check left on the device) only enqueue; the
         # checks of all rounds are read once, after the last one.
         if use_graph and it >= 1:
-            if lg is None:
-                lg = _LloydGraph(n, D, M, n_pq, x.device)
-                lg.C.copy_(C)
+            if rg is None:
+                # round 1 runs the round's body eagerly on the static buffers (every lazy initialisation of the libraries has
+                # happened by then), rounds >= 2 replay its capture
+                rg = _RoundGraph(x, M, n_pq, n_outer)
+                rg.R.copy_(R)
+                rg.C.copy_(C)
+                rg.it.fill_(it)
+                rg.body()
                 try:
-                    lg.capture()
-                except Exception as e:                          # a runtime that cannot capture: the eager rounds
-                    logger.warning("OPQ: hipGraph capture of the Lloyd block failed (%s); continuing eagerly", e)
-                    use_graph, lg = False, None
-            if lg is not None:
-                torch.matmul(x, R, out=lg.xr)
-                if C is not lg.C:
-                    lg.C.copy_(C)
-                codes, xrec, err2 = lg.run()
-                C = lg.C                                        # the centroids live in the graph's buffer from here on
-                mses.append(err2 / float(n))
-                P = (x.T @ xrec).double()
-                if _sync_procrustes:
-                    R = procrustes_rotation(P)
-                else:
-                    R, err = procrustes_rotation(P, defer=True)
-                    errs.append(err)
-                R = R.float().contiguous()
-                continue
+                    rg.capture()
+                except Exception as e:                          # a runtime that cannot capture: the same body, eagerly
+                    logger.warning("OPQ: hipGraph capture of a round failed (%s); continuing eagerly", e)
+            else:
+                rg.step()
+            continue
         xr = (x @ R).contiguous()
         C, mse = train_pq(xr, M, n_pq_first if it == 0 else n_pq, centroids=C, seed=seed, mse_on_device=True)
         mses.append(mse)
@@ -289,6 +307,11 @@ def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, 
         R = R.float().contiguous()                              # fp64 iteration: R stays orthogonal to ~1e-7 after the cast
     vals = [float(v) for v in torch.stack(mses + errs).double().cpu()] if mses else []     # the one synchronisation
     mses, errs = vals[:len(mses)], vals[len(mses):]
+    if rg is not None:                                          # rounds 1 .. n_outer-1 logged on the device
+        rows = rg.log[len(mses):n_outer].cpu()
+        mses += [float(v) for v in rows[:, 0]]
+        errs += [float(v) for v in rows[:, 1]]
+        R = rg.R.clone()
     if any(not (e < 1e-9) for e in errs):
         # a Procrustes matrix the fixed schedule did not orthogonalise (singular, or cond above ~1e12): every rank sees the
         # same values and repeats the training with the checked iteration (library SVD as its fall-back)

@@ -1858,12 +1858,15 @@ def test_ivf_list_centric_search_equals_per_query_scan(M):
         assert torch.equal(i3, i2) and torch.equal(s3, s2), (M, nprobe)
 
 
-def test_opq_training_repeats_with_checked_procrustes_when_a_deferred_check_fails(monkeypatch):
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_opq_training_repeats_with_checked_procrustes_when_a_deferred_check_fails(monkeypatch, graph):
     """train_opq reads the orthogonality checks of all rounds once, after the last; if one is not below 1e-9 (here: forced in
-    round 1) it repeats the training with per-round checks (library SVD as their fall-back).  Rank-deficient training rows
+    round 1) it repeats the training with per-round checks (library SVD as their fall-back) — whether the rounds >= 1 are
+    replayed from the round's hipGraph (RC_WARMUP_GRAPH=1, the default) or enqueued eagerly.  Rank-deficient training rows
     alone do not need that: rounding noise keeps the Procrustes matrices inside the schedule's range and the result is
     orthogonal."""
     from repconc_amd.train import run_warmup
+    monkeypatch.setenv("RC_WARMUP_GRAPH", graph)
     rng = np.random.default_rng(8)
     basis = rng.standard_normal((3, 128)).astype(np.float32)
     x = (rng.standard_normal((4096, 3)).astype(np.float32) @ basis)                  # rows in a 3-dimensional subspace
@@ -1871,18 +1874,46 @@ def test_opq_training_repeats_with_checked_procrustes_when_a_deferred_check_fail
     R = run_warmup.train_opq(_t(x), 8, n_outer=3, n_pq_first=3, n_pq=2)
     assert float((R @ R.T - eye).abs().max()) < 1e-4 and bool(torch.isfinite(R).all())
     modes = []
-    orig = run_warmup.procrustes_rotation
+    orig, orig_static = run_warmup.procrustes_rotation, run_warmup._procrustes_static
 
     def spy(P, lower=1e-12, defer=False):
         modes.append(bool(defer))
         out = orig(P, lower, defer)
-        if defer and len(modes) == 2:                          # round 1 of the deferred pass "fails"
+        if defer and len(modes) == 2:                          # round 1 of the deferred pass "fails" (eager rounds)
             return out[0], out[1] + 1.0
         return out
+
+    def spy_static(*a):                                        # ... and so does the round the graph is made of
+        modes.append("graph")
+        cur, err = orig_static(*a)
+        return cur, err + 1.0
     monkeypatch.setattr(run_warmup, "procrustes_rotation", spy)
+    monkeypatch.setattr(run_warmup, "_procrustes_static", spy_static)
     R2 = run_warmup.train_opq(_t(x), 8, n_outer=3, n_pq_first=3, n_pq=2)
-    assert modes == [True] * 3 + [False] * 3, modes
+    if graph == "0":
+        assert modes == [True] * 3 + [False] * 3, modes
+    else:      # round 0 eager and deferred, round 1 = the body run eagerly, then its capture (round 2 replays it), then the repeat
+        assert modes == [True, "graph", "graph"] + [False] * 3, modes
     assert float((R2 @ R2.T - eye).abs().max()) < 1e-4
+
+
+def test_opq_rounds_replayed_from_the_round_graph_equal_the_eager_rounds(monkeypatch):
+    """Rounds >= 1 of a single-rank OPQ training are one hipGraph each (run_warmup._RoundGraph: rotate, Lloyd block, error,
+    x^T x_rec, Procrustes iteration, R update, log row): the rotation and every round's error are bit-identical to the
+    eagerly enqueued rounds (RC_WARMUP_GRAPH=0), and a second training on the same process replays a fresh capture."""
+    from repconc_amd.train import run_warmup
+    x = _t(synth.gaussian(4242, (8192, 128)) * np.linspace(1.0, 0.05, 128, dtype=np.float32))
+    out = {}
+    for graph in ("0", "1", "1"):
+        monkeypatch.setenv("RC_WARMUP_GRAPH", graph)
+        hist = []
+        R = run_warmup.train_opq(x, 8, n_outer=6, n_pq_first=5, n_pq=2, history=hist)
+        assert len(hist) == 6 and all(np.isfinite(hist))
+        if graph in out:
+            assert torch.equal(out[graph][0], R) and out[graph][1] == hist
+        out[graph] = (R, hist)
+    assert torch.equal(out["0"][0], out["1"][0])
+    assert out["0"][1] == out["1"][1]
 
 
 def test_warmup_procedure_follows_the_oracle_round_by_round():
