@@ -1114,8 +1114,10 @@ def ops_decode_all(index, centroids):
 
 
 # ------------------------------------------------------------------------------------------- round 2
-SK_VARIANTS = [  # (RC_SK_V1, RC_SK_FKLDS, RC_SK_NB, RC_SK_CPB, RC_FUSE_CENTRE)
-    ("0", "1", "", "", "1"),      # default: version-2 sweep, potentials from LDS, 4 blocks per CU
+SK_VARIANTS = [  # (RC_SK_V1, RC_SK_FKLDS, RC_SK_NB, RC_SK_CPB, RC_FUSE_CENTRE, RC_SK_PRIO)
+    ("0", "1", "", "", "1", ""),      # default: version-2 sweep, potentials from LDS, 4 blocks per CU, rotating wave priority
+    ("0", "1", "", "", "1", "0"),     # ... without the rotating priority (round 4: a scheduling matter, never a result)
+    ("0", "1", "", "", "1", "3"),     # ... rotating every 40 ns
     ("0", "0", "", "", "1"),      # potentials in registers
     ("0", "1", "", "", "0"),      # separate centring kernel
     ("0", "1", "7", "", "1"),     # few blocks: every block straddles several sub-quantisers
@@ -1127,7 +1129,7 @@ SK_VARIANTS = [  # (RC_SK_V1, RC_SK_FKLDS, RC_SK_NB, RC_SK_CPB, RC_FUSE_CENTRE)
 ]
 
 
-@pytest.mark.parametrize("variant", SK_VARIANTS, ids=lambda v: "v1=%s,fklds=%s,nb=%s,cpb=%s,fuse=%s" % v)
+@pytest.mark.parametrize("variant", SK_VARIANTS, ids=lambda v: "v1=%s,fklds=%s,nb=%s,cpb=%s,fuse=%s" % v[:5] + (",prio=%s" % v[5] if len(v) > 5 else ""))
 @pytest.mark.parametrize("name", ["m48_b6144_sample", "m48_b1000_ragged", "m96_b512_blend", "m8_b2048_sample",
                                   "m24_b1024_sample"])
 def test_every_sweep_variant_reproduces_the_golden_codes(name, variant, monkeypatch):
@@ -1135,7 +1137,8 @@ def test_every_sweep_variant_reproduces_the_golden_codes(name, variant, monkeypa
     them the one bench.py times — runs against the reference's own codes (fixtures generated by importing the reference,
     oracle/gen_golden.py)."""
     from repconc_amd import ops
-    for key, val in zip(("RC_SK_V1", "RC_SK_FKLDS", "RC_SK_NB", "RC_SK_CPB", "RC_FUSE_CENTRE"), variant):
+    variant = tuple(variant) + ("",) * (6 - len(variant))
+    for key, val in zip(("RC_SK_V1", "RC_SK_FKLDS", "RC_SK_NB", "RC_SK_CPB", "RC_FUSE_CENTRE", "RC_SK_PRIO"), variant):
         if val == "":
             monkeypatch.delenv(key, raising=False)
         else:
