@@ -625,15 +625,36 @@ static double sk_scale() { return (double)SK_N / SK_LN2; }
 
 // version 2 (default) unless RC_SK_V1=1 (the round-1 kernel, kept for A/B runs and as a cross-check in the tests)
 static bool sk_use_v2() { return rc_env_int("RC_SK_V1", 0) == 0; }
-// blocks per sub-quantiser of the version-2 sweep: the chip's resident slots (`per_cu` per CU) divided by M, never fewer
-// than ~32 columns per block.  RC_SK_NB overrides the TOTAL number of blocks (tests).
+// blocks per sub-quantiser of the version-2 sweep.  Large launches: the chip's resident slots (`per_cu` per CU) divided by M
+// — every block does the same work in one round.  Small launches pay per BLOCK (32 KiB table, 256 logarithms, the hand-over of
+// its partial sums), so they take fewer and longer blocks — measured in round 4 (ms per 100-iteration solve, default of rounds
+// 2-3 -> this rule; B x M): 6144 x 24, one chain of the 8-GPU recipe: 3.99 -> 3.62; 6144 x 12: 3.51 -> 2.66; 3072 x 24: 2.82 ->
+// 2.40; 3072 x 48: 3.62 -> 3.44; 1536 x 24: 2.30 -> 1.86; 1024 x 48: 2.13 -> 1.87; 8192 x 8: 3.47 -> 2.55; 2048 x 8: 1.70 -> 1.35;
+// 6144 x 48, 12288 x 24 and everything larger: unchanged —
+//   * three blocks per CU instead of four while a block would hold fewer than 384 columns (768 blocks = exactly three per CU
+//     beat 1008 = "almost four" by 9 % at 6144 x 24, and 912 or 648 blocks, which load the CUs unevenly, lose it again);
+//   * never fewer than 128 columns per block,
+//   * but one block per CU while a block still gets 64 columns (batches of a few hundred rows).
+// RC_SK_NB overrides the TOTAL number of blocks (tests).
 static int sk2_blocks_per_m(rc_handle_t h, int64_t B, int M, int per_cu) {
+    const int64_t cus = (h && h->num_cus > 0) ? h->num_cus : 256;
     int64_t nb = rc_env_int("RC_SK_NB", 0);
-    if (nb <= 0) nb = (int64_t)per_cu * (h && h->num_cus > 0 ? h->num_cus : 256);
+    const bool forced = nb > 0;
+    if (!forced) {
+        nb = (int64_t)per_cu * cus;
+        if (per_cu > 3 && B / (nb / M > 0 ? nb / M : 1) < 384) nb = 3 * cus;
+    }
     if (nb > SK2_MAX_BLOCKS) nb = SK2_MAX_BLOCKS;
     int64_t nbm = nb / M;
-    const int64_t cap = B / 32;
-    if (nbm > cap) nbm = cap;
+    if (!forced) {
+        if (nbm > B / 128) nbm = B / 128;
+        if (nbm * M < cus) {                                  // not even one block per CU: shorter blocks, down to 64 columns
+            nbm = (cus + M - 1) / M;
+            if (nbm > B / 64) nbm = B / 64;
+        }
+    } else if (nbm > B / 32) {
+        nbm = B / 32;
+    }
     if (nbm < 1) nbm = 1;
     return (int)nbm;
 }
