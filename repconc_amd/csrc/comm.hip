@@ -604,9 +604,10 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
         return RC_OK;
     };
     // sweeps t = 0 .. iters-1, the two chains enqueued alternately so both streams stay fed
-    const int variant = rc_env_int("RC_SK_V1", 0) | (rc_env_int("RC_SK_FKLDS", 1) << 1) | (rc_env_int("RC_SK_NB", 0) << 2) |
-                        (rc_env_int("RC_SK_CPB", 0) << 14) | ((int)coll << 24) | ((int)use_ipc << 25) |
-                        ((int)(cx.ipc_base[0] & 1) << 26) | ((int)(cx.ipc_base[1] & 1) << 27);
+    const int variant = (rc_env_int("RC_SK_V1", 0) | (rc_env_int("RC_SK_FKLDS", 1) << 1) | (rc_env_int("RC_SK_NB", 0) << 2) |
+                         (rc_env_int("RC_SK_CPB", 0) << 14) | ((int)coll << 24) | ((int)use_ipc << 25) |
+                         ((int)(cx.ipc_base[0] & 1) << 26) | ((int)(cx.ipc_base[1] & 1) << 27)) ^
+                        (int)((unsigned)(rc_env_int("RC_SK_PRIO", -1) + 1) * 0x10000001u);   // (a captured launch keeps its priority setting)
     // per-launch event marks (profile mode 1) need the eager loop; the bracket mode (2) times the whole run of sweeps
     const bool want_graph = rc_env_int("RC_GRAPH", 1) != 0 && h->profile_on != 1 && !h->graph_broken && iters > 4;
     const bool bracket = h->profile_on == 2 && L.nch == 1 && B > 0;     // one chain: launches are back to back on s0
