@@ -274,16 +274,28 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us_ag = max_over_ranks(e0.elapsed_time(e1)) * 1e3 / 200
-            for _ in range(2):
-                step(0)
-            barrier()
-            tt0 = time.perf_counter()
-            for i in range(3):
-                step(i)
-            barrier()
-            ms_step = max_over_ranks(time.perf_counter() - tt0) * 1e3 / 3
+            # ... as TWO chains of M/2 sub-quantisers (the product default for N > 1: the sweep of one chain hides the exchange of
+            # the other) and as ONE chain (RC_DIST_SPLIT=0: one launch per sweep, the exchange exposed).  Which is faster
+            # depends on what an exchange costs on this node against a second launch per iteration — on one shared GPU one
+            # chain wins at 6 144 rows per rank (6.3 against 8.2 ms per step); the node decides, the line says which ran.
+            by_chains = {}
+            for split in ("1", "0"):
+                os.environ["RC_DIST_SPLIT"] = split
+                for _ in range(2):
+                    step(0)
+                barrier()
+                tt0 = time.perf_counter()
+                for i in range(3):
+                    step(i)
+                barrier()
+                by_chains[split] = max_over_ranks(time.perf_counter() - tt0) * 1e3 / 3
+            split_best = min(by_chains, key=lambda k: by_chains[k])
+            ms_step = by_chains[split_best]
             measured[transport] = {"us_per_allgather": round(us_ag, 2), "ms_per_step": round(ms_step, 3),
-                                   "us_per_iteration": round(ms_step * 1e3 / ITERS, 2)}
+                                   "us_per_iteration": round(ms_step * 1e3 / ITERS, 2),
+                                   "chains": 2 if split_best == "1" else 1,
+                                   "ms_per_step_two_chains": round(by_chains["1"], 3),
+                                   "ms_per_step_one_chain": round(by_chains["0"], 3)}
             ops.comm_check()
             barrier()
             try:
@@ -293,6 +305,7 @@ def main():
         if measured:                                         # the faster one runs the timed region (same choice on every rank:
             chosen = min(measured, key=lambda t: measured[t]["ms_per_step"])     # ms_per_step is a max over ranks)
             os.environ["RC_DIST_NATIVE"], os.environ["RC_COMM"] = "1", chosen
+            os.environ["RC_DIST_SPLIT"] = "1" if measured[chosen]["chains"] == 2 else "0"
         native_all = chosen is not None
         os.environ["RC_DIST_NATIVE"] = "1" if native_all else "0"
         gathered = [torch.empty_like(c_staged) for _ in range(world)]
@@ -307,14 +320,16 @@ def main():
                       "transport": chosen, "native_equals_staged": native_all if candidates else None,
                       "transport_notes": notes or None, "sharded_equals_unsharded": unsharded_equal}
         if native_all:
-            exchange = {"transport": chosen, "bytes_per_rank": (M // 2) * K * 8,
+            exchange = {"transport": chosen, "chains": measured[chosen]["chains"], "bytes_per_rank": (M // 2) * K * 8,
                         "us_per_allgather": measured[chosen]["us_per_allgather"],
                         "per_transport": measured,
                         "what": "per transport that passed the probe and reproduced the staged codes: 200 back-to-back "
                                 "rc_comm_allgather calls of one chain's row sums (fused push + wait kernel, copy-out), and three "
                                 "steps of this run's per-rank batch through the native loop (ms_per_step, us_per_iteration = one "
-                                "Sinkhorn iteration's critical path: sweep of one chain overlapping the exchange of the other); "
-                                "the transport with the shorter step runs the timed region"}
+                                "Sinkhorn iteration's critical path) as two chains of M/2 sub-quantisers (the sweep of one overlaps the "
+                                "exchange of the other: the product default for N > 1) and as one chain (RC_DIST_SPLIT=0: one launch "
+                                "per sweep, the exchange exposed); the (transport, chains) pair with the shortest step runs the timed "
+                                "region"}
             barrier()
         del xs_loc, c_staged, gathered
 
