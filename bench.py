@@ -693,7 +693,7 @@ def main():
 
     # ------------------------------------------------------------------ warm-up leg (OPQ + PQ training, a-12)
     if world == 1 and not args.no_adc and not args.no_opq:
-        from repconc_amd.train.run_warmup import MAX_TRAIN_POINTS, train_opq, train_pq
+        from repconc_amd.train.run_warmup import MAX_TRAIN_POINTS, _xt_y, train_opq, train_pq
         gw = torch.Generator(device=dev).manual_seed(20226)
         xt = torch.randn((MAX_TRAIN_POINTS, D), device=dev, generator=gw)
         xt = (xt @ (torch.randn((D, D), device=dev, generator=gw) / D ** 0.5)).contiguous()    # correlated dimensions
@@ -752,7 +752,7 @@ def main():
             "lloyd_iteration_ms": ev_ms(lloyd),
             "assign_nearest_ms": ev_ms(lambda: ops.assign_nearest(xr, Cw, torch.uint8)),
             "decode_ms": ev_ms(lambda: ops.decode_raw(codes_w, Cw)),
-            "xT_xrec_gemm_fp64cast_ms": ev_ms(lambda: (xt.T @ xrec_w).double()),
+            "xT_xrec_gemm_fp64cast_ms": ev_ms(lambda: _xt_y(xt, xrec_w)),       # 16 row slices as one batched product
             "procrustes_ms": ev_ms(lambda: procrustes_rotation(Pw), reps=3),
         }
         parts = {kk: round(v, 3) for kk, v in parts.items()}
