@@ -276,17 +276,24 @@ def _graph_lloyd_enabled() -> bool:
 def train_opq(x: torch.Tensor, M: int, n_outer: int = 50, n_pq_first: int = 40, n_pq: int = 4, seed: int = SEED,
               R0: Optional[torch.Tensor] = None, history: Optional[list] = None, _sync_procrustes: bool = False):
     """OPQ rotation R [D,D] (x_rot = x @ R) by alternating PQ training and orthogonal Procrustes.  `R0`: starting
-    rotation (default: QR of a seeded Gaussian matrix, the same on every rank); `history`: list that receives the
-    reconstruction MSE of every round (what oracle/pq_oracle.py::train_opq returns, for the parity test)."""
+    rotation (default: the orthogonal polar factor of a seeded Gaussian matrix, the same on every rank); `history`: list
+    that receives the reconstruction MSE of every round (what oracle/pq_oracle.py::train_opq returns, for the parity test)."""
     n, D = x.shape
+    mses, errs = [], []
     if R0 is None:
         g = torch.Generator(device="cpu").manual_seed(seed)
-        # the same seeded Gaussian matrix on every rank, orthogonalised on the device (a 768 x 768 fp64 QR is tens of
-        # milliseconds on a host core, a few on the GPU; every rank of a job runs the same library on the same hardware)
-        R0 = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64).to(x.device))[0]
+        # The same seeded Gaussian matrix on every rank, orthogonalised on the device by the iteration the rounds use anyway:
+        # the polar factor of a Gaussian matrix is Haar-distributed like the Q of its QR (what Faiss's random rotation
+        # takes), costs 2 ms where the library's device QR costs 22 ms (1 300 small kernels) and a host QR 15 - 50 ms, and
+        # its orthogonality check joins the rounds' checks.
+        G = torch.randn(D, D, generator=g, dtype=torch.float64).to(x.device)
+        if _sync_procrustes:
+            R0 = procrustes_rotation(G)
+        else:
+            R0, e0 = procrustes_rotation(G, defer=True)
+            errs.append(e0)
     R = R0.float().to(x.device).contiguous()
     C = None
-    mses, errs = [], []
     rg = None                                                   # the rounds >= 1 of a single rank: one hipGraph each
     use_graph = _graph_lloyd_enabled() and not _multi() and n_outer > 2 and n_pq >= 1 and x.is_cuda and not _sync_procrustes
     for it in range(n_outer):
