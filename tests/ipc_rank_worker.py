@@ -93,6 +93,18 @@ def main() -> int:
             if not np.array_equal(codes.cpu().numpy(), want):
                 print(f"rank {rank}: {int((codes.cpu().numpy() != want).sum())} codes differ from the golden fixture in pass {i}")
                 rc = 1
+        # ONE chain (RC_DIST_SPLIT=0: one launch per sweep, the exchange exposed - what bench.py runs when it is the faster of
+        # the two on the node): eager, capture, replay; every rank switches between the two forms at the same solve
+        os.environ["RC_DIST_SPLIT"] = "0"
+        for i, graph in enumerate(("0", "1", "1")):
+            os.environ["RC_GRAPH"] = graph
+            codes, flags = ops.assign_sinkhorn_dist(xl, Ct, EPS, ITERS, torch.uint8)
+            torch.cuda.synchronize()
+            want = g["codes_constrained"][cuts[rank]:cuts[rank + 1]]
+            if int(flags.item()) != 0 or not np.array_equal(codes.cpu().numpy(), want):
+                print(f"rank {rank}: one-chain solve wrong in pass {i} (flags {int(flags.item())})")
+                rc = 1
+        os.environ.pop("RC_DIST_SPLIT")
         # an odd iteration count flips the exchange parity between solves: the graph cache must key on it
         os.environ["RC_GRAPH"] = "1"
         ref = None

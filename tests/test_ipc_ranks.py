@@ -26,7 +26,8 @@ def _cuts(name, world):
 def test_native_solve_on_ipc_ranks_equals_golden(name, world, tmp_path):
     """Native C loop (two chains on two streams, exchanges as peer stores + one-thread waits) with `world` processes:
     eager, graph capture, graph replay, eager again — every pass of every rank equals the golden codes of its rows;
-    empty ranks take part in every exchange; a 7-iteration solve (odd: flips the exchange parity) is repeatable."""
+    then the same as ONE chain (RC_DIST_SPLIT=0); empty ranks take part in every exchange; a 7-iteration solve (odd: flips
+    the exchange parity) is repeatable."""
     B, cuts = _cuts(name, world)
     codes = run_ranks(world, ["solve", name] + cuts, str(tmp_path), timeout=420)
     assert codes == [0] * world, rank_logs(str(tmp_path), world)
