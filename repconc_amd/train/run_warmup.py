@@ -190,7 +190,7 @@ def _xt_y(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     head = n - n % S
     P = None
     if head:
-        P = torch.bmm(x[:head].view(S, head // S, D).transpose(1, 2), y[:head].view(S, head // S, D)).double().sum(0)
+        P = torch.bmm(x[:head].reshape(S, head // S, D).transpose(1, 2), y[:head].reshape(S, head // S, D)).double().sum(0)
     if head < n:
         tail = (x[head:].T @ y[head:]).double()
         P = tail if P is None else P + tail
