@@ -175,6 +175,28 @@ def test_procrustes_fixed_schedule_and_its_deferred_check():
     assert float((R.T @ R - torch.eye(D, dtype=torch.float64)).abs().max()) < 1e-12
 
 
+def test_procrustes_matrix_as_a_batch_of_row_slices():
+    """run_warmup._xt_y (x^T y for the Procrustes step: sixteen row slices as one batched product, partial products added in
+    fp64): the fp64 product to fp32 accuracy for any number of rows (fewer than 16, a ragged tail, non-contiguous rows), and the
+    static-buffer form of the Procrustes iteration equals the allocating one bit for bit."""
+    import torch
+    from repconc_amd.train.run_warmup import _polar_schedule, _procrustes_static, _xt_y, procrustes_rotation
+    g = torch.Generator().manual_seed(4)
+    for n in (1, 15, 16, 17, 100, 1000, 4099):
+        x, y = torch.randn(n, 24, generator=g), torch.randn(n, 24, generator=g)
+        want = x.double().T @ y.double()
+        assert torch.allclose(_xt_y(x, y), want, atol=1e-4 * max(n, 16) ** 0.5), n
+        xs = torch.randn(n, 48, generator=g)[:, ::2]
+        assert torch.allclose(_xt_y(xs, y), xs.double().T @ y.double(), atol=1e-4 * max(n, 16) ** 0.5), n
+    D = 32
+    P = torch.randn(D, D, generator=g, dtype=torch.float64)
+    X = [torch.empty((D, D), dtype=torch.float64) for _ in range(2)]
+    cur, err = _procrustes_static(P, X, torch.empty((D, D), dtype=torch.float64), torch.eye(D, dtype=torch.float64),
+                                  list(_polar_schedule(1e-12)))
+    ref, err_ref = procrustes_rotation(P, defer=True)
+    assert torch.equal(cur, ref) and float(err) == float(err_ref)
+
+
 def test_faiss_shim_serves_the_scripts_faiss_idioms():
     """compat/faiss: with compat/ first on the path the reference's entry scripts' `import faiss` lines resolve (no edit at
     all): the names they touch exist, `import faiss.contrib.torch_utils` works, and what they do not need is absent."""
