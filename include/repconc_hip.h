@@ -186,6 +186,13 @@ int rc_comm_world(rc_handle_t h);
  * counter and re-arms it: no library call, no communicator, capturable in a hipGraph like any kernel; buffers and
  * counters alternate between two parities so consecutive exchanges need no further handshake.  The wait gives up after
  * RC_IPC_TIMEOUT_MS (flags |= RC_FLAG_COMM) instead of hanging the device when a peer has died.
+ * Round 5: inside rc_pq_assign_sinkhorn_dist the per-iteration exchange (modeling_repconc.py:155-157) is part of the
+ * sweep kernel itself — the block that finishes a sub-quantiser's row sums stores them and a sequence-numbered flag at
+ * every peer, the next sweep's blocks of that sub-quantiser wait for the peers' flags in their prologue (after their
+ * long-latency loads are on their way; a flag-wait kernel instead when ranks share a device): ONE launch per Sinkhorn
+ * iteration on N ranks, one chain of all M sub-quantisers (RC_IPC_XSWEEP=0: the push + wait kernels of rounds 3-4).
+ * One chain moves [M, 256] fp64 through a 256 KiB slot: M <= 128 on this transport (RC_ESHAPE before anything is
+ * enqueued; RC_COMM=rccl has no limit).
  *
  * rc_comm_ipc_export: allocate this rank's buffer, write its RC_IPC_BLOB_BYTES-byte descriptor (IPC handle, device
  *   identity) to blob_host.  The caller gathers the descriptors of all ranks, rank order, through any channel
@@ -203,7 +210,8 @@ int rc_comm_ipc_connect(rc_handle_t h, const void* blobs_host);
 int rc_comm_allgather(rc_handle_t h, const void* src, void* dst, size_t bytes, int* flags, rc_stream_t stream);
 int rc_comm_kind(rc_handle_t h);
 int rc_comm_status(rc_handle_t h); /* IPC transport: RC_FLAG_COMM once a wait has timed out (synchronises the device) */
-int rc_solve_num_chains(int world, int M); /* 1 or 2: launches per sweep (measurement bookkeeping) */
+int rc_solve_num_chains(int world, int M); /* 1 or 2: launches per sweep (measurement bookkeeping; RCCL transport) */
+int rc_solve_num_chains_on(rc_handle_t h, int world, int M); /* ... on h's transport (IPC, fused exchange: one chain) */
 size_t rc_pq_assign_sinkhorn_dist_ws_bytes(int64_t B_local, int M, int K, int world);
 int rc_pq_assign_sinkhorn_dist(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B_local,
                                int D, int M, int K, double eps, int iters, uint8_t* codes_u8,

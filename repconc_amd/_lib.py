@@ -54,6 +54,7 @@ PROTOTYPES = {
     "rc_comm_kind": (_i, [_vp]),
     "rc_comm_status": (_i, [_vp]),
     "rc_solve_num_chains": (_i, [_i, _i]),
+    "rc_solve_num_chains_on": (_i, [_vp, _i, _i]),
     "rc_pq_assign_sinkhorn_dist_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rc_pq_assign_sinkhorn_dist": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_pq_decode": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),

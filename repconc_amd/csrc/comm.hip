@@ -150,16 +150,38 @@ struct ipc_blob {                            // RC_IPC_BLOB_BYTES on the wire
 };
 static_assert(sizeof(ipc_blob) == RC_IPC_BLOB_BYTES, "blob layout");
 
+// after the data: 4 KiB of control words — counters [channel][parity] (64 B apart) | status word at 2048 | first exchange
+// number of the running solve per chain at 3072 / 3136 (sk_xchg::seq_base) | this process's peer pointers at 3328 (the
+// kernels index them with a run-time rank) — then the arrival flags of the fused exchange (sinkhorn.hip, sk_xchg):
+// u64 [chain 0..1][parity][m < IPC_XMAX_M][RC_IPC_MAX_WORLD], one 128-byte line per (chain, parity, m)
+constexpr int IPC_XMAX_M = 128;              // = IPC_SLOT / (256 * 8): sub-quantisers one chain can exchange
+constexpr size_t IPC_XFLAG_BYTES = (size_t)IPC_XMAX_M * RC_IPC_MAX_WORLD * sizeof(unsigned long long);
 size_t ipc_data_bytes(int world) { return (size_t)IPC_CHANNELS * 2 * world * IPC_SLOT; }
-size_t ipc_total_bytes(int world) { return ipc_data_bytes(world) + 4096; }
+size_t ipc_total_bytes(int world) { return ipc_data_bytes(world) + 4096 + 4 * IPC_XFLAG_BYTES; }
 size_t ipc_region_off(int world, int ch, int par) { return ((size_t)ch * 2 + par) * world * IPC_SLOT; }
 size_t ipc_counter_off(int world, int ch, int par) { return ipc_data_bytes(world) + ((size_t)ch * 2 + par) * 64; }
 size_t ipc_status_off(int world) { return ipc_data_bytes(world) + 2048; }
+size_t ipc_seq_off(int world, int ch) { return ipc_data_bytes(world) + 3072 + (size_t)ch * 64; }
+size_t ipc_peers_off(int world) { return ipc_data_bytes(world) + 3328; }
+size_t ipc_xflag_off(int world, int ch, int par) { return ipc_data_bytes(world) + 4096 + ((size_t)ch * 2 + par) * IPC_XFLAG_BYTES; }
+static_assert(3328 + RC_IPC_MAX_WORLD * sizeof(char*) <= 4096, "control block");
 
 struct ipc_peers { char* p[RC_IPC_MAX_WORLD]; };
 
+// A transport that has timed out once (status & RC_FLAG_COMM) is broken for good: its rank neither waits NOR pushes any more
+// (a push without the matching wait has no back-pressure — a late but healthy peer would count it towards an exchange whose
+// region is still being rewritten); the peers run into their own time-out and flag their results.
+__device__ __forceinline__ bool ipc_broken(const int* __restrict__ status) {
+    return (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & RC_FLAG_COMM) != 0;
+}
+
 __global__ __launch_bounds__(256) void ipc_push_kernel(const char* __restrict__ src, size_t bytes, ipc_peers P,
-                                                       size_t region_off, size_t slot_off, size_t counter_off) {
+                                                       size_t region_off, size_t slot_off, size_t counter_off,
+                                                       const int* __restrict__ status) {
+    __shared__ int s_broken;
+    if (threadIdx.x == 0) s_broken = ipc_broken(status);
+    __syncthreads();
+    if (s_broken) return;
     char* dst = P.p[blockIdx.y] + region_off + slot_off;
     const size_t n16 = bytes / 16;
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
@@ -209,6 +231,13 @@ __global__ __launch_bounds__(256) void ipc_pushwait_kernel(const char* __restric
                                                            size_t slot_off, size_t counter_off, unsigned long long* __restrict__ counter,
                                                            unsigned long long want, int* __restrict__ flags, int* __restrict__ status,
                                                            long long timeout_ticks) {
+    __shared__ int s_broken;
+    if (threadIdx.x == 0) s_broken = ipc_broken(status);
+    __syncthreads();
+    if (s_broken) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && flags) atomicOr(flags, RC_FLAG_COMM);
+        return;
+    }
     char* dst = P.p[blockIdx.y] + region_off + slot_off;
     const size_t n16 = bytes / 16;
     const uint4* s4 = reinterpret_cast<const uint4*>(src);       // the solve's row sums: 16-byte aligned, a multiple of 16 bytes
@@ -225,6 +254,58 @@ __global__ __launch_bounds__(256) void ipc_pushwait_kernel(const char* __restric
 __global__ void ipc_wait_kernel(unsigned long long* __restrict__ counter, unsigned long long want, int* __restrict__ flags,
                                 int* __restrict__ status, long long timeout_ticks) {
     ipc_wait_one(counter, want, flags, status, timeout_ticks);
+}
+
+// ---- fused exchange of the Sinkhorn row sums (sk_xchg, sinkhorn.hip): the pieces that are not inside the sweep ---------------
+// first exchange number of the solve on each chain, read by the (possibly replayed) sweeps through sk_xchg::seq_base
+__global__ void xchg_set_seq_kernel(unsigned long long* __restrict__ s0, unsigned long long v0, unsigned long long* __restrict__ s1,
+                                    unsigned long long v1) {
+    *s0 = v0;
+    *s1 = v1;
+}
+// One thread per (m, rank) flag of exchange number `t` of the solve (flag value seq_base + t + 1): used where no sweep follows
+// that could wait in its prologue (before the argmax pass, on a rank without rows) and instead of the in-prologue wait when ranks
+// share a device (a sweep whose blocks spin for a peer would keep that peer's sweep off the CUs).
+__global__ __launch_bounds__(256) void xchg_flagwait_kernel(const unsigned long long* __restrict__ xflags, int M, int world,
+                                                            const unsigned long long* __restrict__ seq_base, int t,
+                                                            int* __restrict__ flags, int* __restrict__ status,
+                                                            long long timeout_ticks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * world) return;
+    const unsigned long long* fp = xflags + (size_t)(i / world) * RC_IPC_MAX_WORLD + (i % world);
+    const unsigned long long want = *seq_base + (unsigned long long)t + 1ull;
+    if (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return;
+    if (ipc_broken(status)) { atomicOr(flags, RC_FLAG_COMM); return; }
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > timeout_ticks) {
+            atomicOr(flags, RC_FLAG_COMM);
+            atomicOr(status, RC_FLAG_COMM);
+            return;
+        }
+    }
+}
+// a rank without rows: block m stores `rows` (zeros) [M][K] and the flags exactly as a sweep's reducer would
+__global__ __launch_bounds__(RC_K) void xchg_rowpush_kernel(const double* __restrict__ rows, int M, int t, const sk_xchg x,
+                                                            int* __restrict__ flags) {
+    __shared__ int s_broken;
+    if (threadIdx.x == 0) s_broken = ipc_broken(x.status);
+    __syncthreads();
+    if (s_broken) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flags, RC_FLAG_COMM);
+        return;
+    }
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const double v = rows[(size_t)m * RC_K + tid];
+    const size_t off = x.push_data_off + (((size_t)x.rank * M + m) * RC_K + tid) * sizeof(double);
+    for (int p = 0; p < x.world; ++p)
+        __hip_atomic_store(reinterpret_cast<double*>(x.peers[p] + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < x.world)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(x.peers[tid] + x.push_flag_off) + (size_t)m * RC_IPC_MAX_WORLD + x.rank,
+                           *x.seq_base + (unsigned long long)t + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // distance range over ranks: gathered [world][2M] (max then min per rank) -> minmax [2M]
@@ -264,10 +345,10 @@ int ipc_exchange(rc_handle_t h, int ch, unsigned long long n, const void* src, s
     }
     if (bytes)
         hipLaunchKernelGGL(ipc_push_kernel, dim3(IPC_PUSH_BLOCKS, world), dim3(256), 0, s, (const char*)src, bytes, P, roff,
-                           (size_t)rank * bytes, coff);
+                           (size_t)rank * bytes, coff, (const int*)(h->ipc.mine + ipc_status_off(world)));
     else   // nothing to send still signals (keeps the counters of all ranks in step)
         hipLaunchKernelGGL(ipc_push_kernel, dim3(IPC_PUSH_BLOCKS, world), dim3(256), 0, s, (const char*)h->ipc.mine, (size_t)0, P,
-                           roff, (size_t)0, coff);
+                           roff, (size_t)0, coff, (const int*)(h->ipc.mine + ipc_status_off(world)));
     RC_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)(h->ipc.mine + coff),
                        (unsigned long long)IPC_PUSH_BLOCKS * world, flags, (int*)(h->ipc.mine + ipc_status_off(world)),
@@ -357,6 +438,8 @@ extern "C" int rc_comm_ipc_connect(rc_handle_t h, const void* blobs_host) {
         }
         h->ipc.peer[r] = (char*)q;
     }
+    // the peer pointers as this process maps them, for kernels that index them with a run-time rank (sk_xchg::peers)
+    RC_HIP_CHECK(h, hipMemcpy(h->ipc.mine + ipc_peers_off(world), h->ipc.peer, (size_t)world * sizeof(char*), hipMemcpyHostToDevice));
     h->ipc.on = 1;
     return RC_OK;
 }
@@ -447,14 +530,27 @@ dist_ws dist_layout(int64_t B, int M, int world, bool split) {
     L.total = o;
     return L;
 }
-bool want_split(int world) {
-    // Default: two chains as soon as there is a collective to hide.  On one GPU the split buys 4-5 % at 49 152 rows
-    // (the tail of one sweep overlaps the head of the other: 43.3 -> 41.5 ms per step, round 4), nothing at 6 144, and
-    // nothing on top of the rotating wave priority of the sweep (sinkhorn.hip, sk_setprio: 41.2 ms in one chain), and
-    // it makes per-launch timings overlap: it stays off unless RC_DIST_SPLIT=1.
+// The exchange of the row sums inside the sweep kernels (sk_xchg): IPC transport + version-2 sweep.  RC_IPC_XSWEEP=0: the
+// round-3/4 form (sweep, then a push + wait kernel per chain and iteration).
+bool want_xsweep(rc_handle_t h) { return h->ipc.on && rc_sk_xchg_capable() && rc_env_int("RC_IPC_XSWEEP", 1) != 0; }
+// ... and the wait for the previous exchange inside the next sweep's prologue: only when no peer shares this device — blocks
+// that spin for a peer's row sums would hold the CU slots that peer's sweep needs (the one-GPU test boxes).  RC_IPC_INWAIT
+// forces it either way (tests: small grids that fit the device together, short time-out).
+bool want_inwait(rc_handle_t h) {
+    const char* e = getenv("RC_IPC_INWAIT");
+    if (e && *e) return atoi(e) != 0;
+    return !h->ipc.shared_device;
+}
+// One chain or two (RC_DIST_SPLIT overrides).  A rule every rank evaluates identically (world, transport): two chains exist
+// to hide a collective behind the other chain's sweep and cost 18-20 us per iteration on their own (twice the per-block
+// prologue and hand-over); with the exchange fused into the sweep there is no collective launch left to hide, so
+// the IPC transport runs ONE chain at every batch size; RCCL (a ~20-30 us collective per iteration) keeps two.  On one GPU the
+// split buys nothing on top of the rotating wave priority of the sweep (round 4) and makes per-launch timings overlap.
+bool want_split(rc_handle_t h, int world) {
     const char* e = getenv("RC_DIST_SPLIT");
-    if (e) return atoi(e) != 0;
-    return world > 1;
+    if (e && *e) return atoi(e) != 0;
+    if (world <= 1) return false;
+    return !(h && want_xsweep(h));
 }
 }  // namespace
 
@@ -476,7 +572,26 @@ struct solve_ctx {
     rc_handle_t h; nccl_api* n; const dist_ws* L; char* w; float* d; float* minmax; int64_t B; int M, G; double eps;
     int* flags; hipStream_t st[2]; bool fuse_centre, coll, ipc;
     unsigned long long ipc_base[2];      // exchange number of sweep 0 on channel 0 / 1 (IPC transport)
+    bool xsweep, inwait; int iters;      // exchange fused into the sweeps (sk_xchg); wait in the next sweep's prologue
 };
+// sk_xchg of sweep t of chain ch (exchange number ipc_base[ch] + t; the previous one has the other parity)
+sk_xchg xchg_of(const solve_ctx& c, int ch, int t) {
+    const int world = c.G, par = (int)((c.ipc_base[ch] + (unsigned long long)t) & 1);
+    char* mine = c.h->ipc.mine;
+    sk_xchg x;
+    x.push = 1;
+    x.wait = (t > 0 && c.inwait) ? 1 : 0;
+    x.rank = c.h->comm_rank;
+    x.world = world;
+    x.peers = reinterpret_cast<char* const*>(mine + ipc_peers_off(world));
+    x.push_data_off = ipc_region_off(world, ch, par);
+    x.push_flag_off = ipc_xflag_off(world, ch, par);
+    x.wait_flags = reinterpret_cast<const unsigned long long*>(mine + ipc_xflag_off(world, ch, par ^ 1));
+    x.seq_base = reinterpret_cast<const unsigned long long*>(mine + ipc_seq_off(world, ch));
+    x.status = reinterpret_cast<int*>(mine + ipc_status_off(world));
+    x.timeout_ticks = ipc_timeout_ticks();
+    return x;
+}
 // where the gathered [G, mc, K] row sums of sweep t of chain ch live: the workspace ping-pong, or (IPC transport) this
 // rank's receive region of that exchange
 const double* gathered_rows(const solve_ctx& c, int ch, int t) {
@@ -494,6 +609,31 @@ int solve_iteration(const solve_ctx& c, int t) {
         // one rank: the sweep writes its row sums straight into the "gathered" slot
         double* rows = c.coll ? (double*)(c.w + cw.rows) : out;
         int rc = RC_OK;
+        if (c.xsweep) {
+            // ONE launch per iteration: the reducer of every sub-quantiser pushes its row sums, the next sweep's prologue
+            // (or, ranks sharing a device / no sweep to follow, a flag-wait kernel) waits for the peers'
+            const sk_xchg x = xchg_of(c, ch, t);
+            const size_t swb = rc_sk_ws_bytes(c.B > 0 ? c.B : 1, mc, RC_K);
+            if (c.B == 0) {
+                hipLaunchKernelGGL(xchg_rowpush_kernel, dim3(mc), dim3(RC_K), 0, c.st[ch], (const double*)(c.w + cw.rows), mc, t, x,
+                                   c.flags);
+                RC_LAUNCH_CHECK(c.h);
+            } else if (t == 0 && c.fuse_centre) {
+                rc = rc_sk_sweep0_centre(c.h, dc, c.minmax + L.m0[ch], c.minmax + c.M + L.m0[ch], (double*)(c.w + cw.g),
+                                         (double*)(c.w + cw.colsum), nullptr, c.B, mc, c.eps, c.flags, c.w + cw.sweep, swb, c.st[ch], &x);
+            } else {
+                rc = rc_sk_sweep_x(c.h, dc, prev, c.G, (double*)(c.w + cw.f2), (double*)(c.w + cw.g), (double*)(c.w + cw.colsum),
+                                   nullptr, c.B, mc, c.eps, t, c.flags, c.w + cw.sweep, swb, c.st[ch], &x);
+            }
+            if (rc != RC_OK) return rc;
+            if (!c.inwait || c.B == 0 || t == c.iters - 1) {
+                hipLaunchKernelGGL(xchg_flagwait_kernel, dim3((mc * c.G + 255) / 256), dim3(256), 0, c.st[ch],
+                                   reinterpret_cast<const unsigned long long*>(c.h->ipc.mine + x.push_flag_off), mc, c.G, x.seq_base, t,
+                                   c.flags, x.status, x.timeout_ticks);
+                RC_LAUNCH_CHECK(c.h);
+            }
+            continue;
+        }
         if (c.B == 0) {
             // a rank without rows contributes zero row sums (already zeroed) and only takes part in the exchange
         } else if (t == 0 && c.fuse_centre) {
@@ -544,8 +684,13 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
         return RC_OK;
     }
     const int64_t Bw = B > 0 ? B : 1;                        // workspace geometry of an empty rank
-    const dist_ws L = dist_layout(Bw, M, G, want_split(G));
+    const dist_ws L = dist_layout(Bw, M, G, want_split(h, G));
     if (!ws || ws_bytes < L.total + 256) return RC_EWORKSPACE;
+    // the IPC transport moves one chain's [mc, K] fp64 row sums per exchange through a fixed slot: refuse BEFORE anything is
+    // enqueued (MCQ_M > 128 in one chain, > 256 in two; RC_COMM=rccl has no such limit)
+    if (coll && ipc)
+        for (int c = 0; c < L.nch; ++c)
+            if ((size_t)L.mc[c] * RC_K * sizeof(double) > IPC_SLOT || L.mc[c] > IPC_XMAX_M) return RC_ESHAPE;
     char* w = (char*)ws;
     float* d = (float*)(w + L.d);
     float* minmax = (float*)(w + L.minmax);
@@ -577,11 +722,18 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
     if (B > 0 && !fuse_centre && (rc = rc_pq_centre(h, d, minmax, B, M, RC_K, (rc_stream_t)s0)) != RC_OK) return rc;
 
     const bool use_ipc = coll && ipc;
+    const bool xsweep = use_ipc && want_xsweep(h);
     solve_ctx cx = {h, n, &L, w, d, minmax, B, M, G, eps, own_flags, {s0, s0}, fuse_centre, coll, use_ipc,
-                    {h->ipc.seq[0], h->ipc.seq[1]}};
+                    {h->ipc.seq[0], h->ipc.seq[1]}, xsweep, xsweep && want_inwait(h), iters};
     if (use_ipc) {   // this solve's exchanges are numbered base .. base + iters - 1 on each channel it uses
         h->ipc.seq[0] += (unsigned long long)iters;
         if (L.nch == 2) h->ipc.seq[1] += (unsigned long long)iters;
+    }
+    if (xsweep) {    // the sweeps (eager or replayed) read their exchange numbers relative to these words
+        hipLaunchKernelGGL(xchg_set_seq_kernel, dim3(1), dim3(1), 0, s0,
+                           reinterpret_cast<unsigned long long*>(h->ipc.mine + ipc_seq_off(G, 0)), cx.ipc_base[0],
+                           reinterpret_cast<unsigned long long*>(h->ipc.mine + ipc_seq_off(G, 1)), cx.ipc_base[1]);
+        RC_LAUNCH_CHECK(h);
     }
     if (L.nch == 2) {
         if ((rc = ensure_side_stream(h)) != RC_OK) return rc;
@@ -606,7 +758,8 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
     // sweeps t = 0 .. iters-1, the two chains enqueued alternately so both streams stay fed
     const int variant = (rc_env_int("RC_SK_V1", 0) | (rc_env_int("RC_SK_FKLDS", 1) << 1) | (rc_env_int("RC_SK_NB", 0) << 2) |
                          (rc_env_int("RC_SK_CPB", 0) << 14) | ((int)coll << 24) | ((int)use_ipc << 25) |
-                         ((int)(cx.ipc_base[0] & 1) << 26) | ((int)(cx.ipc_base[1] & 1) << 27)) ^
+                         ((int)(cx.ipc_base[0] & 1) << 26) | ((int)(cx.ipc_base[1] & 1) << 27) | ((int)cx.xsweep << 28) |
+                         ((int)cx.inwait << 29)) ^
                         (int)((unsigned)(rc_env_int("RC_SK_PRIO", -1) + 1) * 0x10000001u);   // (a captured launch keeps its priority setting)
     // per-launch event marks (profile mode 1) need the eager loop; the bracket mode (2) times the whole run of sweeps
     const bool want_graph = rc_env_int("RC_GRAPH", 1) != 0 && h->profile_on != 1 && !h->graph_broken && iters > 4;
@@ -680,7 +833,9 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
 }
 
 // number of independent chains (launches per sweep) the solve uses for `world` ranks and M sub-quantisers
-extern "C" int rc_solve_num_chains(int world, int M) { return (want_split(world) && M >= 2) ? 2 : 1; }
+extern "C" int rc_solve_num_chains(int world, int M) { return (want_split(nullptr, world) && M >= 2) ? 2 : 1; }
+// ... on THIS handle's transport (the IPC transport with the exchange fused into the sweeps runs one chain)
+extern "C" int rc_solve_num_chains_on(rc_handle_t h, int world, int M) { return (want_split(h, world) && M >= 2) ? 2 : 1; }
 
 extern "C" size_t rc_pq_assign_sinkhorn_dist_ws_bytes(int64_t B_local, int M, int K, int world) {
     if (B_local < 0 || M <= 0 || K != RC_K || world < 1) return 0;

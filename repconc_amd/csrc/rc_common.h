@@ -52,6 +52,20 @@ struct rc_handle_s {
     unsigned long long km_calls;                      // parity picks the hint word read / written by a call
 };
 
+// Fused exchange of the Sinkhorn row sums (sinkhorn.hip: sk_sweep2_kernel<.., XCHG = true>; set up by comm.hip on the IPC
+// transport).  Passed by value in the kernel arguments.
+struct sk_xchg {
+    int push;                                 // the reducer of sub-quantiser m stores its [K] sums + flag (m, rank) at every peer
+    int wait;                                 // the prologue waits for the `world` flags of m of the PREVIOUS exchange
+    int rank, world;
+    char* const* peers;                       // device array [world]: every rank's receive buffer as mapped here
+    size_t push_data_off, push_flag_off;      // byte offsets (the same in every rank's buffer) of THIS sweep's exchange
+    const unsigned long long* wait_flags;     // my flags of the previous exchange, u64 [M][RC_IPC_MAX_WORLD]
+    const unsigned long long* seq_base;       // device word: number of the solve's first exchange on this channel
+    int* status;                              // the transport's status word (RC_FLAG_COMM once broken)
+    long long timeout_ticks;                  // of the 100 MHz clock
+};
+
 // comm.hip: the full constrained assignment as one or two chains of sub-quantisers (world == 1: no RCCL)
 size_t rc_solve_ws_bytes(int64_t B, int M, int world);
 int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, int64_t B, int D, int M, double eps,
@@ -59,7 +73,12 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
                     hipStream_t s0);
 int rc_sk_sweep0_centre(rc_handle_t h, float* d, const float* mx, const float* mn, double* g, double* colsum,
                         double* rows_out, int64_t B, int M, double eps, int* flags, void* ws, size_t ws_bytes,
-                        hipStream_t s);
+                        hipStream_t s, const sk_xchg* xc = nullptr);
+// rc_sk_sweep with the row sums leaving / arriving through `xc` (version-2 sweep only; nullptr = rc_sk_sweep)
+int rc_sk_sweep_x(rc_handle_t h, const float* d, const double* rows_prev, int G, double* f2, double* g, double* colsum,
+                  double* rows_out, int64_t B, int M, double eps, int t, int* flags, void* ws, size_t ws_bytes,
+                  hipStream_t s, const sk_xchg* xc);
+bool rc_sk_xchg_capable();                    // the version-2 sweep is selected (RC_SK_V1 unset)
 int rc_sk_argmax_strided(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2, int64_t B,
                          int M, double eps, int t, int code_stride, int m_offset, uint8_t* codes_u8,
                          int64_t* codes_i64, int* flags, hipStream_t s);

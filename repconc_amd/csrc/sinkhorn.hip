@@ -446,14 +446,46 @@ __device__ __forceinline__ void sk_setprio(int p) {     // s_setprio takes an im
 }
 #define SK_PRIO_SHIFT 10                 // 2^10 ticks of 10 ns
 
+// ---- fused exchange (round 5; IPC transport of comm.hip, modeling_repconc.py:155-157) ------------------------------------------
+// One Sinkhorn iteration on N > 1 ranks is ONE launch: the block that reduces sub-quantiser m's partials stores the [K] row
+// sums straight into every peer's receive region (slot `rank` of the dense [world][M][K] all-gather result) and, once its
+// stores have drained, writes the exchange's sequence number into flag (m, rank) of every peer; the next sweep's blocks of m
+// wait for the `world` flags of m in their prologue — AFTER the exp2 table and the first column have been requested, so the
+// flight time of the peers' stores hides behind those loads — and read the gathered sums with system-scope loads.
+// Sequence numbers never repeat (seq_base: a device word the solve sets before its first sweep, so a replayed graph reads the
+// current one), hence nothing is re-armed and a late or repeated arrival cannot be mistaken for the next exchange; the
+// two-parity argument of comm.hip covers the regions, per sub-quantiser: rank q's push of (exchange n + 2, m) follows its
+// m-blocks' wait for MY push of (n + 1, m), which my reducer issues after all my m-blocks of sweep n + 1 have read region n.
+// A wait that times out raises RC_FLAG_COMM in the result flags and in the transport's status word; a broken transport
+// neither waits nor pushes (peers time out instead of reading half an exchange).
+__device__ __forceinline__ bool sk_xchg_wait_flag(const unsigned long long* __restrict__ fp, unsigned long long want,
+                                                  const sk_xchg& x, int* __restrict__ flags) {
+    if (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
+    if (__hip_atomic_load(x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & RC_FLAG_COMM) {
+        atomicOr(flags, RC_FLAG_COMM);
+        return false;
+    }
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > x.timeout_ticks) {
+            atomicOr(flags, RC_FLAG_COMM);
+            atomicOr(x.status, RC_FLAG_COMM);
+            return false;
+        }
+    }
+    return true;
+}
+
 // MODE 0: first sweep on a centred table; 1: first sweep, centring fused (d holds the raw table); 2: sweep t >= 1.
-template <int MODE, bool FKLDS>
+// XCHG: the row sums leave through sk_xchg (x.push) and / or the prologue waits for the previous exchange (x.wait).
+template <int MODE, bool FKLDS, bool XCHG = false>
 __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_sweep2_kernel(
     float* __restrict__ d, const double* __restrict__ rows_prev, int G, const double* __restrict__ f_in,
     double* __restrict__ f_out, int* __restrict__ gq, double* __restrict__ part, unsigned* __restrict__ counters,
     double* __restrict__ rows_out, unsigned B, int M, unsigned rq, unsigned rr, double nse, double scale, double lmax,
     const double* __restrict__ exp2_tab, int t, int* __restrict__ flags, const float* __restrict__ cmx,
-    const float* __restrict__ cmn, int prio_shift, int blocks_per_round) {
+    const float* __restrict__ cmn, int prio_shift, int blocks_per_round, const sk_xchg x) {
     constexpr bool FIRST = MODE != 2;
     static_assert(!(FIRST && FKLDS), "the first sweep has no row potentials");
     __shared__ __attribute__((aligned(16))) double s_tab[SK2_N];      // red[16][256] aliases it after the main loop
@@ -469,11 +501,23 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
     const unsigned c0 = sk2_range_lo(bi, rq, rr), c1 = sk2_range_lo(bi + 1u, rq, rr);
     bool bad = false;
     {
-        // ---- (a) everything with a long latency first: the table, the first column
-        double2 tv[SK2_N / 2 / SK_THREADS];
+        // ---- (a) everything with a long latency first: the table, the first column.  XCHG: the table goes global -> LDS
+        // by DMA (global_load_lds_dwordx4, no registers: the wait below must not push the prologue into scratch)
+        constexpr bool TAB_DMA = XCHG;
+        double2 tv[TAB_DMA ? 1 : SK2_N / 2 / SK_THREADS];
+        if constexpr (TAB_DMA) {
 #pragma unroll
-        for (int j = 0; j < SK2_N / 2 / SK_THREADS; ++j)
-            tv[j] = reinterpret_cast<const double2*>(exp2_tab)[j * SK_THREADS + tid];
+            for (int j = 0; j < SK2_N / 2 / SK_THREADS; ++j) {
+                const int w0 = j * SK_THREADS + (tid & ~63);              // first 16-byte chunk of this wave (wave-uniform)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(reinterpret_cast<const double2*>(exp2_tab) + w0 + (tid & 63)),
+                    (__attribute__((address_space(3))) void*)(reinterpret_cast<double2*>(s_tab) + w0), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SK2_N / 2 / SK_THREADS; ++j)
+                tv[j] = reinterpret_cast<const double2*>(exp2_tab)[j * SK_THREADS + tid];
+        }
         float* dm = d + (size_t)m * B * RC_K + lane * 4;
         int* gm = gq + (size_t)m * B;
         float xa[SK_EPL], xb[SK_EPL];
@@ -489,13 +533,33 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
         double rs = 1.0, fo = 0.0;
         if constexpr (!FIRST) {
             rs = 0.0;
-            for (int r = 0; r < G; ++r) rs += rows_prev[((size_t)r * M + m) * RC_K + tid];
+            if constexpr (XCHG) {
+                if (x.wait) {
+                    // lanes r < world of every wave watch flag (m, r) of the previous exchange (number seq_base + t - 1,
+                    // written as seq_base + t); the gathered sums are then read past every cache
+                    const int wl = tid & 63;
+                    if (wl < G)
+                        (void)sk_xchg_wait_flag(x.wait_flags + (size_t)m * RC_IPC_MAX_WORLD + wl,
+                                                *x.seq_base + (unsigned long long)t, x, flags);
+                    for (int r = 0; r < G; ++r)
+                        rs += __hip_atomic_load(rows_prev + ((size_t)r * M + m) * RC_K + tid, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    for (int r = 0; r < G; ++r) rs += rows_prev[((size_t)r * M + m) * RC_K + tid];
+                }
+            } else {
+                for (int r = 0; r < G; ++r) rs += rows_prev[((size_t)r * M + m) * RC_K + tid];
+            }
             bad |= !(rs > 0.0) || !(rs < INFINITY);
             if (t > 1) fo = f_in[(size_t)m * RC_K + tid];
         }
+        if constexpr (TAB_DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the table have landed
+        } else {
 #pragma unroll
-        for (int j = 0; j < SK2_N / 2 / SK_THREADS; ++j)
-            reinterpret_cast<double2*>(s_tab)[j * SK_THREADS + tid] = tv[j];
+            for (int j = 0; j < SK2_N / 2 / SK_THREADS; ++j)
+                reinterpret_cast<double2*>(s_tab)[j * SK_THREADS + tid] = tv[j];
+        }
         double fn = 0.0;
         if constexpr (!FIRST) {
             fn = fo - log(rs);
@@ -579,10 +643,14 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
         __syncthreads();
         if (tid_e == 0) {
             const unsigned old = __hip_atomic_fetch_add(counters + m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (old + 1u == cnt);
+            int last = (old + 1u == cnt);
             // the last arriver re-arms the counter: the next sweep may use another grid (first sweep: 4 blocks per CU,
             // register-potential sweeps: 3), so nothing may depend on the count left behind
-            if (old + 1u == cnt) __hip_atomic_store(counters + m, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last) __hip_atomic_store(counters + m, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (XCHG)      // 2: the reducer also pushes (decided by one thread: the branch holds a barrier)
+                if (last && x.push && !(__hip_atomic_load(x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & RC_FLAG_COMM))
+                    last = 2;
+            s_last = last;
         }
         __syncthreads();
         if (s_last) {
@@ -599,7 +667,24 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
             }
             for (; i < cnt; ++i)
                 acc += __hip_atomic_load(pm + (size_t)i * RC_K + tid_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            rows_out[(size_t)m * RC_K + tid_e] = acc;
+            if (rows_out) rows_out[(size_t)m * RC_K + tid_e] = acc;
+            if constexpr (XCHG) {
+                if (s_last == 2) {
+                    // slot `rank` of every peer's region of this exchange: write-through system-scope stores, drained by
+                    // every wave, then the sequence number into flag (m, rank) of each peer (one lane per peer)
+                    const size_t off = x.push_data_off + (((size_t)x.rank * M + m) * RC_K + tid_e) * sizeof(double);
+                    for (int p = 0; p < x.world; ++p)
+                        __hip_atomic_store(reinterpret_cast<double*>(x.peers[p] + off), acc, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid_e < x.world)
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(x.peers[tid_e] + x.push_flag_off) +
+                                               (size_t)m * RC_IPC_MAX_WORLD + x.rank,
+                                           *x.seq_base + (unsigned long long)t + 1ull, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
         }
     }
     if (__any(bad) && (tid & 63) == 0) atomicOr(flags, RC_FLAG_NONFINITE);
@@ -679,7 +764,7 @@ static sk_sweep_ws sk_ws(int64_t B, int M) {
 // int32 [M*B] column exponents.
 static int sk2_launch(rc_handle_t h, int mode, float* d, const double* rows_prev, int G, double* f2, double* g,
                       double* rows_out, int64_t B, int M, double eps, int t, int* flags, void* ws, const float* mx,
-                      const float* mn, hipStream_t s) {
+                      const float* mn, hipStream_t s, const sk_xchg* xc = nullptr) {
     const sk_sweep_ws W = sk_ws(B, M);
     const double* tab = rc_exp2_table(h, SK2_TB);
     if (!tab) return RC_EHIP;
@@ -702,28 +787,23 @@ static int sk2_launch(rc_handle_t h, int mode, float* d, const double* rows_prev
     const int prio_env = rc_env_int("RC_SK_PRIO", -1);
     const int prio_shift = prio_env == 0 ? -1 : (prio_env > 0 ? prio_env - 1 : SK_PRIO_SHIFT);
     const int per_round = (h && h->num_cus > 0) ? h->num_cus : 256;
+    const sk_xchg x0 = {};
+    const sk_xchg xv = xc ? *xc : x0;
+#define SK2_GO(MODE, FK, XC)                                                                                              \
+    hipLaunchKernelGGL((sk_sweep2_kernel<MODE, FK, XC>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in, f_out, gq, part, \
+                       counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t, flags, mx, mn, prio_shift,  \
+                       per_round, xv)
     if (mode != 2) {
         RC_HIP_CHECK(h, hipMemsetAsync(counters, 0, (size_t)M * sizeof(unsigned), s));
-        if (mode == 0)
-            hipLaunchKernelGGL((sk_sweep2_kernel<0, false>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
-                               f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
-                               flags, mx, mn, prio_shift, per_round);
-        else
-            hipLaunchKernelGGL((sk_sweep2_kernel<1, false>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
-                               f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
-                               flags, mx, mn, prio_shift, per_round);
+        if (mode == 0) { if (xc) SK2_GO(0, false, true); else SK2_GO(0, false, false); }
+        else           { if (xc) SK2_GO(1, false, true); else SK2_GO(1, false, false); }
     } else {
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
-        if (fklds)
-            hipLaunchKernelGGL((sk_sweep2_kernel<2, true>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
-                               f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
-                               flags, mx, mn, prio_shift, per_round);
-        else
-            hipLaunchKernelGGL((sk_sweep2_kernel<2, false>), grid, dim3(SK_THREADS), 0, s, d, rows_prev, G, f_in,
-                               f_out, gq, part, counters, rows_out, Bu, M, Bu / nbm, Bu % nbm, nse, scale, lmax, tab, t,
-                               flags, mx, mn, prio_shift, per_round);
+        if (fklds) { if (xc) SK2_GO(2, true, true); else SK2_GO(2, true, false); }
+        else       { if (xc) SK2_GO(2, false, true); else SK2_GO(2, false, false); }
         rc_prof_mark(h, RC_PROF_SK_PASS, s);
     }
+#undef SK2_GO
     RC_LAUNCH_CHECK(h);
     return RC_OK;
 }
@@ -731,6 +811,19 @@ static int sk2_launch(rc_handle_t h, int mode, float* d, const double* rows_prev
 extern "C" size_t rc_sk_ws_bytes(int64_t B, int M, int K) {
     if (B <= 0 || M <= 0 || K != RC_K) return 0;
     return sk_ws(B, M).total;
+}
+
+bool rc_sk_xchg_capable() { return sk_use_v2(); }
+
+int rc_sk_sweep_x(rc_handle_t h, const float* d, const double* rows_prev, int G, double* f2, double* g, double* colsum,
+                  double* rows_out, int64_t B, int M, double eps, int t, int* flags, void* ws, size_t ws_bytes,
+                  hipStream_t s, const sk_xchg* xc) {
+    if (!xc) return rc_sk_sweep(h, d, rows_prev, G, f2, g, colsum, rows_out, B, M, RC_K, eps, t, flags, ws, ws_bytes, (rc_stream_t)s);
+    if (!sk_use_v2() || !h || !d || !flags || B <= 0 || M <= 0 || t < 0 || !(eps > 0.0)) return RC_EINVAL;
+    if (t > 0 && (!rows_prev || G <= 0 || !f2 || !g)) return RC_EINVAL;
+    if (!ws || ws_bytes < sk_ws(B, M).total) return RC_EWORKSPACE;
+    return sk2_launch(h, t == 0 ? 0 : 2, const_cast<float*>(d), rows_prev, G, f2, g, rows_out, B, M, eps, t, flags, ws, nullptr,
+                      nullptr, s, xc);
 }
 
 extern "C" int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_prev, int G, double* f2, double* g,
@@ -785,11 +878,12 @@ extern "C" int rc_sk_sweep(rc_handle_t h, const float* d, const double* rows_pre
 // minima.  Equivalent to rc_pq_centre followed by rc_sk_sweep(t = 0).
 int rc_sk_sweep0_centre(rc_handle_t h, float* d, const float* mx, const float* mn, double* g, double* colsum,
                         double* rows_out, int64_t B, int M, double eps, int* flags, void* ws, size_t ws_bytes,
-                        hipStream_t s) {
+                        hipStream_t s, const sk_xchg* xc) {
     const sk_sweep_ws W = sk_ws(B, M);
     if (!ws || ws_bytes < W.total) return RC_EWORKSPACE;
     if (sk_use_v2())
-        return sk2_launch(h, 1, d, nullptr, 1, nullptr, g, rows_out, B, M, eps, 0, flags, ws, mx, mn, s);
+        return sk2_launch(h, 1, d, nullptr, 1, nullptr, g, rows_out, B, M, eps, 0, flags, ws, mx, mn, s, xc);
+    if (xc) return RC_EINVAL;
     const double* tab = rc_exp2_table(h, SK_TB);
     if (!tab) return RC_EHIP;
     double* part = (double*)((char*)ws + W.part);

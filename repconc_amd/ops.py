@@ -246,6 +246,7 @@ def comm_transport() -> str:
 
 
 RC_IPC_MAX_WORLD = 16
+IPC_MAX_M = 128        # csrc/comm.hip: IPC_XMAX_M (sub-quantisers per chain on the IPC transport)
 
 
 def _all_ranks_ok(ok: bool, group) -> bool:
@@ -321,26 +322,35 @@ def comm_init(group=None, transport: Optional[str] = None) -> str:
     if dev in _comm_ready:                                  # another process group / transport: start over
         comm_destroy(group_barrier=False)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    import logging
+    log = logging.getLogger(__name__)
     tried = []
     if want in ("ipc", "auto"):
         ipc_possible = world <= RC_IPC_MAX_WORLD and _same_node(group)
         if ipc_possible and _connect_ipc(lib, h, rank, world, group):
             _comm_ready[dev] = (key0, "ipc")
+            log.info("comm_init: rank %d / %d on cuda:%d exchanges over the IPC transport", rank, world, dev)
             return "ipc"
         tried.append("ipc (world > 16 or ranks on several hosts)" if not ipc_possible else "ipc (export / connect failed on a rank)")
-        if want == "ipc" and rc_env_strict():
-            raise _lib.RepconcHipError("comm_init: the IPC transport is unavailable: " + tried[-1])
+        # an EXPLICIT request for ipc (argument or RC_COMM=ipc) is strict: ranks that share one GPU cannot run RCCL at all
+        # (its ncclCommInitRank would hang, not fail), so only "auto" falls back.  RC_COMM_STRICT=0 restores the fall-back.
+        if want == "ipc" and rc_env_strict(default=True):
+            raise _lib.RepconcHipError("comm_init: the IPC transport was requested and is unavailable: " + tried[-1] +
+                                       " (RC_COMM=auto or RC_COMM_STRICT=0 fall back to rccl)")
+        log.warning("comm_init: %s; falling back to rccl", tried[-1])
     if _connect_rccl(lib, h, dev, rank, world, group):
         _comm_ready[dev] = (key0, "rccl")
+        log.info("comm_init: rank %d / %d on cuda:%d exchanges over RCCL", rank, world, dev)
         return "rccl"
     tried.append("rccl (rc_comm_init failed on a rank)")
     raise _lib.RepconcHipError("comm_init: no exchange transport could be set up on all ranks: " + "; ".join(tried))
 
 
-def rc_env_strict() -> bool:
-    """RC_COMM_STRICT=1: an explicitly requested transport that is unavailable raises instead of falling back (tests)."""
+def rc_env_strict(default: bool = False) -> bool:
+    """RC_COMM_STRICT=1 / 0: whether an explicitly requested transport that is unavailable raises instead of falling back."""
     import os
-    return os.environ.get("RC_COMM_STRICT", "0") == "1"
+    v = os.environ.get("RC_COMM_STRICT", "")
+    return default if v == "" else v == "1"
 
 
 _comm_flags = {}       # device index -> int32 flags word passed to every rc_comm_allgather of that device
@@ -426,6 +436,10 @@ def assign_sinkhorn_dist(x: torch.Tensor, centroids: torch.Tensor, eps: float, i
     world = lib.rc_comm_world(h)
     if world < 1:
         raise _lib.RepconcHipError("assign_sinkhorn_dist: call ops.comm_init() first")
+    if lib.rc_comm_kind(h) == 2 and M > IPC_MAX_M * lib.rc_solve_num_chains_on(h, world, M):
+        raise _lib.RepconcHipError(f"assign_sinkhorn_dist: MCQ_M = {M} exceeds what the IPC transport exchanges per chain "
+                                   f"({IPC_MAX_M} sub-quantisers: [M, 256] fp64 row sums through a 256 KiB slot); "
+                                   "set RC_COMM=rccl for this model")
     codes = torch.empty((B, M), dtype=dtype, device=x.device)
     flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
     # a rank without rows (ragged last batch) still takes part in every collective of the solve

@@ -3,6 +3,7 @@
     python tests/ipc_rank_worker.py solve <case> <cut_0> ... <cut_world>     constrained codes of rows [cut_r, cut_r+1)
     python tests/ipc_rank_worker.py allgather                                 rc_comm_allgather, several sizes
     python tests/ipc_rank_worker.py timeout                                   a missing peer is reported, not waited for
+    python tests/ipc_rank_worker.py timeout_solve                             ... inside a whole solve (fused exchange)
     python tests/ipc_rank_worker.py warmup                                    corpus-sharded OPQ + PQ training
     python tests/ipc_rank_worker.py search                                    row-sharded + replicated search gathers
     python tests/ipc_rank_worker.py encode                                    corpus encoding, rows split over the ranks
@@ -70,6 +71,28 @@ def main() -> int:
         ops.comm_destroy()
         dist.destroy_process_group()
         return rc
+    if what == "timeout_solve":
+        # rank 0 runs a whole solve with a 300 ms limit while its peer never calls: every wait of the fused exchange (flag-wait
+        # kernels, or the sweeps' prologues with RC_IPC_INWAIT=1) gives up ONCE, the rest of the solve neither waits nor pushes
+        os.environ["RC_IPC_TIMEOUT_MS"] = "300"
+        ops.comm_init(transport="ipc")
+        if rank == 0:
+            import time
+            xl = torch.randn(512, 768, device=dev)
+            Ct = torch.randn(48, 256, 16, device=dev)
+            lib, h = _lib.load(), _lib.handle(local)
+            t0 = time.perf_counter()
+            _, flags = ops.assign_sinkhorn_dist(xl, Ct, EPS, ITERS, torch.uint8)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ok = bool(int(flags.item()) & _lib.RC_FLAG_COMM) and bool(lib.rc_comm_status(h) & _lib.RC_FLAG_COMM) and dt < 5.0
+            if not ok:
+                print(f"rank 0: flags {int(flags.item())}, status {lib.rc_comm_status(h)}, {dt:.2f} s")
+            rc = 0 if ok else 1
+        dist.barrier()
+        ops.comm_destroy()
+        dist.destroy_process_group()
+        return rc
     ops.comm_init(transport=os.environ.get("RC_COMM", "ipc"))
     lib, h = _lib.load(), _lib.handle(local)
     assert lib.rc_comm_world(h) == world and lib.rc_comm_kind(h) == (2 if os.environ.get("RC_COMM", "ipc") == "ipc" else 1)
@@ -81,30 +104,32 @@ def main() -> int:
         g, x, C = load_case(name)
         xl = torch.from_numpy(x[cuts[rank]:cuts[rank + 1]]).to(dev)
         Ct = torch.from_numpy(C).to(dev)
-        for i, graph in enumerate(("0", "1", "1", "0")):           # eager, capture, replay, eager again (parities keep alternating)
-            os.environ["RC_GRAPH"] = graph
-            codes, flags = ops.assign_sinkhorn_dist(xl, Ct, EPS, ITERS, torch.uint8)
-            torch.cuda.synchronize()
-            if int(flags.item()) != 0:
-                print(f"rank {rank}: flags {int(flags.item())} in pass {i}")
-                rc = 1
-            np.save(os.path.join(out, f"codes{i}_rank{rank}.npy"), codes.cpu().numpy())
-            want = g["codes_constrained"][cuts[rank]:cuts[rank + 1]]
-            if not np.array_equal(codes.cpu().numpy(), want):
-                print(f"rank {rank}: {int((codes.cpu().numpy() != want).sum())} codes differ from the golden fixture in pass {i}")
-                rc = 1
-        # ONE chain (RC_DIST_SPLIT=0: one launch per sweep, the exchange exposed - what bench.py runs when it is the faster of
-        # the two on the node): eager, capture, replay; every rank switches between the two forms at the same solve
-        os.environ["RC_DIST_SPLIT"] = "0"
-        for i, graph in enumerate(("0", "1", "1")):
-            os.environ["RC_GRAPH"] = graph
-            codes, flags = ops.assign_sinkhorn_dist(xl, Ct, EPS, ITERS, torch.uint8)
-            torch.cuda.synchronize()
-            want = g["codes_constrained"][cuts[rank]:cuts[rank + 1]]
-            if int(flags.item()) != 0 or not np.array_equal(codes.cpu().numpy(), want):
-                print(f"rank {rank}: one-chain solve wrong in pass {i} (flags {int(flags.item())})")
-                rc = 1
-        os.environ.pop("RC_DIST_SPLIT")
+        want = g["codes_constrained"][cuts[rank]:cuts[rank + 1]]
+        # Every form of the exchange, each eager / captured / replayed (/ eager again: the parities keep alternating); all
+        # ranks switch between the forms at the same solve.  The small grids of these fixtures fit the one GPU together, so
+        # the in-prologue wait (the default when every rank has a GPU of its own) can run between processes that share one;
+        # a wait that could not be satisfied ends in RC_FLAG_COMM after the time-out, never in a hang.
+        os.environ.setdefault("RC_IPC_TIMEOUT_MS", "30000")
+        forms = (("one chain, exchange fused into the sweep, flag-wait kernels (default on a shared GPU)", {}, ("0", "1", "1", "0")),
+                 ("one chain, fused, wait inside the next sweep's prologue", {"RC_IPC_INWAIT": "1"}, ("0", "1", "1")),
+                 ("two chains, fused", {"RC_DIST_SPLIT": "1"}, ("0", "1", "1")),
+                 ("two chains, fused, wait in the prologue", {"RC_DIST_SPLIT": "1", "RC_IPC_INWAIT": "1"}, ("1", "1")),
+                 ("two chains, push + wait kernels (rounds 3-4)", {"RC_IPC_XSWEEP": "0"}, ("0", "1", "1")),
+                 ("one chain, push + wait kernels", {"RC_IPC_XSWEEP": "0", "RC_DIST_SPLIT": "0"}, ("0", "1", "1")))
+        for fi, (form, env, graphs) in enumerate(forms):
+            os.environ.update(env)
+            for i, graph in enumerate(graphs):
+                os.environ["RC_GRAPH"] = graph
+                codes, flags = ops.assign_sinkhorn_dist(xl, Ct, EPS, ITERS, torch.uint8)
+                torch.cuda.synchronize()
+                if fi == 0:
+                    np.save(os.path.join(out, f"codes{i}_rank{rank}.npy"), codes.cpu().numpy())
+                if int(flags.item()) != 0 or not np.array_equal(codes.cpu().numpy(), want):
+                    print(f"rank {rank}: [{form}] pass {i}: flags {int(flags.item())}, "
+                          f"{int((codes.cpu().numpy() != want).sum())} codes differ from the golden fixture")
+                    rc = 1
+            for k in env:
+                os.environ.pop(k)
         # an odd iteration count flips the exchange parity between solves: the graph cache must key on it
         os.environ["RC_GRAPH"] = "1"
         ref = None

@@ -1149,6 +1149,25 @@ def test_every_sweep_variant_reproduces_the_golden_codes(name, variant, monkeypa
     assert int((codes.cpu().numpy() != g["codes_constrained"]).sum()) == 0
 
 
+@pytest.mark.parametrize("kind", ["sample", "lloyd"])
+def test_full_training_batch_against_the_reference_49152_m48(kind):
+    """BASELINE configs[1], the shape bench.py times, pinned to the REFERENCE directly: tests/golden/headline_b49152_m48_*.npz
+    hold what /root/reference's RepCONC.quantize returned for this 49 152 x 768 batch at M = 48 (constrained, eps 0.003,
+    T = 100, and nearest), computed as four column slices of twelve sub-quantisers (oracle/gen_golden.py --headline: the
+    reference cannot hold its [48, 49152, 256, 16] scratch in 62 GB, and every reduction of quantize is per sub-quantiser).
+    All 2 359 296 constrained codes and all nearest codes of the HIP path equal them, for sampled and Lloyd-refined centroids."""
+    from conftest import load_headline
+    from repconc_amd import ops
+    x, C, con, near = load_headline(kind)
+    xt, Ct = _t(x), _t(C)
+    got, flags = ops.assign_sinkhorn(xt, Ct, EPS, ITERS, torch.uint8)
+    assert int(flags.item()) == 0
+    assert int((got.cpu().numpy() != con).sum()) == 0
+    assert np.array_equal(ops.assign_nearest(xt, Ct, torch.uint8).cpu().numpy(), near)
+    g64, _ = ops.assign_sinkhorn(xt, Ct, EPS, ITERS, torch.int64)          # the reference's own dtype
+    assert np.array_equal(g64.cpu().numpy().astype(np.uint8), con)
+
+
 @pytest.mark.parametrize("kind", ["sampled", "lloyd"])
 def test_full_training_batch_against_the_oracle_49152_m48(kind):
     """BASELINE configs[1]: ONE whole 49 152 x 768 training batch, M = 48, eps 0.003, T = 100 — every one of the
@@ -1356,6 +1375,55 @@ def test_native_rccl_collectives_inside_the_graph_single_rank(monkeypatch):
                 assert int(flags.item()) == 0
                 assert np.array_equal(codes.cpu().numpy(), g["codes_constrained"]), (split, graph)
     finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_fused_exchange_on_a_one_rank_ipc_transport(monkeypatch):
+    """RC_DIST_FORCE_COLL=1 on a one-rank IPC transport (the proxy bench.py and DESIGN 9.15 time): every iteration's exchange
+    runs — the sweep's reducer stores the row sums and the flags into the rank's OWN receive buffer, the next sweep's prologue
+    waits for them (no peer shares the device, so the wait is inside the sweep) — eager, captured, replayed, one chain and two,
+    and the round-3/4 push + wait kernels; golden codes every time, at a fixture and at the per-rank shape of the 8-GPU recipe."""
+    import socket
+    import torch.distributed as dist
+    from repconc_amd import _lib, ops
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        created = True
+    try:
+        assert ops.comm_init(transport="ipc") == "ipc"
+        lib, h = _lib.load(), _lib.handle(torch.cuda.current_device())
+        monkeypatch.setenv("RC_DIST_FORCE_COLL", "1")
+        monkeypatch.setenv("RC_IPC_TIMEOUT_MS", "20000")
+        assert lib.rc_solve_num_chains_on(h, 8, 48) == 1 and lib.rc_solve_num_chains(8, 48) == 2
+        g, x, C = load_case("m48_b1024_sample")
+        x6 = synth.clustered_embeddings(4242, 6144)
+        C6 = synth.sample_centroids(4243, x6, 48)
+        want6 = None
+        for xsweep, inwait, split in (("1", "1", "0"), ("1", "0", "0"), ("1", "1", "1"), ("0", "0", "1"), ("0", "0", "0")):
+            monkeypatch.setenv("RC_IPC_XSWEEP", xsweep)
+            monkeypatch.setenv("RC_IPC_INWAIT", inwait)
+            monkeypatch.setenv("RC_DIST_SPLIT", split)
+            for graph in ("0", "1", "1"):
+                monkeypatch.setenv("RC_GRAPH", graph)
+                codes, flags = ops.assign_sinkhorn_dist(_t(x), _t(C), EPS, ITERS, torch.uint8)
+                torch.cuda.synchronize()
+                assert int(flags.item()) == 0
+                assert np.array_equal(codes.cpu().numpy(), g["codes_constrained"]), (xsweep, inwait, split, graph)
+            codes, flags = ops.assign_sinkhorn_dist(_t(x6), _t(C6), EPS, ITERS, torch.uint8)
+            if want6 is None:
+                want6, _ = c_oracle.quantize(x6, C6, True, EPS, ITERS)
+            assert int(flags.item()) == 0 and np.array_equal(codes.cpu().numpy(), want6), (xsweep, inwait, split)
+        ops.comm_check()
+    finally:
+        try:
+            ops.comm_destroy(group_barrier=False)
+        except Exception:
+            pass
         if created:
             dist.destroy_process_group()
 

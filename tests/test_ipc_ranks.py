@@ -24,10 +24,11 @@ def _cuts(name, world):
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("name", ["m48_b1024_sample", "m8_b2048_sample", "m48_b1000_ragged", "m96_b512_blend"])
 def test_native_solve_on_ipc_ranks_equals_golden(name, world, tmp_path):
-    """Native C loop (two chains on two streams, exchanges as peer stores + one-thread waits) with `world` processes:
-    eager, graph capture, graph replay, eager again — every pass of every rank equals the golden codes of its rows;
-    then the same as ONE chain (RC_DIST_SPLIT=0); empty ranks take part in every exchange; a 7-iteration solve (odd: flips
-    the exchange parity) is repeatable."""
+    """Native C loop with `world` processes, every form of the exchange: ONE launch per iteration (the sweep's reducer pushes
+    the row sums, flag-wait kernels or the next sweep's prologue wait; one chain — the default — and two), and the push + wait
+    kernels of rounds 3-4 (two chains, one chain) — eager, graph capture, graph replay(, eager again): every pass of every
+    rank equals the golden codes of its rows; empty ranks take part in every exchange; a 7-iteration solve (odd: flips the
+    exchange parity) is repeatable."""
     B, cuts = _cuts(name, world)
     codes = run_ranks(world, ["solve", name] + cuts, str(tmp_path), timeout=420)
     assert codes == [0] * world, rank_logs(str(tmp_path), world)
@@ -59,6 +60,15 @@ def test_ipc_wait_gives_up_on_a_missing_peer(tmp_path):
     """A peer that never pushes: the wait kernel leaves after RC_IPC_TIMEOUT_MS and raises RC_FLAG_COMM (flags word and
     rc_comm_status) instead of hanging the queue."""
     assert run_ranks(2, ["timeout"], str(tmp_path), timeout=240) == [0, 0], rank_logs(str(tmp_path), 2)
+
+
+@pytest.mark.parametrize("inwait", ["0", "1"])
+def test_fused_exchange_gives_up_on_a_missing_peer(inwait, tmp_path, monkeypatch):
+    """A whole solve whose peer never calls: the first wait of the fused exchange (flag-wait kernel / the sweep's prologue)
+    leaves after RC_IPC_TIMEOUT_MS, the transport is broken from then on (no later wait, no later push), the solve returns
+    within seconds with RC_FLAG_COMM in its flags."""
+    monkeypatch.setenv("RC_IPC_INWAIT", inwait)
+    assert run_ranks(2, ["timeout_solve"], str(tmp_path), timeout=240) == [0, 0], rank_logs(str(tmp_path), 2)
 
 
 def test_corpus_sharded_warmup_on_ipc_ranks_is_rank_identical(tmp_path):

@@ -36,6 +36,21 @@ def test_c_oracle_fp32_stage_bitwise(name):
     assert np.array_equal(d[idx[:, 0], idx[:, 1], idx[:, 2]].view(np.uint32), g["samp_centred_bits"])
 
 
+@pytest.mark.parametrize("kind,m0", [("sample", 0), ("lloyd", 44)])
+def test_c_oracle_on_the_headline_batch_equals_the_reference(kind, m0):
+    """BASELINE configs[1] itself — 49 152 x 768, M = 48 — as the REFERENCE computed it (oracle/gen_golden.py --headline: four
+    column slices of twelve sub-quantisers; every reduction of quantize is per sub-quantiser).  The CPU suite checks the C
+    restatement on four of the 48 sub-quantisers per centroid kind (the same slicing argument; all 48 took 93 s per kind when
+    the fixtures were made: 0 mismatches); the GPU suite compares the HIP path with all 2 x 2 359 296 codes."""
+    from conftest import load_headline
+    x, C, con, near = load_headline(kind)
+    xs = np.ascontiguousarray(x[:, m0 * 16:(m0 + 4) * 16])
+    Cs = np.ascontiguousarray(C[m0:m0 + 4])
+    got, fl = c_oracle.quantize(xs, Cs, True, EPS, ITERS)
+    assert fl == 0 and np.array_equal(got, con[:, m0:m0 + 4])
+    assert np.array_equal(c_oracle.quantize(xs, Cs, False)[0], near[:, m0:m0 + 4])
+
+
 @pytest.mark.parametrize("name", ["m8_b300_gauss", "m64_b512_sample", "m96_b512_blend", "m48_b1000_ragged"])
 def test_numpy_oracle_matches_reference(name):
     g, x, C = load_case(name)
