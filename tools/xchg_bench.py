@@ -28,11 +28,14 @@ with socket.socket() as s:
     port = s.getsockname()[1]
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
 assert ops.comm_init(transport="ipc") == "ipc"
-KEYS = ("RC_DIST_FORCE_COLL", "RC_IPC_XSWEEP", "RC_IPC_INWAIT", "RC_DIST_SPLIT")
+KEYS = ("RC_DIST_FORCE_COLL", "RC_IPC_XSWEEP", "RC_IPC_INWAIT", "RC_DIST_SPLIT", "RC_SK_CHAIN")
+SOLO = "solo"
 forms = [
-    ("stand-alone, no exchange (rc_pq_assign_sinkhorn)", None),
-    ("one chain, no exchange (dist entry, world 1)", {}),
-    ("one chain, fused exchange, wait in the prologue", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "0"}),
+    ("stand-alone (rc_pq_assign_sinkhorn), one launch after the other", {SOLO: "1", "RC_SK_CHAIN": "0"}),
+    ("stand-alone, chained launches (loop-back flags)", {SOLO: "1", "RC_SK_CHAIN": "1"}),
+    ("one chain, fused exchange, prologue wait, chained launches", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "0"}),
+    ("one chain, fused exchange, prologue wait, not chained", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "0",
+                                                               "RC_SK_CHAIN": "0"}),
     ("one chain, fused exchange, flag-wait kernel", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "0", "RC_DIST_SPLIT": "0"}),
     ("two chains, fused exchange, wait in the prologue", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "1"}),
     ("one chain, push + wait kernel (rounds 3-4)", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_XSWEEP": "0", "RC_DIST_SPLIT": "0"}),
@@ -43,9 +46,9 @@ for rep in range(3):
     for name, env in forms:
         for k in KEYS:
             os.environ.pop(k, None)
-        if env:
-            os.environ.update(env)
-        fn = (lambda: ops.assign_sinkhorn(x, C, 0.003, 100, torch.uint8)) if env is None else \
+        solo = SOLO in env
+        os.environ.update({k: v for k, v in env.items() if k != SOLO})
+        fn = (lambda: ops.assign_sinkhorn(x, C, 0.003, 100, torch.uint8)) if solo else \
              (lambda: ops.assign_sinkhorn_dist(x, C, 0.003, 100, torch.uint8))
         for _ in range(3):
             codes, fl = fn()
