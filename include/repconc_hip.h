@@ -303,6 +303,9 @@ int64_t rc_adc_scan_image_rows_at(int M, int64_t n, int m);
  * not, RC_ESHAPE for an M without an image. */
 int rc_adc_q16_describe(int M, int lane, int step, int* slot);
 size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, int k);
+/* measurement: byte offsets, inside the workspace a search was given, of its per-query counts — unsigned[nq] rows that passed
+ * the 8-bit screen (0: no screen at this size) and unsigned[nq] rows the exact rescoring kept */
+int rc_adc_search_ws_counts(int64_t N, int M, int K, int nq, size_t* survivors_off, size_t* candidates_off);
 int rc_adc_search_img(rc_handle_t h, const uint8_t* codes, const uint8_t* scan_image, int64_t N, int M, int K,
                       const float* C, int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,
                       float* scores, int64_t* ids, int* status, void* ws, size_t ws_bytes, rc_stream_t stream);

@@ -86,7 +86,9 @@ def decode(codes, centroids):
     return out
 
 
-def adc_search(codes, centroids, q, k):
+def adc_search(codes, centroids, q, k, tile=None):
+    """tile=None: one query per thread, each streaming the whole code array (Faiss's IndexPQ search loop); tile=rows: the
+    cache-blocked form (orc_adc_search_tiled; 0 = its default tile) — identical results."""
     codes = np.ascontiguousarray(codes, np.uint8)
     Cn = np.ascontiguousarray(centroids, np.float32)
     q = np.ascontiguousarray(q, np.float32)
@@ -94,5 +96,17 @@ def adc_search(codes, centroids, q, k):
     nq = q.shape[0]
     scores = np.empty((nq, k), np.float32)
     ids = np.empty((nq, k), np.int64)
-    lib().orc_adc_search(_f(codes), C.c_int64(N), M, Cn.shape[2], _f(Cn), _f(q), nq, k, _f(scores), _f(ids))
+    if tile is None:
+        lib().orc_adc_search(_f(codes), C.c_int64(N), M, Cn.shape[2], _f(Cn), _f(q), nq, k, _f(scores), _f(ids))
+    else:
+        lib().orc_adc_search_tiled(_f(codes), C.c_int64(N), M, Cn.shape[2], _f(Cn), _f(q), nq, k, C.c_int64(int(tile)),
+                                   _f(scores), _f(ids))
     return scores, ids
+
+
+def first_touch_copy(a):
+    """A copy of `a` whose pages were first written by all OpenMP threads in parallel (NUMA placement for the CPU baselines)."""
+    a = np.ascontiguousarray(a)
+    out = np.empty_like(a)
+    lib().orc_first_touch_copy(_f(out), _f(a), C.c_int64(a.nbytes))
+    return out

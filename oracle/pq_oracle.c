@@ -324,3 +324,94 @@ void orc_adc_search(const uint8_t* codes, int64_t N, int M, int dsub, const floa
         free(heap);
     }
 }
+
+/* The same search, cache-blocked for many queries (bench.py's CPU baseline on a many-core host): rows are visited in tiles
+ * of `tile` rows (outer loop) and the queries are spread over the threads inside a tile, so a tile's codes are read from DRAM
+ * once per nq queries instead of once per query — Faiss's own IndexPQ search parallelises over queries only and streams the
+ * whole code array per query, which on a two-socket host is bound by the memory one thread's first touch put on ONE node
+ * (42 GB/s for 128 threads).  Every query still sees the rows in ascending order with its own heap, so the
+ * results are those of orc_adc_search bit for bit (same sums, same tie rule).  tile <= 0: 16384 rows. */
+void orc_adc_search_tiled(const uint8_t* codes, int64_t N, int M, int dsub, const float* C, const float* q, int nq, int k,
+                          int64_t tile, float* scores, int64_t* ids) {
+    if (tile <= 0) tile = 16384;
+    tile = (tile + 3) & ~(int64_t)3;          /* whole groups of four rows per tile */
+    float* luts = (float*)malloc(sizeof(float) * (size_t)nq * M * K);
+    hit_t* heaps = (hit_t*)malloc(sizeof(hit_t) * (size_t)nq * k);
+    int* hns = (int*)calloc((size_t)nq, sizeof(int));
+#pragma omp parallel for schedule(static)
+    for (int qi = 0; qi < nq; ++qi) {
+        float* lut = luts + (size_t)qi * M * K;
+        for (int m = 0; m < M; ++m)
+            for (int kk = 0; kk < K; ++kk) {
+                const float* qs = q + (int64_t)qi * M * dsub + m * dsub;
+                const float* c = C + ((int64_t)m * K + kk) * dsub;
+                float s = 0.f;
+                for (int j = 0; j < dsub; ++j) s = s + qs[j] * c[j];
+                lut[m * K + kk] = s;
+            }
+    }
+    for (int64_t n0 = 0; n0 < N; n0 += tile) {
+        const int64_t n1 = n0 + tile < N ? n0 + tile : N;
+#pragma omp parallel for schedule(static)
+        for (int qi = 0; qi < nq; ++qi) {
+            const float* lut = luts + (size_t)qi * M * K;
+            hit_t* heap = heaps + (size_t)qi * k;
+            int hn = hns[qi];
+            float s4[4];
+            for (int64_t n = n0; n < n1; ++n) {
+                if (((n - n0) & 3) == 0) {      /* tiles start at multiples of 4: the same groups of four rows as above */
+                    const int64_t left = N - n < 4 ? N - n : 4;
+                    const uint8_t* c0 = codes + n * M;
+                    const uint8_t* c1 = c0 + (left > 1 ? M : 0);
+                    const uint8_t* c2 = c0 + (left > 2 ? 2 * M : 0);
+                    const uint8_t* c3 = c0 + (left > 3 ? 3 * M : 0);
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int m = 0; m < M; ++m) {
+                        const float* t = lut + m * K;
+                        a0 = a0 + t[c0[m]];
+                        a1 = a1 + t[c1[m]];
+                        a2 = a2 + t[c2[m]];
+                        a3 = a3 + t[c3[m]];
+                    }
+                    s4[0] = a0; s4[1] = a1; s4[2] = a2; s4[3] = a3;
+                }
+                const float sc = s4[(n - n0) & 3];
+                hit_t h = {sc, n};
+                if (hn < k) {
+                    heap[hn++] = h;
+                    if (hn == k)
+                        for (int i = k / 2 - 1; i >= 0; --i) heap_sift_down(heap, k, i);
+                } else if (hit_worse(heap[0], h)) {
+                    heap[0] = h;
+                    heap_sift_down(heap, k, 0);
+                }
+            }
+            hns[qi] = hn;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int qi = 0; qi < nq; ++qi) {
+        hit_t* heap = heaps + (size_t)qi * k;
+        const int hn = hns[qi];
+        qsort(heap, hn, sizeof(hit_t), hit_cmp_desc);
+        for (int j = 0; j < k; ++j) {
+            scores[(int64_t)qi * k + j] = j < hn ? heap[j].s : -INFINITY;
+            ids[(int64_t)qi * k + j] = j < hn ? heap[j].id : -1;
+        }
+    }
+    free(luts);
+    free(heaps);
+    free(hns);
+}
+
+/* Copy with a parallel first touch: dst (freshly allocated, untouched) gets its pages from the memory nodes of the threads that
+ * copy them (static schedule over 2 MiB pieces), instead of all from the node of the one thread that happened to write the
+ * array first — the many-thread scans of bench.py's CPU baseline then read from every memory controller of the host. */
+void orc_first_touch_copy(void* dst, const void* src, int64_t bytes) {
+    const int64_t piece = 2 << 20, n = (bytes + piece - 1) / piece;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t o = i * piece, len = (o + piece <= bytes) ? piece : bytes - o;
+        memcpy((char*)dst + o, (const char*)src + o, (size_t)len);
+    }
+}

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "rc_adc_scan_image_rows_bytes": (_sz, [_i64, _i]),
     "rc_adc_scan_image_rows_at": (_i64, [_i, _i64, _i]),
     "rc_adc_search_img_ws_bytes": (_sz, [_i64, _i, _i, _i, _i]),
+    "rc_adc_search_ws_counts": (_i, [_i64, _i, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "rc_adc_search_img": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_adc_search_q": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_adc_search_exact_ws_bytes": (_sz, [_i64, _i, _i, _i, _i]),

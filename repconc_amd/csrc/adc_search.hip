@@ -1107,6 +1107,18 @@ extern "C" size_t rc_adc_search_img_ws_bytes(int64_t N, int M, int K, int nq, in
 }
 // bytes of the permuted code image of an N-row index (0: this M has no image — M = 8, 12, 24 run the round-1 screens on the
 // canonical codes): whole tiles of ADC_Q16_TILE rows, [tile][phase][round][wave][lane][chunk][step] (adc_q16_image_at)
+// Where a finished search left its per-query counts inside the caller's workspace (measurement only: SURVEY 8d asks for the
+// screen's survivors next to queries/s): *survivors_off = byte offset of unsigned[nq] rows that passed the 8-bit screen
+// (0 when the index is too small for a screen), *candidates_off = unsigned[nq] rows kept by the exact rescoring.
+// own_image: the workspace of rc_adc_search_ws_bytes (1) or rc_adc_search_img_ws_bytes (0) — the offsets are the same.
+extern "C" int rc_adc_search_ws_counts(int64_t N, int M, int K, int nq, size_t* survivors_off, size_t* candidates_off) {
+    if (N <= 0 || M <= 0 || K != RC_K || nq <= 0 || !survivors_off || !candidates_off) return RC_EINVAL;
+    const adc_ws_layout L = adc_layout(N, M, nq, false);
+    *survivors_off = (N >= ADC_SCREEN_MIN_N) ? L.idcnt : 0;
+    *candidates_off = L.cnt;
+    return RC_OK;
+}
+
 extern "C" size_t rc_adc_scan_image_bytes(int64_t N, int M) {
     if (N < 0 || !adc_cf_supported(M)) return 0;
     const int64_t T = ADC_Q16_TILE;

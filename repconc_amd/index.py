@@ -98,7 +98,7 @@ class PQIndex:
         in -> CUDA tensors out (finetune_jpq.py:176 via faiss.contrib.torch_utils)."""
         return self.search_async(x, k)()
 
-    def search_async(self, x, k: int):
+    def search_async(self, x, k: int, stats=None):
         """Enqueue the search and return a callable that yields what `search` returns.  Nothing synchronises with the
         host until it is called, so a caller with several query batches (`batch_search`) can enqueue them all first: the
         device then never idles between batches waiting for the host to read a status word and launch the next one."""
@@ -107,7 +107,7 @@ class PQIndex:
         q = q.to(self.device, torch.float32, non_blocking=True)
         # prefixes of the row-major buffers are contiguous views: nothing is copied
         pending = ops.adc_search(self._codes[: self.ntotal], self._centroids, q, int(k), id_offset=self.id_offset,
-                                 scan_image=self._image, defer=True)
+                                 scan_image=self._image, defer=True, stats=stats)
 
         def finish():
             scores, ids = pending.result()

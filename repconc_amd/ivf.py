@@ -98,6 +98,11 @@ class IVFPQIndex:
         self.list_off = torch.zeros((nlist + 1,), dtype=torch.int64, device=self.device)
         self.ntotal = 0
         self._sizes_desc = np.zeros(0, np.int64)      # cell sizes, descending (host copy; set_lists fills it)
+        self.nprobe = 8                               # Faiss's attribute: cells probed when search() is not told
+        # batch_search (models/repconc/evaluate_repconc.py) hands an index with this attribute the WHOLE query set in one
+        # call: a probed cell is scanned once for all the queries that probe it (6 980 dev queries at nprobe 8: ~11 per probed
+        # cell instead of ~2 in 1 200-query batches — the screen's 8 gather columns fill up)
+        self.whole_query_set = True
 
     # ---- build
     def train(self, x, iters: int = 10, seed: int = 1234):
@@ -158,6 +163,7 @@ class IVFPQIndex:
         out.list_off = self.list_off.to(device)
         out.ntotal = self.ntotal
         out._sizes_desc = self._sizes_desc
+        out.nprobe = self.nprobe
         if self.image is not None:                      # the permutation of row n depends on n mod 16 only: copy, not rebuild
             out.image = self.image.to(device)
         if device == self.device:                       # same device (virtual replica in the tests): real copies
@@ -190,14 +196,17 @@ class IVFPQIndex:
             order = torch.argsort(s, dim=1, descending=True, stable=True)[:, :nprobe]
         return order.to(torch.int32).contiguous()
 
-    def search(self, x, k: int, nprobe: int, method: str = "auto"):
-        """method: "lists" = list-centric 8-bit screen (rc_ivf_search_lists: the queries probing a cell share its read,
+    def search(self, x, k: int, nprobe: Optional[int] = None, method: str = "auto"):
+        """nprobe: cells probed per query (default: the index's `nprobe` attribute, as with a Faiss IVF index).
+        method: "lists" = list-centric 8-bit screen (rc_ivf_search_lists: the queries probing a cell share its read,
         M in {16,32,48,64,96}); "scan" = the per-query exact scan (rc_ivf_search); "auto" = lists where available.
         Both return the same (scores, ids)."""
         as_numpy = not isinstance(x, torch.Tensor)
         q = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if as_numpy else x).to(self.device, torch.float32)
         q = q.contiguous()
         nq = q.shape[0]
+        if nprobe is None:
+            nprobe = self.nprobe
         if nq > self.MAX_QUERY_BATCH:                      # the C entries index their per-query workspaces with 32 bits
             parts = [self.search(q[i:i + self.MAX_QUERY_BATCH], k, nprobe, method) for i in range(0, nq, self.MAX_QUERY_BATCH)]
             scores, ids = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])

@@ -195,6 +195,10 @@ def batch_search(query_ids: np.ndarray, query_embeds, corpus_ids: np.ndarray, in
     """evaluate_repconc.py:188-206 (np.array_split batching).  Every batch is enqueued before the first result is read
     (`search_async`), so the device runs the batches back to back; indexes without `search_async` (the multi-device
     wrappers, anything Faiss-shaped) take the reference's batch-by-batch loop."""
+    if getattr(index, "whole_query_set", False):
+        # a list-centric index (repconc_amd.ivf.IVFPQIndex) scans a probed cell once for every query that probes it: the more
+        # queries in hand, the fuller its gather columns — all of them go in one call (the index chunks at 16 384 itself)
+        return search(query_ids, query_embeds, corpus_ids, index, topk)
     iterations = max(1, math.ceil(len(query_ids) / batch_size))
     qid_parts, emb_parts = np.array_split(query_ids, iterations), np.array_split(query_embeds, iterations)
     if not hasattr(index, "search_async"):

@@ -713,12 +713,14 @@ def adc_search_exact(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tens
 
 def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k: int, id_offset: int = 0,
                sel_slack: float = 6.0, max_retries: int = 2, scan_image: Optional[torch.Tensor] = None,
-               defer: bool = False):
+               defer: bool = False, stats: Optional[dict] = None):
     """Top-k inner-product ADC search of `q` [nq,D] against uint8 `codes` [N,M].
     Returns (scores [nq,k] fp32, ids [nq,k] int64), sorted (score desc, id asc).
     evaluate_repconc.py:180-185 / finetune_jpq.py:176.
     scan_image: the index's permuted code image (adc_scan_image_), kept by PQIndex; None = rebuilt per call.
     defer: return a `PendingSearch` instead (no host synchronisation here; `.result()` gives the pair).
+    stats (measurement): receives "survivors" / "candidates" = int32 [nq] device tensors, the rows of every query that passed
+    the 8-bit screen / that the exact rescoring kept in the FIRST pass (rc_adc_search_ws_counts).
     Never raises on degenerate index content: see `PendingSearch`."""
     _need_cuda(codes, centroids, q, scan_image)
     if codes.dtype != torch.uint8 or not codes.is_contiguous():
@@ -753,6 +755,12 @@ def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k:
         _lib.check(lib.rc_adc_search_q(h, _p(codes), _p(scan_image), N, M, K, _p(c), D, _p(qq), n, int(k), int(id_offset),
                                        float(slack), _p(out_s), _p(out_i), _p(status), _p(qstatus), _p(ws), wsb, st),
                    "rc_adc_search_q", h)
+        if stats is not None and "candidates" not in stats:
+            so, co = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(lib.rc_adc_search_ws_counts(N, M, K, n, C.byref(so), C.byref(co)), "rc_adc_search_ws_counts", h)
+            if so.value:
+                stats["survivors"] = ws[so.value:so.value + 4 * n].view(torch.int32).clone()
+            stats["candidates"] = ws[co.value:co.value + 4 * n].view(torch.int32).clone()
         return status, qstatus
 
     def rerun(idx, slack, exact):

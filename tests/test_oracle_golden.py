@@ -51,6 +51,33 @@ def test_c_oracle_on_the_headline_batch_equals_the_reference(kind, m0):
     assert np.array_equal(c_oracle.quantize(xs, Cs, False)[0], near[:, m0:m0 + 4])
 
 
+@pytest.mark.parametrize("name", ["m48_b1024_sample", "m8_b2048_sample", "m96_b512_blend", "m48_b1000_ragged"])
+def test_torch_port_matches_reference(name):
+    """oracle/torch_port.py — bench.py's torch-CPU baseline (the reference's algorithmic shape on the host's
+    cores) — returns the reference's codes on the golden fixtures."""
+    import torch
+    from oracle import torch_port
+    g, x, C = load_case(name)
+    xt, Ct = torch.from_numpy(x), torch.from_numpy(C)
+    assert np.array_equal(torch_port.quantize(xt, Ct, False).numpy().astype(np.uint8), g["codes_nearest"])
+    assert np.array_equal(torch_port.quantize(xt, Ct, True, EPS, ITERS).numpy().astype(np.uint8), g["codes_constrained"])
+
+
+def test_tiled_cpu_search_equals_the_query_parallel_one():
+    """oracle/pq_oracle.c: the cache-blocked ADC search (bench.py's many-core CPU baseline) returns the ids and score bits of
+    the Faiss-style one (every query streams the whole index), ragged tile sizes included."""
+    rng = np.random.default_rng(5)
+    N, M = 50003, 24
+    codes = rng.integers(0, 256, (N, M), dtype=np.uint8)
+    codes[1000:1400] = codes[999]                                             # a run of tied rows
+    C = rng.standard_normal((M, 256, 32)).astype(np.float32)
+    q = rng.standard_normal((9, 768)).astype(np.float32)
+    s0, i0 = c_oracle.adc_search(codes, C, q, 300)
+    for tile in (0, 4 * 1001, 4, 1 << 20):
+        s1, i1 = c_oracle.adc_search(codes, C, q, 300, tile=tile)
+        assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(i0, i1), tile
+
+
 @pytest.mark.parametrize("name", ["m8_b300_gauss", "m64_b512_sample", "m96_b512_blend", "m48_b1000_ragged"])
 def test_numpy_oracle_matches_reference(name):
     g, x, C = load_case(name)

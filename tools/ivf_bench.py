@@ -12,7 +12,8 @@ from repconc_amd.index import PQIndex  # noqa: E402
 from repconc_amd.ivf import IVFPQIndex  # noqa: E402
 
 dev = "cuda:0"
-N, M, nlist, nq, k = 8841823, int(sys.argv[1]) if len(sys.argv) > 1 else 48, 5000, 1200, 1000
+N, M, nlist, k = 8841823, int(sys.argv[1]) if len(sys.argv) > 1 else 48, 5000, 1000
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1200       # 6980 = the MS MARCO dev set in one call (batch_search does that for IVF)
 g = torch.Generator(device=dev).manual_seed(1)
 codes = torch.randint(0, 256, (N, M), dtype=torch.uint8, device=dev, generator=g)
 cells = torch.randint(0, nlist, (N,), device=dev, generator=g)

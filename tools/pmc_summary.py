@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """profiles/pmc_summary.json from the raw per-kernel counter means (tools/pmc_parse.py output).
-    python tools/pmc_summary.py <raw.json> <out.json> [note]
+    python tools/pmc_summary.py <raw.json> <out.json> [note] [kmeans_raw.json]
+kmeans_raw.json: the counters of `tools/kmeans_one.py 48` (2^20-row launches ONLY) — the k-means row is taken from there, because
+the bench command runs the statistics kernel at 65 536 AND 2^20 rows and a mean over both sizes compares with nothing.
 FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half the bytes of
 wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is used as reported."""
 import json
@@ -8,27 +10,34 @@ import sys
 
 raw = json.load(open(sys.argv[1]))
 note = sys.argv[3] if len(sys.argv) > 3 else ""
+km_raw = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
 B, M, K, NC, NQ, NB = 49152, 48, 256, 8841823, 1200, 1 << 20
 ALG = {  # SURVEY 8(d) per-unit bytes x units per launch
     "sk_sweep_kernel": ("sk_sweep2_kernel<2, true>", B * M * K * 4),
     "adc_screen_q16_kernel": ("adc_screen_q16_kernel<48>", NQ * NC * M),
     "assign_mfma_kernel": ("assign_mfma_kernel<16>", NB * (768 * 4 + M)),
-    "kmeans_stats_fx_kernel": ("kmeans_stats_fx_kernel<0, 8>", NB * (768 * 4 + M)),   # the 2^20-row launches (the mean also holds the 65 536-row ones)
+    "kmeans_stats_fx_kernel": ("kmeans_stats_fx_kernel<0, 8>", NB * (768 * 4 + M)),   # 2^20-row launches only (kmeans_raw.json)
 }
 out = {"_how": "tools/pmc_collect.sh: rocprofv3 --pmc <group> --kernel-trace, one pass per counter group, over "
                "`python bench.py --steps 1 --warmup 1 --no-cpu --no-per-rank --no-opq --adc-batches 1`; means per launch. FETCH_SIZE/WRITE_SIZE are "
                "KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md. " + note}
 for key, (kname, alg) in ALG.items():
-    c = raw.get(kname)
+    src = raw
+    if key == "kmeans_stats_fx_kernel":
+        if km_raw is None:
+            continue                                       # no size-pure counters: no row (a mixed mean is worse than none)
+        src = km_raw
+    c = src.get(kname)
     if not c:                                              # template argument lists grow: match on the leading arguments
-        hits = [k for k in raw if k.startswith(kname.rstrip(">"))]
+        hits = [k for k in src if k.startswith(kname.rstrip(">"))]
         if not hits:
             continue
-        kname, c = hits[0], raw[hits[0]]
+        kname, c = hits[0], src[hits[0]]
     f, w = c.get("FETCH_SIZE", {}).get("mean"), c.get("WRITE_SIZE", {}).get("mean")
     e = {"kernel": kname, "launches": c.get("FETCH_SIZE", {}).get("n"), "fetch_size_kib_mean": f, "write_size_kib_mean": w,
          "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024) if f is not None and w is not None else None,
          "algorithmic_bytes_per_launch": alg,
+         **({"source": "tools/kmeans_one.py 48: 2^20-row launches only"} if src is km_raw else {}),
          "sq": {k: v["mean"] for k, v in c.items() if k not in ("FETCH_SIZE", "WRITE_SIZE")}}
     sq = e["sq"]
     if "SQ_INSTS_VALU" in sq and "GRBM_GUI_ACTIVE" in sq:

@@ -83,6 +83,9 @@ __global__ __launch_bounds__(THREADS) void k(unsigned* out, long long* cyc, unsi
                 const unsigned off = base + (((pos128 + g) & 15) + 16 * (g & 1)) * 16;   // [code][32 slots][16 B]
                 unsigned addr;
                 if constexpr (ADDR == 1) addr = fixed[g];
+                else if constexpr (ADDR == 2)   // round 4's one-instruction address: [code][16 slots][16 B] rows of 256 B in 64 KiB buffers
+                    addr = __builtin_amdgcn_perm(w[g >> 2], base + (unsigned)(g & 1) * 65536u + (unsigned)((pos128 + g) & 15) * 16u,
+                                                 0x03020000u | ((4u + (unsigned)(g & 3)) << 8));
                 else asm("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_add_u32 %0, %0, 9, %3" : "=&v"(addr) : "v"(w[g >> 2]), "n"(8 * (g & 3)), "v"(off));
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 v = *reinterpret_cast<const u32x4 __attribute__((address_space(3)))*>(addr);
@@ -105,6 +108,9 @@ __global__ __launch_bounds__(THREADS) void k(unsigned* out, long long* cyc, unsi
                 const unsigned off = base + (KIND == 0 ? ((((l & 31) + g) & 31) + 32 * (g & 1)) * 8 : ((w[g >> 2] >> 3) & 0x1F8));
                 unsigned addr;
                 if constexpr (ADDR == 1) addr = fixed[g];
+                else if constexpr (ADDR == 2)   // [code][32 slots][8 B] rows of 256 B in 64 KiB buffers (32 sub-quantisers x 8 queries each)
+                    addr = __builtin_amdgcn_perm(w[g >> 2], base + (unsigned)(g & 1) * 65536u + (unsigned)(((l & 31) + g) & 31) * 8u,
+                                                 0x03020000u | ((4u + (unsigned)(g & 3)) << 8));
                 else asm("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_add_u32 %0, %0, 9, %3" : "=&v"(addr) : "v"(w[g >> 2]), "n"(8 * (g & 3)), "v"(off));
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 const u32x2 v = *reinterpret_cast<const u32x2 __attribute__((address_space(3)))*>(addr);
@@ -173,7 +179,7 @@ void run(const char* name, int blocks) {
     const double ghz = cy / (wl * 10.0);                          // wall_clock64 ticks are 10 ns
     const double ns = ms * 1e6 / instr_per_cu;
     printf("%-34s %s blk %3d thr %4d | launch %.3f ms (cold %.3f) | %5.2f ns = %5.2f cyc per gather per CU (wave 0 alone: %4.2f) | clock %.2f GHz (sysfs %s) | %5.1f B/clk/CU | chip %5.1f TB/s\n",
-           name, ADDR ? "fixed-addr " : "screen-addr", blocks, THREADS, ms, ms0, ns, ns * ghz, cy / instr_per_cu, ghz, sclk.c_str(),
+           name, ADDR == 1 ? "fixed-addr " : ADDR == 2 ? "perm-addr  " : "screen-addr", blocks, THREADS, ms, ms0, ns, ns * ghz, cy / instr_per_cu, ghz, sclk.c_str(),
            bytes / (ns * ghz), bytes * instr_per_cu * blocks / (ms * 1e-3) / 1e12);
     fflush(stdout);
     hipFree(out); hipFree(cyc);
@@ -181,6 +187,16 @@ void run(const char* name, int blocks) {
 
 int main(int argc, char** argv) {
     if (argc > 1) g_warm_ms = atof(argv[1]);
+    if (argc > 2 && !strcmp(argv[2], "perm")) {              // round 5: 8-query (b64) against 16-query (b128) gathers with the one-instruction address
+        run<12, 2, true, 1024, 2>("b128 cf 12 + 12 MFMA", 256);
+        run<24, 0, true, 1024, 2>("b64 cf 24 + 12 MFMA", 256);
+        run<12, 0, true, 1024, 2>("b64 cf 12 + 6 MFMA", 256);
+        run<24, 0, false, 1024, 2>("b64 cf 24, no MFMA", 256);
+        run<12, 2, false, 1024, 2>("b128 cf 12, no MFMA", 256);
+        run<12, 2, true, 1024>("b128 cf 12 + 12 MFMA", 256);
+        run<24, 0, true, 1024>("b64 cf 24 + 12 MFMA", 256);
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "b96")) {               // the question of the 12-query single-phase screen only
         run<12, 2, true, 1024>("b128 conflict-free 12 + 12 MFMA", 256);
         run<12, 3, false, 1024>("b96 dense rows, random codes 12", 256);
