@@ -104,31 +104,36 @@ __global__ __launch_bounds__(256) void kmeans_stats_reduce_kernel(const double* 
 // to be rounded.  The answer is a pure function of the data either way.
 // Non-finite input (max|x| = inf / NaN) takes the strip kernels, which propagate it as the reference would.
 #define KM_FX_LO_BITS 38
-#define KM_FX_JN 32                                     // dimensions of a sub-vector per pass: 256 x 32 x 16 B = 128 KiB of LDS
 #define KM_FX_U 4                                       // rows in flight per thread
 #define KM_FX_EB0 4                                     // first hint of a handle: |x| < 16
+//
+// Round 5 (0.36 of the roof at the 65 536 rows the warm-up runs, 0.34 at M = 64 at every size):
+//  * a block's share of a row is a PIECE of 32 consecutive floats at a 128-byte boundary whatever the sub-vector width — whole
+//    cache lines for every M (dsub = 12 / 24 / 48 used to give 96- or 64-byte pieces: each line fetched by two blocks); lane q of
+//    a piece (one float4) belongs to sub-quantiser (32 p + 4 q) / dsub and adds into the LDS accumulators of ITS code;
+//  * one launch in the common case instead of six: the decision "did the hint hold" is taken PER PIECE by the piece's
+//    last-arriving block (arrival counter, as the Sinkhorn sweep's reducer), which sums the piece's per-strip partials as
+//    integers, rounds once and adds into sums / counts; a piece whose data exceeded the hint or needed a rounded low part leaves
+//    its tight bound in the control block and is repeated by the second launch (which every other block leaves at once);
+//  * the low parts and the non-finite marks of a block are written (and read back) only when it used them;
+//  * inf / NaN no longer leave the fixed-point path: an accumulator carries three marks (+inf, -inf, NaN seen) and the total is
+//    what IEEE addition gives in ANY order (NaN if NaN or both infinities, else the infinity, else the exact finite sum).
+// The control block lives on the handle (device memory, zero = idle): nothing depends on a host-side call count, so a captured
+// sequence of calls (the warm-up's round graph) replays correctly from any state.
+#define KM_PX_TPR 8                                     // float4 lanes per row piece
+#define KM_PX_MAXM 8                                    // sub-quantisers a piece can touch (dsub >= 4)
+#define KM_PX_MAXP 64                                   // pieces of a row (D <= 2048)
+#define KM_NONE INT_MIN
 
-// per-call state words in scratch: [0] max|x| bits seen by pass 0 (also the strip kernels' gate), [1] flags of pass 0
-// (bit 0: a part was rounded), hint[2] lives on the handle (parity = call number)
-struct km_decision { int sexp; bool accept0, redo, nonfinite; int tight_eb; };
+struct km_piece_ctl { unsigned arrive, am, fl; int redo; unsigned pad[4]; };
+struct km_ctl {
+    int hint;                                            // |x| < 2^hint expected by the next call
+    int hint_acc;                                        // max over the pieces of (tight bound + 1) of the running call
+    int pad[14];
+    km_piece_ctl piece[KM_PX_MAXP];
+};
 
 __device__ __forceinline__ int km_tight_eb(unsigned am) { return am == 0u ? -126 : (int)(am >> 23) - 126; }   // |x| < 2^eb
-
-template <int PASS>
-__device__ __forceinline__ km_decision km_decide(const unsigned* __restrict__ state, int hint_eb, int log2n) {
-    km_decision d;
-    if (PASS == 0) {
-        d.sexp = 61 - log2n - hint_eb; d.accept0 = d.redo = d.nonfinite = false; d.tight_eb = hint_eb;
-        return d;
-    }
-    const unsigned am = state[0], fl = state[1];
-    d.nonfinite = am >= 0x7F800000u;
-    d.tight_eb = km_tight_eb(am);
-    d.accept0 = !d.nonfinite && d.tight_eb <= hint_eb && !(fl & 1u);
-    d.redo = !d.nonfinite && !d.accept0;
-    d.sexp = 61 - log2n - (d.accept0 ? hint_eb : d.tight_eb);
-    return d;
-}
 
 // x 2^sexp = hi + lo 2^-38 on the bits of x (finite).  Returns true when lo had to be rounded.
 __device__ __forceinline__ bool km_fx_split(unsigned b, int sexp, long long& hi, long long& lo) {
@@ -174,15 +179,15 @@ __device__ __forceinline__ bool km_fx_split(unsigned b, int sexp, long long& hi,
     return inexact;
 }
 
-// One row's float4 (values j = 4 q .. 4 q + 3 of sub-quantiser m) into the LDS accumulators of centroid k.
+// One row's float4 (lane q of the piece) into the LDS accumulators of centroid k: accumulator (k, q, e) at e ESTRIDE + 8 k + q.
 // Fast path (every value's significand is shifted LEFT: nothing below the integer grid): per value 3 + 3 + 1 + 1 integer
-// instructions and one ds_add_u64 at an immediate offset; otherwise the general split.  emax collects the exponent fields.
-template <int TPR>
-__device__ __forceinline__ bool km_fx_row(const float4 v, int k, int q, int sexp, unsigned long long* __restrict__ hi,
-                                          unsigned long long* __restrict__ lo, unsigned& emax) {
-    constexpr int ESTRIDE = RC_K * TPR;                    // accumulator (k, j = 4 q + e) at e ESTRIDE + k TPR + q
+// instructions and one ds_add_u64 at an immediate offset; otherwise the general split.  emax collects the exponent fields of
+// the FINITE values; bit 0 of the result: a low part was rounded, bit 1: a low part was used, bit 2: a non-finite value.
+__device__ __forceinline__ unsigned km_px_row(const float4 v, int k, int q, int sexp, unsigned long long* __restrict__ hi,
+                                              unsigned long long* __restrict__ lo, unsigned* __restrict__ nfl, unsigned& emax) {
+    constexpr int ESTRIDE = RC_K * KM_PX_TPR;
     const unsigned b[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    unsigned long long* a = hi + (k * TPR + q);
+    unsigned long long* a = hi + (k * KM_PX_TPR + q);
     unsigned e[4];
     int sh[4];
 #pragma unroll
@@ -190,11 +195,11 @@ __device__ __forceinline__ bool km_fx_row(const float4 v, int k, int q, int sexp
         e[i] = (b[i] >> 23) & 0xFFu;
         sh[i] = (int)(e[i] ? e[i] : 1u) - 150 + sexp;       // |x| 2^sexp = significand 2^sh
     }
-    emax = max(emax, max(max(e[0], e[1]), max(e[2], e[3])));
     const int shmin = min(min(sh[0], sh[1]), min(sh[2], sh[3]));
     const int shmax = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
-    bool inexact = false;
+    unsigned what = 0u;
     if (shmin >= 0 && shmax <= 40) {
+        emax = max(emax, max(max(e[0], e[1]), max(e[2], e[3])));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int sig = (int)((b[i] & 0x7FFFFFu) | ((e[i] ? 1u : 0u) << 23));
@@ -205,56 +210,109 @@ __device__ __forceinline__ bool km_fx_row(const float4 v, int k, int q, int sexp
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (e[i] == 0xFFu) {                                             // inf / NaN: a mark on the accumulator, no value
+                const unsigned mark = (b[i] & 0x7FFFFFu) ? 4u : ((b[i] >> 31) ? 2u : 1u);
+                const int acc = i * ESTRIDE + k * KM_PX_TPR + q;
+                atomicOr(nfl + (acc >> 2), mark << (8 * (acc & 3)));
+                what |= 4u;
+                continue;
+            }
+            emax = max(emax, e[i]);
             long long hl, ll;
-            inexact |= km_fx_split(b[i], sexp, hl, ll);
+            if (km_fx_split(b[i], sexp, hl, ll)) what |= 1u;
             atomicAdd(a + i * ESTRIDE, (unsigned long long)hl);
-            if (ll) atomicAdd(lo + (k * TPR + q) + i * ESTRIDE, (unsigned long long)ll);
+            if (ll) {
+                atomicAdd(lo + (k * KM_PX_TPR + q) + i * ESTRIDE, (unsigned long long)ll);
+                what |= 2u;
+            }
         }
     }
-    return inexact;
+    return what;
 }
 
-// 1-D grid of strips x (M / G) blocks.  A block owns a strip of rows and G ADJACENT sub-quantisers whose G dsub floats
-// are one contiguous piece of a row (128 bytes where dsub allows: whole cache lines); TPR = float4 lanes per row =
-// G qpm.  dynamic LDS: hi[4][256][TPR] | lo[...] (int64) | cnt[G][256] (u32).  Sub-vectors wider than 32 floats go
-// in column passes (j0, G = 1).  The row loop is software-pipelined: the next KM_FX_U rows per thread are requested
-// before the current ones are split and added.
-template <int PASS, int TPR>
-__global__ __launch_bounds__(1024) void kmeans_stats_fx_kernel(const float* __restrict__ x, int64_t ldx,
-                                                               const uint8_t* __restrict__ codes, int64_t n, int M, int dsub,
-                                                               int j0, int qpm, int64_t rows_per_strip,
-                                                               unsigned* __restrict__ state, const int* __restrict__ hint,
-                                                               int log2n, long long* __restrict__ phi,
-                                                               long long* __restrict__ plo, unsigned* __restrict__ pcnt) {
-    constexpr int ESTRIDE = RC_K * TPR;
+// (hi 2^38 + lo) 2^(-sexp-38), rounded to nearest-even once
+__device__ __forceinline__ double km_fx_to_double(long long H, long long L, int sexp) {
+    __int128 t = ((__int128)H << KM_FX_LO_BITS) + (__int128)L;
+    const bool neg = t < 0;
+    unsigned __int128 u = neg ? (unsigned __int128)(-t) : (unsigned __int128)t;
+    const unsigned long long uh = (unsigned long long)(u >> 64), ul = (unsigned long long)u;
+    if ((uh | ul) == 0ull) return 0.0;
+    const int msb = uh ? 127 - __clzll((long long)uh) : 63 - __clzll((long long)ul);
+    double r;
+    if (msb <= 52) {
+        r = (double)ul;
+    } else {
+        const int sh = msb - 52;
+        unsigned long long qq = (unsigned long long)(u >> sh);                    // 53 bits
+        const unsigned __int128 rem = u & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+        qq += (rem > half || (rem == half && (qq & 1ull))) ? 1ull : 0ull;         // <= 2^53: exact in fp64
+        r = ldexp((double)qq, sh);
+    }
+    r = ldexp(r, -sexp - KM_FX_LO_BITS);
+    return neg ? -r : r;
+}
+
+// 1-D grid of strips x P blocks of 1024 threads (128 rows x 8 lanes per trip).  dynamic LDS: hi[4][256][8] | lo[4][256][8]
+// (int64) | cnt[KM_PX_MAXM][256] (u32) | nfl[4 x 256 x 8 bytes] | a few words.  The row loop is software-pipelined: the next
+// KM_FX_U rows per thread are requested before the current ones are split and added.
+// PASS 0: every block works, scale from the hint.  PASS 1: only the pieces whose control word holds a tight bound (the others
+// leave at once), scale from that bound; block (0, 0) commits the next call's hint.
+// scratch: phi / plo [strips][M K dsub] int64, pcnt [strips][M K] u32, pnf [strips][M K dsub] bytes, sfl [strips][P] u32.
+template <int PASS>
+__global__ __launch_bounds__(1024) void kmeans_stats_px_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const uint8_t* __restrict__ codes, int64_t n, int D, int M,
+                                                               int dsub, int P, int strips, int64_t rows_per_strip,
+                                                               km_ctl* __restrict__ ctl, int log2n, long long* __restrict__ phi,
+                                                               long long* __restrict__ plo, unsigned* __restrict__ pcnt,
+                                                               unsigned char* __restrict__ pnf, unsigned* __restrict__ sfl,
+                                                               double* __restrict__ sums,
+                                                               unsigned long long* __restrict__ counts) {
+    constexpr int TPR = KM_PX_TPR, ESTRIDE = RC_K * TPR, NACC = 4 * ESTRIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
     unsigned long long* hi = reinterpret_cast<unsigned long long*>(km_smem);
-    unsigned long long* lo = hi + 4 * ESTRIDE;
-    unsigned* cnt = reinterpret_cast<unsigned*>(lo + 4 * ESTRIDE);
-    const km_decision dec = km_decide<PASS>(state, *hint, log2n);
-    if (PASS == 1 && !dec.redo) return;                    // the hint held (or inf / NaN: the strip kernels take the call)
-    const int sexp = dec.sexp;
+    unsigned long long* lo = hi + NACC;
+    unsigned* cnt = reinterpret_cast<unsigned*>(lo + NACC);
+    unsigned* nfl = cnt + KM_PX_MAXM * RC_K;                  // NACC bytes
+    unsigned* s_w = nfl + NACC / 4;                           // [0] what-bits of the block, [1] last-block flag, [2] decision
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int G = TPR / qpm, groups = M / G;
-    // XCD x (blocks L = x mod 8) walks a contiguous range of (strip, group) pairs, group fastest
-    const unsigned L = blockIdx.x, T = gridDim.x, per = T / 8u;
-    const unsigned v = (L < per * 8u) ? (L % 8u) * per + L / 8u : L;
-    const int m0 = (int)(v % (unsigned)groups) * G, strip = (int)(v / (unsigned)groups);
-    for (int i = tid; i < 8 * ESTRIDE; i += nthr) hi[i] = 0ull;
-    for (int i = tid; i < G * RC_K; i += nthr) cnt[i] = 0u;
+    // XCD x (blocks L = x mod 8) walks a contiguous range of (strip, piece) pairs, piece fastest: the blocks that share a
+    // strip's codes (and the two 64-byte halves of every line) meet in one L2
+    const unsigned Lb = blockIdx.x, T = gridDim.x, per = T / 8u;
+    const unsigned v = (Lb < per * 8u) ? (Lb % 8u) * per + Lb / 8u : Lb;
+    const int p = (int)(v % (unsigned)P), strip = (int)(v / (unsigned)P);
+    km_piece_ctl* pc = &ctl->piece[p];
+    int sexp;
+    if (PASS == 0) {
+        sexp = 61 - log2n - ctl->hint;
+    } else {
+        if (blockIdx.x == 0 && tid == 0) {                    // the bound of this call's data + one bit becomes the next hint
+            const int acc = ctl->hint_acc;
+            if (acc != KM_NONE) ctl->hint = acc > 127 ? 127 : acc;
+            ctl->hint_acc = KM_NONE;
+        }
+        const int eb = __hip_atomic_load(&pc->redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (eb == KM_NONE) return;                            // the hint held for this piece (block-uniform)
+        sexp = 61 - log2n - eb;
+    }
+    for (int i = tid; i < 2 * NACC; i += nthr) hi[i] = 0ull;
+    for (int i = tid; i < KM_PX_MAXM * RC_K + NACC / 4; i += nthr) cnt[i] = 0u;
+    if (tid < 4) s_w[tid] = 0u;
     __syncthreads();
     const int64_t r0 = (int64_t)strip * rows_per_strip;
     const int64_t r1 = (r0 + rows_per_strip < n) ? r0 + rows_per_strip : n;
     const int rpi = nthr / TPR;                            // rows per block iteration (one float4 per thread)
-    const int q = tid % TPR, mloc = q / qpm;
-    unsigned emax = 0u;
-    bool inexact = false;
-    const bool count = PASS == 0 && (q % qpm) == 0 && j0 == 0;
-    unsigned* mycnt = cnt + mloc * RC_K;
-    if (tid < rpi * TPR) {
+    const int q = tid % TPR;
+    const int fl0 = 32 * p + 4 * q;                        // this lane's first float of the row
+    const int mfirst = (32 * p) / dsub;
+    const bool lane_on = fl0 < D;
+    const int m = lane_on ? fl0 / dsub : 0;
+    const bool count = lane_on && (fl0 % dsub) == 0;
+    unsigned emax = 0u, what = 0u;
+    unsigned* mycnt = cnt + (m - mfirst) * RC_K;
+    if (lane_on && tid < rpi * TPR) {
         int64_t r = r0 + tid / TPR;
-        const float* xp = x + r * ldx + (m0 + mloc) * dsub + j0 + 4 * (q % qpm);
-        const uint8_t* cp = codes + r * M + m0 + mloc;
+        const float* xp = x + r * ldx + fl0;
+        const uint8_t* cp = codes + r * M + m;
         const int64_t xstep = (int64_t)rpi * ldx, cstep = (int64_t)rpi * M;
         int kc[KM_FX_U];
         float4 vc[KM_FX_U];
@@ -287,7 +345,7 @@ __global__ __launch_bounds__(1024) void kmeans_stats_fx_kernel(const float* __re
 #pragma unroll
             for (int u = 0; u < KM_FX_U; ++u) {
                 if (kc[u] >= 0) {
-                    inexact |= km_fx_row<TPR>(vc[u], kc[u], q, sexp, hi, lo, emax);
+                    what |= km_px_row(vc[u], kc[u], q, sexp, hi, lo, nfl, emax);
                     if (count) atomicAdd(&mycnt[kc[u]], 1u);
                 }
             }
@@ -295,112 +353,101 @@ __global__ __launch_bounds__(1024) void kmeans_stats_fx_kernel(const float* __re
             for (int u = 0; u < KM_FX_U; ++u) { kc[u] = kn[u]; vc[u] = vn[u]; }
         }
     }
-    if (PASS == 0) {
-        unsigned amax = emax << 23;                        // ordered like max|x|: only its exponent field is used
+    __builtin_amdgcn_s_setprio(0);
+    {
+        unsigned amax = emax << 23;                        // ordered like max|x| of the finite values: only its exponent field is used
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned t = (unsigned)__shfl_xor((int)amax, o);
             amax = t > amax ? t : amax;
+            what |= (unsigned)__shfl_xor((int)what, o);
         }
-        const unsigned long long anyx = __ballot(inexact);
         if ((tid & 63) == 0) {
-            if (amax > __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&state[0], amax);
-            if (anyx) atomicOr(&state[1], 1u);
+            if (PASS == 0 && amax > __hip_atomic_load(&pc->am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&pc->am, amax);
+            if (PASS == 0 && (what & 1u)) atomicOr(&pc->fl, 1u);
+            if (what) atomicOr(&s_w[0], what);
         }
     }
     __syncthreads();
-    // partials of this (strip, group): plain stores, [strip][m][k][j]
-    const int jn = 4 * qpm;                                // columns of one sub-quantiser in this pass
-    for (int i = tid; i < G * RC_K * jn; i += nthr) {
-        const int j = i % jn, k = (i / jn) % RC_K, ml = i / (jn * RC_K);
-        const int a = (j & 3) * ESTRIDE + k * TPR + ml * qpm + (j >> 2);
-        const size_t o = (((size_t)strip * M + m0 + ml) * RC_K + k) * dsub + j0 + j;
-        phi[o] = (long long)hi[a];
-        plo[o] = (long long)lo[a];
+    const unsigned bw = s_w[0];                            // bit 1: low parts used, bit 2: non-finite marks set (by this block)
+    // ---- partials of this (strip, piece): write-through stores (the reducer may sit on another XCD), [strip][m][k][j]
+    const size_t per_strip = (size_t)M * RC_K * dsub;
+    for (int i = tid; i < RC_K * 32; i += nthr) {
+        const int f = i & 31, k = i >> 5, fl = 32 * p + f;
+        if (fl >= D) continue;
+        const int a = (f & 3) * ESTRIDE + k * TPR + (f >> 2);
+        const size_t o = (size_t)strip * per_strip + ((size_t)(fl / dsub) * RC_K + k) * dsub + (fl % dsub);
+        __hip_atomic_store(phi + o, (long long)hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bw & 2u) __hip_atomic_store(plo + o, (long long)lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bw & 4u) __hip_atomic_store(pnf + o, reinterpret_cast<const unsigned char*>(nfl)[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (PASS == 0 && j0 == 0)
-        for (int i = tid; i < G * RC_K; i += nthr) pcnt[((size_t)strip * M + m0) * RC_K + i] = cnt[i];
-}
-
-// (hi 2^38 + lo) 2^(-sexp-38), rounded to nearest-even once
-__device__ __forceinline__ double km_fx_to_double(long long H, long long L, int sexp) {
-    __int128 t = ((__int128)H << KM_FX_LO_BITS) + (__int128)L;
-    const bool neg = t < 0;
-    unsigned __int128 u = neg ? (unsigned __int128)(-t) : (unsigned __int128)t;
-    const unsigned long long uh = (unsigned long long)(u >> 64), ul = (unsigned long long)u;
-    if ((uh | ul) == 0ull) return 0.0;
-    const int msb = uh ? 127 - __clzll((long long)uh) : 63 - __clzll((long long)ul);
-    double r;
-    if (msb <= 52) {
-        r = (double)ul;
-    } else {
-        const int sh = msb - 52;
-        unsigned long long qq = (unsigned long long)(u >> sh);                    // 53 bits
-        const unsigned __int128 rem = u & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
-        qq += (rem > half || (rem == half && (qq & 1ull))) ? 1ull : 0ull;         // <= 2^53: exact in fp64
-        r = ldexp((double)qq, sh);
+    {
+        const int nm = (min(32 * p + 31, D - 1)) / dsub - mfirst + 1;          // sub-quantisers this piece touches
+        for (int i = tid; i < nm * RC_K; i += nthr) {
+            const int ml = i / RC_K, mm = mfirst + ml;
+            if ((mm * dsub) >= 32 * p && (mm * dsub) < 32 * p + 32)            // ... and counts: the one whose first float is here
+                __hip_atomic_store(pcnt + ((size_t)strip * M + mm) * RC_K + (i % RC_K), cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    r = ldexp(r, -sexp - KM_FX_LO_BITS);
-    return neg ? -r : r;
-}
-
-template <int PASS>
-__global__ __launch_bounds__(256) void kmeans_stats_fx_finish_kernel(const long long* __restrict__ phi,
-                                                                     const long long* __restrict__ plo,
-                                                                     const unsigned* __restrict__ pcnt, int strips,
-                                                                     const unsigned* __restrict__ state,
-                                                                     const int* __restrict__ hint, int* __restrict__ hint_next,
-                                                                     int log2n, int64_t total, int dsub,
-                                                                     double* __restrict__ sums,
-                                                                     unsigned long long* __restrict__ counts) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const km_decision dec = km_decide<1>(state, *hint, log2n);
-    if (PASS == 0 && i == 0) {
-        // the next call's bound: this data's, plus one bit so that a slightly larger maximum does not cost a second pass
-        *hint_next = dec.nonfinite ? *hint : (dec.tight_eb + 1 > 127 ? 127 : dec.tight_eb + 1);
+    if (tid == 0) __hip_atomic_store(sfl + (size_t)strip * P + p, bw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&pc->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned last = (old + 1u == (unsigned)strips), go = 0u;
+        if (last) {
+            // the piece's last block decides for the piece (its data only: another piece exceeding the hint does not touch these sums)
+            __hip_atomic_store(&pc->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (PASS == 0) {
+                const unsigned am = __hip_atomic_load(&pc->am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned fl = __hip_atomic_load(&pc->fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int tight = km_tight_eb(am);
+                atomicMax(&ctl->hint_acc, tight + 1);
+                go = (tight <= ctl->hint && !(fl & 1u)) ? 1u : 0u;
+                __hip_atomic_store(&pc->redo, go ? KM_NONE : tight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&pc->am, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&pc->fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                go = 1u;
+                __hip_atomic_store(&pc->redo, KM_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        s_w[1] = last;
+        s_w[2] = go;
     }
-    if (i >= total) return;
-    if (PASS == 0 ? !dec.accept0 : !dec.redo) return;
-    long long H = 0, L = 0;
-    for (int t = 0; t < strips; ++t) {
-        H += phi[(size_t)t * total + i];
-        L += plo[(size_t)t * total + i];
+    __syncthreads();
+    if (!s_w[1] || !s_w[2]) return;
+    // ---- the piece's total: integer sums over the strips (any order), one rounding, into the caller's sums / counts
+    unsigned sf_any = 0u;
+    for (int t = 0; t < strips; ++t) sf_any |= __hip_atomic_load(sfl + (size_t)t * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < RC_K * 32; i += nthr) {
+        const int f = i & 31, k = i >> 5, fl = 32 * p + f;
+        if (fl >= D) continue;
+        const int mm = fl / dsub, j = fl % dsub;
+        const size_t o = ((size_t)mm * RC_K + k) * dsub + j;
+        long long H = 0, L = 0;
+        unsigned marks = 0u;
+        for (int t = 0; t < strips; ++t) {
+            H += __hip_atomic_load(phi + (size_t)t * per_strip + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sf_any & 6u) {
+                const unsigned sf = __hip_atomic_load(sfl + (size_t)t * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sf & 2u) L += __hip_atomic_load(plo + (size_t)t * per_strip + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sf & 4u) marks |= __hip_atomic_load(pnf + (size_t)t * per_strip + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        double r;
+        if (marks & 4u || (marks & 3u) == 3u) r = __builtin_nan("");
+        else if (marks & 1u) r = INFINITY;
+        else if (marks & 2u) r = -INFINITY;
+        else r = km_fx_to_double(H, L, sexp);
+        sums[o] += r;
+        if (j == 0) {                                          // (a repeated piece counts in the pass that produces its sums)
+            unsigned long long c = 0;
+            for (int t = 0; t < strips; ++t)
+                c += __hip_atomic_load(pcnt + ((size_t)t * M + mm) * RC_K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            counts[(size_t)mm * RC_K + k] += c;
+        }
     }
-    sums[i] += km_fx_to_double(H, L, dec.sexp);
-    if (i % dsub == 0) {
-        unsigned long long c = 0;
-        for (int t = 0; t < strips; ++t) c += pcnt[(size_t)t * (total / dsub) + i / dsub];
-        counts[i / dsub] += c;
-    }
-}
-
-__global__ void km_zero_state_kernel(unsigned* __restrict__ state) {
-    if (threadIdx.x < 2) state[threadIdx.x] = 0u;
-}
-
-template <int PASS, int TPR>
-static int km_fx_launch_tpr(rc_handle_t h, int blocks, int nthr, size_t lds, size_t lds_max, hipStream_t s, const float* x,
-                            int64_t ldx, const uint8_t* codes, int64_t n, int M, int dsub, int j0, int qpm, int64_t frps, unsigned* state,
-                            const int* hint, int log2n, long long* phi, long long* plo, unsigned* pcn) {
-    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmeans_stats_fx_kernel<PASS, TPR>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_max));
-    hipLaunchKernelGGL((kmeans_stats_fx_kernel<PASS, TPR>), dim3((unsigned)blocks), dim3(nthr), lds, s, x, ldx, codes, n, M, dsub, j0,
-                       qpm, frps, state, hint, log2n, phi, plo, pcn);
-    RC_LAUNCH_CHECK(h);
-    return RC_OK;
-}
-
-template <int PASS>
-static int km_fx_launch(rc_handle_t h, int tpr, int blocks, int nthr, size_t lds, size_t lds_max, hipStream_t s, const float* x,
-                        int64_t ldx, const uint8_t* codes, int64_t n, int M, int dsub, int j0, int qpm, int64_t frps, unsigned* state,
-                        const int* hint, int log2n, long long* phi, long long* plo, unsigned* pcn) {
-#define KM_FX_CASE(T) case T: return km_fx_launch_tpr<PASS, T>(h, blocks, nthr, lds, lds_max, s, x, ldx, codes, n, M, dsub, j0, qpm, frps, \
-                                                              state, hint, log2n, phi, plo, pcn)
-    switch (tpr) {
-        KM_FX_CASE(1); KM_FX_CASE(2); KM_FX_CASE(3); KM_FX_CASE(4); KM_FX_CASE(5); KM_FX_CASE(6); KM_FX_CASE(7); KM_FX_CASE(8);
-        default: return RC_ESHAPE;
-    }
-#undef KM_FX_CASE
 }
 
 extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const uint8_t* codes, int64_t n, int D,
@@ -414,10 +461,55 @@ extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0) && (dsub % 4 == 0);
     const int64_t per_strip = (int64_t)M * RC_K * dsub;
-    // exact fixed-point path (see above): float4 rows, n < 2^24 per call, finite input (checked on the device)
-    const bool fx = vec && n < (1ll << 24) && !rc_env_set("RC_KMEANS_STRIPS");
-    const unsigned* gate = nullptr;                                // device word: strip kernels run iff it is not finite
-    // strip fall-back geometry (shares the scratch block)
+    // exact fixed-point path (see above): float4 rows, n < 2^24 per call
+    const int P = (D + 31) / 32;
+    const bool fx = vec && n < (1ll << 24) && P <= KM_PX_MAXP && !rc_env_set("RC_KMEANS_STRIPS");
+    if (fx) {
+        int log2n = 0;
+        while ((1ll << log2n) < n) ++log2n;
+        if (!h->km_ctl) {                                           // control block: zero = idle, first hint
+            void* c = nullptr;
+            RC_HIP_CHECK(h, hipMalloc(&c, sizeof(km_ctl)));
+            km_ctl init;
+            memset(&init, 0, sizeof init);
+            init.hint = KM_FX_EB0;
+            init.hint_acc = KM_NONE;
+            for (auto& pc : init.piece) pc.redo = KM_NONE;
+            RC_HIP_CHECK(h, hipMemcpy(c, &init, sizeof init, hipMemcpyHostToDevice));
+            h->km_ctl = c;
+        }
+        km_ctl* ctl = (km_ctl*)h->km_ctl;
+        constexpr int NACC = 4 * RC_K * KM_PX_TPR;
+        const size_t lds = (size_t)2 * NACC * sizeof(unsigned long long) + (size_t)KM_PX_MAXM * RC_K * sizeof(unsigned) + NACC + 64;
+        const int slots = h->num_cus;                               // one 1024-thread block (134 KiB of LDS) per CU
+        int fstrips = slots / P;                                    // one round of equal blocks
+        if (fstrips < 1) fstrips = 1;
+        if (fstrips > (int)((n + 255) / 256)) fstrips = (int)((n + 255) / 256);
+        const int64_t frps = (n + fstrips - 1) / fstrips;
+        fstrips = (int)((n + frps - 1) / frps);
+        const size_t lbytes = rc_align_up((size_t)fstrips * per_strip * sizeof(long long), 256);
+        const size_t cb = rc_align_up((size_t)fstrips * M * RC_K * sizeof(unsigned), 256);
+        const size_t nb = rc_align_up((size_t)fstrips * per_strip, 256);
+        const size_t fb = rc_align_up((size_t)fstrips * P * sizeof(unsigned), 256);
+        char* ws = (char*)rc_scratch(h, 2 * lbytes + cb + nb + fb);
+        if (!ws) return RC_EHIP;
+        long long* phi = (long long*)ws;
+        long long* plo = (long long*)(ws + lbytes);
+        unsigned* pcn = (unsigned*)(ws + 2 * lbytes);
+        unsigned char* pnf = (unsigned char*)(ws + 2 * lbytes + cb);
+        unsigned* sfl = (unsigned*)(ws + 2 * lbytes + cb + nb);
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmeans_stats_px_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmeans_stats_px_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kmeans_stats_px_kernel<0>, dim3((unsigned)(fstrips * P)), dim3(1024), lds, s, x, ldx, codes, n, D, M, dsub, P,
+                           fstrips, frps, ctl, log2n, phi, plo, pcn, pnf, sfl, sums, reinterpret_cast<unsigned long long*>(counts));
+        RC_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL(kmeans_stats_px_kernel<1>, dim3((unsigned)(fstrips * P)), dim3(1024), lds, s, x, ldx, codes, n, D, M, dsub, P,
+                           fstrips, frps, ctl, log2n, phi, plo, pcn, pnf, sfl, sums, reinterpret_cast<unsigned long long*>(counts));
+        RC_LAUNCH_CHECK(h);
+        return RC_OK;
+    }
+    // fixed-order strip kernels: rows that are not float4-addressable, sub-vector widths that are not multiples of 4, 2^24 rows
+    // or more in one call, RC_KMEANS_STRIPS=1
     int64_t rps = 8192;                                            // rows per strip
     int strips = (int)((n + rps - 1) / rps);
     if (strips > KM_MAX_STRIPS) {
@@ -428,71 +520,8 @@ extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const
     }
     const size_t pbytes = rc_align_up((size_t)strips * per_strip * sizeof(double), 256);
     const size_t cbytes = rc_align_up((size_t)strips * M * RC_K * sizeof(unsigned), 256);
-    if (fx) {
-        int log2n = 0;
-        while ((1ll << log2n) < n) ++log2n;
-        if (!h->km_hint) {                                          // hint[2] + first-call value
-            RC_HIP_CHECK(h, hipMalloc((void**)&h->km_hint, 2 * sizeof(int)));
-            const int init[2] = {KM_FX_EB0, KM_FX_EB0};
-            RC_HIP_CHECK(h, hipMemcpy(h->km_hint, init, sizeof(init), hipMemcpyHostToDevice));
-            h->km_calls = 0;
-        }
-        // G adjacent sub-quantisers per block so that a row's piece is 128 bytes where the width allows (whole lines)
-        int G = dsub <= 32 ? 32 / dsub : 1;
-        if (G > 1 && M % G != 0) G = 1;
-        const int tpr_max = dsub <= KM_FX_JN ? G * dsub / 4 : KM_FX_JN / 4;
-        const size_t lds_max = (size_t)8 * RC_K * tpr_max * sizeof(unsigned long long) + (size_t)G * RC_K * sizeof(unsigned);
-        const int nthr = lds_max > 80 * 1024 ? 1024 : 512;          // 16 waves per CU either way
-        const int slots = h->num_cus * (nthr == 1024 ? 1 : 2);
-        const int groups = M / G;
-        int fstrips = slots / groups;                               // one round of equal blocks
-        if (fstrips < 1) fstrips = 1;
-        if (fstrips > (int)((n + 255) / 256)) fstrips = (int)((n + 255) / 256);
-        const int64_t frps = (n + fstrips - 1) / fstrips;
-        fstrips = (int)((n + frps - 1) / frps);
-        const size_t lbytes = rc_align_up((size_t)fstrips * per_strip * sizeof(long long), 256);
-        const size_t cb = rc_align_up((size_t)fstrips * M * RC_K * sizeof(unsigned), 256);
-        const size_t fx_bytes = 2 * lbytes + cb;
-        const size_t body = fx_bytes > pbytes + cbytes ? fx_bytes : pbytes + cbytes;
-        char* ws = (char*)rc_scratch(h, body + 256);
-        if (!ws) return RC_EHIP;
-        long long* phi = (long long*)ws;
-        long long* plo = (long long*)(ws + lbytes);
-        unsigned* pcn = (unsigned*)(ws + 2 * lbytes);
-        unsigned* state = (unsigned*)(ws + body);                   // behind everything the strip kernels use
-        const int* hint = h->km_hint + (h->km_calls & 1);
-        int* hint_next = h->km_hint + ((h->km_calls + 1) & 1);
-        ++h->km_calls;
-        // a kernel store, not hipMemsetAsync: inside a captured hipGraph (the warm-up's Lloyd block) repeated memset nodes
-        // faulted on the graph's second replay (round 4, ROCm 7.0 runtime of the torch wheel)
-        hipLaunchKernelGGL(km_zero_state_kernel, dim3(1), dim3(64), 0, s, state);
-        RC_LAUNCH_CHECK(h);
-        const unsigned fin_blocks = (unsigned)((per_strip + 255) / 256);
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int j0 = 0; j0 < dsub; j0 += KM_FX_JN) {
-                const int jn = dsub - j0 < KM_FX_JN ? dsub - j0 : KM_FX_JN;
-                const int qpm = jn / 4, tpr = G * qpm;
-                const size_t lds = (size_t)8 * RC_K * tpr * sizeof(unsigned long long) + (size_t)G * RC_K * sizeof(unsigned);
-                const int rc = pass == 0 ? km_fx_launch<0>(h, tpr, fstrips * groups, nthr, lds, lds_max, s, x, ldx, codes, n, M, dsub, j0, qpm,
-                                                           frps, state, hint, log2n, phi, plo, pcn)
-                                         : km_fx_launch<1>(h, tpr, fstrips * groups, nthr, lds, lds_max, s, x, ldx, codes, n, M, dsub, j0, qpm,
-                                                           frps, state, hint, log2n, phi, plo, pcn);
-                if (rc != RC_OK) return rc;
-                RC_LAUNCH_CHECK(h);
-            }
-            if (pass == 0)
-                hipLaunchKernelGGL(kmeans_stats_fx_finish_kernel<0>, dim3(fin_blocks), dim3(256), 0, s, (const long long*)phi,
-                                   (const long long*)plo, (const unsigned*)pcn, fstrips, (const unsigned*)state, hint, hint_next,
-                                   log2n, per_strip, dsub, sums, reinterpret_cast<unsigned long long*>(counts));
-            else
-                hipLaunchKernelGGL(kmeans_stats_fx_finish_kernel<1>, dim3(fin_blocks), dim3(256), 0, s, (const long long*)phi,
-                                   (const long long*)plo, (const unsigned*)pcn, fstrips, (const unsigned*)state, hint, hint_next,
-                                   log2n, per_strip, dsub, sums, reinterpret_cast<unsigned long long*>(counts));
-            RC_LAUNCH_CHECK(h);
-        }
-        gate = state;             // the strip kernels below leave at once unless max|x| is inf / NaN (decided on the device)
-    }
-    char* ws = (char*)rc_scratch(h, pbytes + cbytes + (fx ? 256 : 0));
+    const unsigned* gate = nullptr;
+    char* ws = (char*)rc_scratch(h, pbytes + cbytes);
     if (!ws) return RC_EHIP;
     double* part = (double*)ws;
     unsigned* pcnt = (unsigned*)(ws + pbytes);

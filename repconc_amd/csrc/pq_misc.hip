@@ -47,8 +47,7 @@ extern "C" int rc_create(rc_handle_t* out, int device) {
     h->scratch_bytes = 0;
     h->graph_broken = 0;
     h->capturing = 0;
-    h->km_hint = nullptr;
-    h->km_calls = 0;
+    h->km_ctl = nullptr;
     memset(&h->ipc, 0, sizeof(h->ipc));
     *out = h;
     return RC_OK;
@@ -64,7 +63,8 @@ extern "C" int rc_destroy(rc_handle_t h) {
         for (double* t : h->exp2_tab)
             if (t) (void)hipFree(t);
         if (h->scratch) (void)hipFree(h->scratch);
-        if (h->km_hint) (void)hipFree(h->km_hint);
+        for (void* r : h->scratch_retired) (void)hipFree(r);
+        if (h->km_ctl) (void)hipFree(h->km_ctl);
         for (auto& g : h->graphs) {
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
             if (g.graph) (void)hipGraphDestroy(g.graph);
@@ -77,14 +77,14 @@ extern "C" int rc_destroy(rc_handle_t h) {
 void* rc_scratch(rc_handle_t h, size_t bytes) {
     if (!h) return nullptr;
     if (bytes <= h->scratch_bytes) return h->scratch;
-    if (h->scratch) {
-        (void)hipDeviceSynchronize();                    // work queued on the old block finishes before it is freed
-        (void)hipFree(h->scratch);
-        h->scratch = nullptr;
-        h->scratch_bytes = 0;
-    }
+    // Growth RETIRES the old block instead of freeing it (released by rc_destroy): work already queued on it — and any hipGraph a
+    // caller captured over rc_* calls (the warm-up's round graph bakes the scratch pointer into its kernel nodes) — keeps
+    // running on valid memory, each captured call sequence consistently on the block it was captured with; nothing here
+    // synchronises the device, so growing inside a stream capture is harmless too.  Geometric growth bounds what is retained.
+    if (bytes < h->scratch_bytes + h->scratch_bytes / 2) bytes = h->scratch_bytes + h->scratch_bytes / 2;
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (h->scratch) h->scratch_retired.push_back(h->scratch);
     h->scratch = p;
     h->scratch_bytes = bytes;
     return p;

@@ -46,10 +46,10 @@ struct rc_handle_s {
     } ipc;
     void* scratch;                                    // handle-owned device scratch (rc_scratch), grown on demand
     size_t scratch_bytes;
+    std::vector<void*> scratch_retired;               // outgrown scratch blocks, kept until rc_destroy (see rc_scratch)
     int graph_broken;                                 // capture failed once on this handle: stay eager
     int capturing;                                    // inside stream capture: no event marks
-    int* km_hint;                                     // kmeans.hip: device int[2], bound exponent of the fixed-point statistics
-    unsigned long long km_calls;                      // parity picks the hint word read / written by a call
+    void* km_ctl;                                     // kmeans.hip: device control block of the fixed-point statistics (hint, per-piece words)
 };
 
 // Fused exchange of the Sinkhorn row sums (sinkhorn.hip: sk_sweep2_kernel<.., XCHG = true>; set up by comm.hip on the IPC
