@@ -107,29 +107,40 @@ __global__ __launch_bounds__(256) void kmeans_stats_reduce_kernel(const double* 
 #define KM_FX_U 4                                       // rows in flight per thread
 #define KM_FX_EB0 4                                     // first hint of a handle: |x| < 16
 //
-// Round 5 (0.36 of the roof at the 65 536 rows the warm-up runs, 0.34 at M = 64 at every size):
+// Round 5 (0.34 of the roof at M = 64 at every size; six launches per call, four of them idle):
 //  * a block's share of a row is a PIECE of 32 consecutive floats at a 128-byte boundary whatever the sub-vector width — whole
 //    cache lines for every M (dsub = 12 / 24 / 48 used to give 96- or 64-byte pieces: each line fetched by two blocks); lane q of
 //    a piece (one float4) belongs to sub-quantiser (32 p + 4 q) / dsub and adds into the LDS accumulators of ITS code;
-//  * one launch in the common case instead of six: the decision "did the hint hold" is taken PER PIECE by the piece's
-//    last-arriving block (arrival counter, as the Sinkhorn sweep's reducer), which sums the piece's per-strip partials as
-//    integers, rounds once and adds into sums / counts; a piece whose data exceeded the hint or needed a rounded low part leaves
-//    its tight bound in the control block and is repeated by the second launch (which every other block leaves at once);
+//  * three launches, the middle one never idle: A adds the rows and stores per-strip partials, B reads every piece's verdict
+//    ("did the hint hold, was nothing rounded" — decided PER PIECE, on the piece's own data) and either takes its share of the
+//    piece's finish (integer sum over the strips, one rounding, into sums / counts) or repeats the piece with the tight bound of
+//    its data, C finishes the repeated pieces (normally none: every block leaves at once) and closes the call;
 //  * the low parts and the non-finite marks of a block are written (and read back) only when it used them;
 //  * inf / NaN no longer leave the fixed-point path: an accumulator carries three marks (+inf, -inf, NaN seen) and the total is
 //    what IEEE addition gives in ANY order (NaN if NaN or both infinities, else the infinity, else the exact finite sum).
-// The control block lives on the handle (device memory, zero = idle): nothing depends on a host-side call count, so a captured
-// sequence of calls (the warm-up's round graph) replays correctly from any state.
+// Built and measured on the way (profiles/r05*_kmeans*.txt): the finish done by each piece's last-arriving block (one launch, as
+// the Sinkhorn sweep's reducer) costs 55 us at 65 536 rows — the 24 reducing CUs read 650 KB each past their L2 at ~12-25 GB/s,
+// one CU's share of the memory system — against 11 us for launch B, whose finish runs on every CU.
+// The control block lives on the handle (device memory): nothing depends on a host-side call count, so a captured sequence of
+// calls (the warm-up's round graph) replays correctly from any state.
 #define KM_PX_TPR 8                                     // float4 lanes per row piece
 #define KM_PX_MAXM 8                                    // sub-quantisers a piece can touch (dsub >= 4)
 #define KM_PX_MAXP 64                                   // pieces of a row (D <= 2048)
-#define KM_NONE INT_MIN
 
-struct km_piece_ctl { unsigned arrive, am, fl; int redo; unsigned pad[4]; };
+// Control block (device memory on the handle).  Nothing in it is ever reset: the per-piece words carry the call's sequence
+// number in their high bits and are combined with atomicMax, so what an earlier call left behind is simply smaller; `seq` and
+// `hint` are advanced by the block of the call's last launch that arrives last (every block of that launch has read them by then).
+struct km_piece_ctl {
+    unsigned long long am;                               // max over the blocks of (seq << 8 | largest finite exponent field)
+    unsigned long long fl;                               // max of (seq << 1 | a low part was rounded)
+    unsigned long long redo;                             // (seq << 16 | tight bound + 32768) when launch B repeated the piece
+    unsigned long long pad[5];
+};
 struct km_ctl {
     int hint;                                            // |x| < 2^hint expected by the next call
-    int hint_acc;                                        // max over the pieces of (tight bound + 1) of the running call
-    int pad[14];
+    unsigned carrive;                                    // blocks of launch C that have read what they need (the last one closes the call)
+    unsigned long long seq;                              // calls completed on this handle
+    unsigned long long pad[6];
     km_piece_ctl piece[KM_PX_MAXP];
 };
 
@@ -252,17 +263,80 @@ __device__ __forceinline__ double km_fx_to_double(long long H, long long L, int 
     return neg ? -r : r;
 }
 
-// 1-D grid of strips x P blocks of 1024 threads (128 rows x 8 lanes per trip).  dynamic LDS: hi[4][256][8] | lo[4][256][8]
-// (int64) | cnt[KM_PX_MAXM][256] (u32) | nfl[4 x 256 x 8 bytes] | a few words.  The row loop is software-pipelined: the next
-// KM_FX_U rows per thread are requested before the current ones are split and added.
-// PASS 0: every block works, scale from the hint.  PASS 1: only the pieces whose control word holds a tight bound (the others
-// leave at once), scale from that bound; block (0, 0) commits the next call's hint.
-// scratch: phi / plo [strips][M K dsub] int64, pcnt [strips][M K] u32, pnf [strips][M K dsub] bytes, sfl [strips][P] u32.
+// The piece's share of the finish that block `strip` takes: entries [strip per, (strip + 1) per) of the piece's 256 x 32, summed
+// over the strips as integers (any order), rounded once, added into the caller's sums / counts.  Plain loads: the partials
+// were written by the previous launch.
+__device__ __forceinline__ void km_px_finish_share(int p, int strip, int strips, int D, int M, int dsub, int P, int sexp,
+                                                   size_t sstride, size_t cstride, const long long* __restrict__ phi,
+                                                   const long long* __restrict__ plo, const unsigned* __restrict__ pcnt,
+                                                   const unsigned char* __restrict__ pnf, const unsigned* __restrict__ sfl,
+                                                   double* __restrict__ sums, unsigned long long* __restrict__ counts) {
+    constexpr int SB = 16;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    unsigned sf_any = ((tid & 63) < strips) ? sfl[(size_t)(tid & 63) * P + p] : 0u;           // strips <= 64 (host)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sf_any |= (unsigned)__shfl_xor((int)sf_any, o);
+    const int per = (RC_K * 32 + strips - 1) / strips;
+    const int e1 = min(RC_K * 32, (strip + 1) * per);
+    for (int i = strip * per + tid; i < e1; i += nthr) {
+        const int f = i & 31, k = i >> 5, fl = 32 * p + f;
+        if (fl >= D) continue;
+        const int mm = fl / dsub, j = fl % dsub;
+        const size_t o = ((size_t)mm * RC_K + k) * dsub + j;
+        long long H = 0, L = 0;
+        unsigned marks = 0u;
+        for (int t0 = 0; t0 < strips; t0 += SB) {
+            long long hv[SB];                                  // a strip index past the end is clamped and its value masked: the
+#pragma unroll                                                 // loads of a thread go out side by side
+            for (int w = 0; w < SB; ++w) hv[w] = phi[(size_t)(t0 + w < strips ? t0 + w : strips - 1) * sstride + o];
+#pragma unroll
+            for (int w = 0; w < SB; ++w) H += (t0 + w < strips) ? hv[w] : 0ll;
+        }
+        if (sf_any & 6u) {                                     // rare: a block of the piece used low parts or met inf / NaN
+            for (int t = 0; t < strips; ++t) {
+                const unsigned sf = sfl[(size_t)t * P + p];
+                if (sf & 2u) L += plo[(size_t)t * sstride + o];
+                if (sf & 4u) marks |= pnf[(size_t)t * sstride + o];
+            }
+        }
+        double r;
+        if ((marks & 4u) || (marks & 3u) == 3u) r = __builtin_nan("");
+        else if (marks & 1u) r = INFINITY;
+        else if (marks & 2u) r = -INFINITY;
+        else r = km_fx_to_double(H, L, sexp);
+        sums[o] += r;
+        if (j == 0) {
+            unsigned long long c = 0;
+            for (int t0 = 0; t0 < strips; t0 += SB) {
+                unsigned cv[SB];
+#pragma unroll
+                for (int w = 0; w < SB; ++w) cv[w] = pcnt[(size_t)(t0 + w < strips ? t0 + w : strips - 1) * cstride + (size_t)mm * RC_K + k];
+#pragma unroll
+                for (int w = 0; w < SB; ++w) c += (t0 + w < strips) ? cv[w] : 0u;
+            }
+            counts[(size_t)mm * RC_K + k] += c;
+        }
+    }
+}
+
+// 1-D grid of strips x P blocks of 1024 threads (128 rows x 8 lanes per trip), three launches per call:
+//   PASS 0 (A)  every block adds its rows (scale from the hint) and stores its partials; the exponent maximum and the "a low part
+//               was rounded" flag of every piece go to the control block;
+//   PASS 1 (B)  every block reads its piece's verdict.  Hint held, nothing rounded (the normal case): it takes its share of the
+//               piece's finish.  Otherwise the piece is repeated: the block adds its rows again with the tight bound of the
+//               piece's own data and stores its partials again;
+//   PASS 2 (C)  blocks of repeated pieces take their share of the finish, all others leave at once; the block that arrives last
+//               moves the hint to this call's bound + one bit and closes the call (seq).
+// A piece is judged on its own data: another piece exceeding the hint does not touch these sums.
+// dynamic LDS: hi[4][256][8] | lo[4][256][8] (int64) | cnt[KM_PX_MAXM][256] (u32) | nfl[4 x 256 x 8 bytes] | a few words.  The row
+// loop is software-pipelined: the next KM_FX_U rows per thread are requested before the current ones are split and added.
+// scratch: phi / plo [strips][sstride] int64, pcnt [strips][cstride] u32, pnf [strips][sstride] bytes, sfl [strips][P] u32.
 template <int PASS>
 __global__ __launch_bounds__(1024) void kmeans_stats_px_kernel(const float* __restrict__ x, int64_t ldx,
                                                                const uint8_t* __restrict__ codes, int64_t n, int D, int M,
                                                                int dsub, int P, int strips, int64_t rows_per_strip,
-                                                               km_ctl* __restrict__ ctl, int log2n, long long* __restrict__ phi,
+                                                               km_ctl* __restrict__ ctl, int log2n, size_t sstride, size_t cstride,
+                                                               long long* __restrict__ phi,
                                                                long long* __restrict__ plo, unsigned* __restrict__ pcnt,
                                                                unsigned char* __restrict__ pnf, unsigned* __restrict__ sfl,
                                                                double* __restrict__ sums,
@@ -273,7 +347,7 @@ __global__ __launch_bounds__(1024) void kmeans_stats_px_kernel(const float* __re
     unsigned long long* lo = hi + NACC;
     unsigned* cnt = reinterpret_cast<unsigned*>(lo + NACC);
     unsigned* nfl = cnt + KM_PX_MAXM * RC_K;                  // NACC bytes
-    unsigned* s_w = nfl + NACC / 4;                           // [0] what-bits of the block, [1] last-block flag, [2] decision
+    unsigned* s_w = nfl + NACC / 4;                           // [0] what-bits of the block
     const int tid = threadIdx.x, nthr = blockDim.x;
     // XCD x (blocks L = x mod 8) walks a contiguous range of (strip, piece) pairs, piece fastest: the blocks that share a
     // strip's codes (and the two 64-byte halves of every line) meet in one L2
@@ -281,18 +355,41 @@ __global__ __launch_bounds__(1024) void kmeans_stats_px_kernel(const float* __re
     const unsigned v = (Lb < per * 8u) ? (Lb % 8u) * per + Lb / 8u : Lb;
     const int p = (int)(v % (unsigned)P), strip = (int)(v / (unsigned)P);
     km_piece_ctl* pc = &ctl->piece[p];
-    int sexp;
-    if (PASS == 0) {
-        sexp = 61 - log2n - ctl->hint;
-    } else {
-        if (blockIdx.x == 0 && tid == 0) {                    // the bound of this call's data + one bit becomes the next hint
-            const int acc = ctl->hint_acc;
-            if (acc != KM_NONE) ctl->hint = acc > 127 ? 127 : acc;
-            ctl->hint_acc = KM_NONE;
+    const unsigned long long seq = ctl->seq;               // stable during A, B and all of C but its last instruction
+    const int hint = ctl->hint;
+    int sexp = 61 - log2n - hint;
+    if (PASS >= 1) {
+        // the piece's verdict, the same in every block of the piece: am / fl are complete (launch A is over)
+        const unsigned long long am = pc->am, fl = pc->fl;
+        const int tight = ((am >> 8) == seq) ? km_tight_eb((unsigned)(am & 0xFFu) << 23) : -126;
+        const bool inexact = ((fl >> 1) == seq) && (fl & 1ull);
+        const bool accept = tight <= hint && !inexact;
+        if (PASS == 1) {
+            if (accept) {
+                km_px_finish_share(p, strip, strips, D, M, dsub, P, sexp, sstride, cstride, phi, plo, pcnt, pnf, sfl, sums, counts);
+                return;
+            }
+            if (strip == 0 && tid == 0) pc->redo = (seq << 16) | (unsigned long long)(tight + 32768);
+            sexp = 61 - log2n - tight;                     // repeat the piece with the bound of its own data
+        } else {
+            const unsigned long long rd = pc->redo;
+            if ((rd >> 16) == seq)                          // launch B repeated this piece: its partials are the new ones
+                km_px_finish_share(p, strip, strips, D, M, dsub, P, 61 - log2n - ((int)(rd & 0xFFFFull) - 32768), sstride, cstride, phi,
+                                   plo, pcnt, pnf, sfl, sums, counts);
+            if (tid == 0 && __hip_atomic_fetch_add(&ctl->carrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+                // the last block of the call's last launch (every other one has read hint and seq): the bound of this call's
+                // data (all pieces) + one bit becomes the next call's hint; then the call is closed
+                __hip_atomic_store(&ctl->carrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int eb = -126;
+                for (int q = 0; q < P; ++q) {
+                    const unsigned long long a2 = ctl->piece[q].am;
+                    if ((a2 >> 8) == seq) eb = max(eb, km_tight_eb((unsigned)(a2 & 0xFFu) << 23));
+                }
+                ctl->hint = eb + 1 > 127 ? 127 : eb + 1;
+                ctl->seq = seq + 1ull;
+            }
+            return;
         }
-        const int eb = __hip_atomic_load(&pc->redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (eb == KM_NONE) return;                            // the hint held for this piece (block-uniform)
-        sexp = 61 - log2n - eb;
     }
     for (int i = tid; i < 2 * NACC; i += nthr) hi[i] = 0ull;
     for (int i = tid; i < KM_PX_MAXM * RC_K + NACC / 4; i += nthr) cnt[i] = 0u;
@@ -355,99 +452,42 @@ __global__ __launch_bounds__(1024) void kmeans_stats_px_kernel(const float* __re
     }
     __builtin_amdgcn_s_setprio(0);
     {
-        unsigned amax = emax << 23;                        // ordered like max|x| of the finite values: only its exponent field is used
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const unsigned t = (unsigned)__shfl_xor((int)amax, o);
-            amax = t > amax ? t : amax;
+            const unsigned t = (unsigned)__shfl_xor((int)emax, o);
+            emax = t > emax ? t : emax;
             what |= (unsigned)__shfl_xor((int)what, o);
         }
         if ((tid & 63) == 0) {
-            if (PASS == 0 && amax > __hip_atomic_load(&pc->am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&pc->am, amax);
-            if (PASS == 0 && (what & 1u)) atomicOr(&pc->fl, 1u);
+            if (PASS == 0) {
+                const unsigned long long tag = (seq << 8) | (unsigned long long)emax;        // emax <= 254: finite values only
+                if (tag > __hip_atomic_load(&pc->am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&pc->am, tag);
+                if (what & 1u) atomicMax(&pc->fl, (seq << 1) | 1ull);
+            }
             if (what) atomicOr(&s_w[0], what);
         }
     }
     __syncthreads();
     const unsigned bw = s_w[0];                            // bit 1: low parts used, bit 2: non-finite marks set (by this block)
-    // ---- partials of this (strip, piece): write-through stores (the reducer may sit on another XCD), [strip][m][k][j]
-    const size_t per_strip = (size_t)M * RC_K * dsub;
+    // ---- partials of this (strip, piece), [strip][m][k][j].  Strips are `sstride` entries apart, not a power-of-two-ish 1.5 MiB.
     for (int i = tid; i < RC_K * 32; i += nthr) {
         const int f = i & 31, k = i >> 5, fl = 32 * p + f;
         if (fl >= D) continue;
         const int a = (f & 3) * ESTRIDE + k * TPR + (f >> 2);
-        const size_t o = (size_t)strip * per_strip + ((size_t)(fl / dsub) * RC_K + k) * dsub + (fl % dsub);
-        __hip_atomic_store(phi + o, (long long)hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (bw & 2u) __hip_atomic_store(plo + o, (long long)lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (bw & 4u) __hip_atomic_store(pnf + o, reinterpret_cast<const unsigned char*>(nfl)[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const size_t o = (size_t)strip * sstride + ((size_t)(fl / dsub) * RC_K + k) * dsub + (fl % dsub);
+        phi[o] = (long long)hi[a];
+        if (bw & 2u) plo[o] = (long long)lo[a];
+        if (bw & 4u) pnf[o] = reinterpret_cast<const unsigned char*>(nfl)[a];
     }
     {
         const int nm = (min(32 * p + 31, D - 1)) / dsub - mfirst + 1;          // sub-quantisers this piece touches
         for (int i = tid; i < nm * RC_K; i += nthr) {
-            const int ml = i / RC_K, mm = mfirst + ml;
+            const int mm = mfirst + i / RC_K;
             if ((mm * dsub) >= 32 * p && (mm * dsub) < 32 * p + 32)            // ... and counts: the one whose first float is here
-                __hip_atomic_store(pcnt + ((size_t)strip * M + mm) * RC_K + (i % RC_K), cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pcnt[(size_t)strip * cstride + (size_t)mm * RC_K + (i % RC_K)] = cnt[i];
         }
     }
-    if (tid == 0) __hip_atomic_store(sfl + (size_t)strip * P + p, bw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(&pc->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned last = (old + 1u == (unsigned)strips), go = 0u;
-        if (last) {
-            // the piece's last block decides for the piece (its data only: another piece exceeding the hint does not touch these sums)
-            __hip_atomic_store(&pc->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (PASS == 0) {
-                const unsigned am = __hip_atomic_load(&pc->am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned fl = __hip_atomic_load(&pc->fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int tight = km_tight_eb(am);
-                atomicMax(&ctl->hint_acc, tight + 1);
-                go = (tight <= ctl->hint && !(fl & 1u)) ? 1u : 0u;
-                __hip_atomic_store(&pc->redo, go ? KM_NONE : tight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&pc->am, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&pc->fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                go = 1u;
-                __hip_atomic_store(&pc->redo, KM_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        s_w[1] = last;
-        s_w[2] = go;
-    }
-    __syncthreads();
-    if (!s_w[1] || !s_w[2]) return;
-    // ---- the piece's total: integer sums over the strips (any order), one rounding, into the caller's sums / counts
-    unsigned sf_any = 0u;
-    for (int t = 0; t < strips; ++t) sf_any |= __hip_atomic_load(sfl + (size_t)t * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = tid; i < RC_K * 32; i += nthr) {
-        const int f = i & 31, k = i >> 5, fl = 32 * p + f;
-        if (fl >= D) continue;
-        const int mm = fl / dsub, j = fl % dsub;
-        const size_t o = ((size_t)mm * RC_K + k) * dsub + j;
-        long long H = 0, L = 0;
-        unsigned marks = 0u;
-        for (int t = 0; t < strips; ++t) {
-            H += __hip_atomic_load(phi + (size_t)t * per_strip + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (sf_any & 6u) {
-                const unsigned sf = __hip_atomic_load(sfl + (size_t)t * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sf & 2u) L += __hip_atomic_load(plo + (size_t)t * per_strip + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sf & 4u) marks |= __hip_atomic_load(pnf + (size_t)t * per_strip + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        double r;
-        if (marks & 4u || (marks & 3u) == 3u) r = __builtin_nan("");
-        else if (marks & 1u) r = INFINITY;
-        else if (marks & 2u) r = -INFINITY;
-        else r = km_fx_to_double(H, L, sexp);
-        sums[o] += r;
-        if (j == 0) {                                          // (a repeated piece counts in the pass that produces its sums)
-            unsigned long long c = 0;
-            for (int t = 0; t < strips; ++t)
-                c += __hip_atomic_load(pcnt + ((size_t)t * M + mm) * RC_K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            counts[(size_t)mm * RC_K + k] += c;
-        }
-    }
+    if (tid == 0) sfl[(size_t)strip * P + p] = bw;
 }
 
 extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const uint8_t* codes, int64_t n, int D,
@@ -473,8 +513,7 @@ extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const
             km_ctl init;
             memset(&init, 0, sizeof init);
             init.hint = KM_FX_EB0;
-            init.hint_acc = KM_NONE;
-            for (auto& pc : init.piece) pc.redo = KM_NONE;
+            init.seq = 1ull;                                        // (0 is what the zeroed per-piece words carry)
             RC_HIP_CHECK(h, hipMemcpy(c, &init, sizeof init, hipMemcpyHostToDevice));
             h->km_ctl = c;
         }
@@ -484,12 +523,17 @@ extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const
         const int slots = h->num_cus;                               // one 1024-thread block (134 KiB of LDS) per CU
         int fstrips = slots / P;                                    // one round of equal blocks
         if (fstrips < 1) fstrips = 1;
+        if (fstrips > 64) fstrips = 64;                             // (the reducer fetches a piece's strip flags with one wave)
         if (fstrips > (int)((n + 255) / 256)) fstrips = (int)((n + 255) / 256);
         const int64_t frps = (n + fstrips - 1) / fstrips;
         fstrips = (int)((n + frps - 1) / frps);
-        const size_t lbytes = rc_align_up((size_t)fstrips * per_strip * sizeof(long long), 256);
-        const size_t cb = rc_align_up((size_t)fstrips * M * RC_K * sizeof(unsigned), 256);
-        const size_t nb = rc_align_up((size_t)fstrips * per_strip, 256);
+        // strip strides: the dense size plus an odd number of 256-byte lines, so that an entry's partials of consecutive strips
+        // fall into different HBM channels (see the kernel)
+        const size_t sstride = (size_t)per_strip + 37 * 32;          // int64 entries (also the byte stride of the marks)
+        const size_t cstride = (size_t)M * RC_K + 37 * 64;           // u32 entries
+        const size_t lbytes = rc_align_up((size_t)fstrips * sstride * sizeof(long long), 256);
+        const size_t cb = rc_align_up((size_t)fstrips * cstride * sizeof(unsigned), 256);
+        const size_t nb = rc_align_up((size_t)fstrips * sstride, 256);
         const size_t fb = rc_align_up((size_t)fstrips * P * sizeof(unsigned), 256);
         char* ws = (char*)rc_scratch(h, 2 * lbytes + cb + nb + fb);
         if (!ws) return RC_EHIP;
@@ -498,14 +542,17 @@ extern "C" int rc_kmeans_stats(rc_handle_t h, const float* x, int64_t ldx, const
         unsigned* pcn = (unsigned*)(ws + 2 * lbytes);
         unsigned char* pnf = (unsigned char*)(ws + 2 * lbytes + cb);
         unsigned* sfl = (unsigned*)(ws + 2 * lbytes + cb + nb);
-        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmeans_stats_px_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmeans_stats_px_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kmeans_stats_px_kernel<0>, dim3((unsigned)(fstrips * P)), dim3(1024), lds, s, x, ldx, codes, n, D, M, dsub, P,
-                           fstrips, frps, ctl, log2n, phi, plo, pcn, pnf, sfl, sums, reinterpret_cast<unsigned long long*>(counts));
-        RC_LAUNCH_CHECK(h);
-        hipLaunchKernelGGL(kmeans_stats_px_kernel<1>, dim3((unsigned)(fstrips * P)), dim3(1024), lds, s, x, ldx, codes, n, D, M, dsub, P,
-                           fstrips, frps, ctl, log2n, phi, plo, pcn, pnf, sfl, sums, reinterpret_cast<unsigned long long*>(counts));
-        RC_LAUNCH_CHECK(h);
+#define KM_PX_GO(PASS)                                                                                                          \
+    RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kmeans_stats_px_kernel<PASS>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                        (int)lds));                                                                             \
+    hipLaunchKernelGGL(kmeans_stats_px_kernel<PASS>, dim3((unsigned)(fstrips * P)), dim3(1024), (PASS == 2 ? 0 : lds), s, x, ldx, codes, \
+                       n, D, M, dsub, P, fstrips, frps, ctl, log2n, sstride, cstride, phi, plo, pcn, pnf, sfl, sums,            \
+                       reinterpret_cast<unsigned long long*>(counts));                                                          \
+    RC_LAUNCH_CHECK(h)
+        KM_PX_GO(0);
+        KM_PX_GO(1);
+        KM_PX_GO(2);
+#undef KM_PX_GO
         return RC_OK;
     }
     // fixed-order strip kernels: rows that are not float4-addressable, sub-vector widths that are not multiples of 4, 2^24 rows
