@@ -342,6 +342,11 @@ __global__ __launch_bounds__(1024) void adc_rescore_kernel(const uint8_t* __rest
     if (tid == 0 && s_slots) cand_count[qi] = base0 + s_slots;
 }
 
+// widths the screened flat search is compiled for (rc_adc_search*: ADC_CASE); every other divisor of D is answered by the exact
+// scan with a run-time width (rc_adc_search_exact, adc_scan_rt_kernel)
+static inline bool adc_search_supported(int M) {
+    return M == 8 || M == 12 || M == 16 || M == 24 || M == 32 || M == 48 || M == 64 || M == 96;
+}
 static inline bool adc_cf_supported(int M) { return M == 16 || M == 32 || M == 48 || M == 64 || M == 96; }
 
 // adc_search.hip: sort + emit of the per-query key lists

@@ -1479,6 +1479,28 @@ extern "C" size_t rc_adc_search_exact_ws_bytes(int64_t N, int M, int K, int nq, 
     return adc_exact_ws(N, M, nq).total;
 }
 
+// Any other M (the reference's IndexPQ takes every divisor of the hidden size: modeling_repconc.py:41, evaluate_repconc.py:81):
+// exact scores with a run-time width — thread = row, the row's codes walked once for up to ADC_EXACT_QX queries, tables read
+// through the caches (M x 1 KiB per query: no LDS size fits every M), m-ascending fp32 sums like every other scoring path.
+__global__ __launch_bounds__(256) void adc_scan_rt_kernel(const uint8_t* __restrict__ codes, int64_t N, int M,
+                                                          const float* __restrict__ lut, int nq, float* __restrict__ sc) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const uint8_t* cp = codes + n * M;
+    float s[ADC_EXACT_QX];
+#pragma unroll
+    for (int t = 0; t < ADC_EXACT_QX; ++t) s[t] = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const unsigned c = cp[m];
+#pragma unroll
+        for (int t = 0; t < ADC_EXACT_QX; ++t)
+            if (t < nq) s[t] = s[t] + lut[((size_t)t * M + m) * RC_K + c];
+    }
+#pragma unroll
+    for (int t = 0; t < ADC_EXACT_QX; ++t)
+        if (t < nq) sc[(size_t)t * N + n] = s[t];
+}
+
 template <int M, int QT>
 static int adc_exact_scores(rc_handle_t h, const uint8_t* codes, int64_t N, const float* lut, int nq, float* sc, hipStream_t s) {
     const size_t lds = (size_t)M * RC_K * QT * sizeof(float);
@@ -1523,7 +1545,10 @@ extern "C" int rc_adc_search_exact(rc_handle_t h, const uint8_t* codes, int64_t 
             ADC_EXACT_CASE(8, 4) ADC_EXACT_CASE(12, 4) ADC_EXACT_CASE(16, 4) ADC_EXACT_CASE(24, 4) ADC_EXACT_CASE(32, 4)
             ADC_EXACT_CASE(48, 2) ADC_EXACT_CASE(64, 2) ADC_EXACT_CASE(96, 1)
 #undef ADC_EXACT_CASE
-            default: return RC_ESHAPE;
+            default:
+                hipLaunchKernelGGL(adc_scan_rt_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, codes, N, M, lq, nx, sc);
+                RC_LAUNCH_CHECK(h);
+                rc = RC_OK;
         }
         if (rc != RC_OK) return rc;
         hipLaunchKernelGGL(adc_exact_init_kernel, dim3((unsigned)nx), dim3(256), 0, s, hist, prefix, rank, cnt, want);

@@ -10,6 +10,7 @@
 // and retries with another selection slack exactly like repconc_amd.ops.adc_search.  Python uses torch-owned tensors
 // (repconc_amd/index.py) over the stateless entry points; this file is for hosts without torch.
 #include "rc_common.h"
+#include "adc_common.h"
 
 struct rc_index_s {
     rc_handle_t h;
@@ -161,6 +162,22 @@ extern "C" int rc_index_search(rc_index_t idx, const float* q, int nq, int k, fl
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         free(hs); free(hi);
         if (e != hipSuccess) { idx->h->last_hip_error = (int)e; return RC_EHIP; }
+        return RC_OK;
+    }
+    if (!adc_search_supported(idx->M)) {
+        // a width without a screening kernel (Faiss's IndexPQ takes any M: evaluate_repconc.py:81): the exact scan answers
+        const size_t need_x = rc_adc_search_exact_ws_bytes(idx->n, idx->M, idx->K, nq, k);
+        if (need_x == 0) return RC_ESHAPE;
+        if (need_x > idx->ws_bytes) {
+            if (idx->ws) (void)hipFree(idx->ws);
+            idx->ws = nullptr; idx->ws_bytes = 0;
+            RC_IDX_HIP(idx, hipMalloc(&idx->ws, need_x));
+            idx->ws_bytes = need_x;
+        }
+        const int rcx = rc_adc_search_exact(idx->h, idx->codes, idx->n, idx->M, idx->K, idx->C, idx->D, q, nq, k, 0, scores, ids,
+                                            idx->ws, idx->ws_bytes, stream);
+        if (rcx != RC_OK) return rcx;
+        RC_IDX_HIP(idx, hipStreamSynchronize(s));
         return RC_OK;
     }
     const size_t need = idx->image ? rc_adc_search_img_ws_bytes(idx->n, idx->M, idx->K, nq, k)

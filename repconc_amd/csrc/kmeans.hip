@@ -459,15 +459,16 @@ __global__ __launch_bounds__(1024) void kmeans_stats_px_kernel(const float* __re
             what |= (unsigned)__shfl_xor((int)what, o);
         }
         if ((tid & 63) == 0) {
-            if (PASS == 0) {
-                const unsigned long long tag = (seq << 8) | (unsigned long long)emax;        // emax <= 254: finite values only
-                if (tag > __hip_atomic_load(&pc->am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&pc->am, tag);
-                if (what & 1u) atomicMax(&pc->fl, (seq << 1) | 1ull);
-            }
+            if (emax) atomicMax(&s_w[1], emax);
             if (what) atomicOr(&s_w[0], what);
         }
     }
     __syncthreads();
+    if (PASS == 0 && tid == 0) {
+        // one fire-and-forget atomic per block (sixteen returning ones per block queued at 24 words: ~2 us of launch A's tail)
+        (void)atomicMax(&pc->am, (seq << 8) | (unsigned long long)s_w[1]);                  // <= 254: finite values only
+        if (s_w[0] & 1u) (void)atomicMax(&pc->fl, (seq << 1) | 1ull);
+    }
     const unsigned bw = s_w[0];                            // bit 1: low parts used, bit 2: non-finite marks set (by this block)
     // ---- partials of this (strip, piece), [strip][m][k][j].  Strips are `sstride` entries apart, not a power-of-two-ish 1.5 MiB.
     for (int i = tid; i < RC_K * 32; i += nthr) {

@@ -145,8 +145,11 @@ __global__ __launch_bounds__(256) void assign_prep_kernel(const float* __restric
     const float4* cp = reinterpret_cast<const float4*>(C + ((size_t)m * RC_K + tid) * DSUB);
 #pragma unroll
     for (int j4 = 0; j4 < DSUB / 4; ++j4) cst[j4] = cp[j4];
-    uint4* whi = reinterpret_cast<uint4*>(buf) + (size_t)tid * (KP / 8);
-    uint4* wlo = reinterpret_cast<uint4*>(buf + RC_K * KP * 2) + (size_t)tid * (KP / 8);
+    // 16-byte chunk g of centroid tid sits at [tile = tid / 32][g][tid % 32]: the 64 lanes of a wave that fetch one A fragment
+    // (32 centroids x 2 chunks) read 1 KiB of CONSECUTIVE 16-byte slots — conflict-free for ds_read_b128 (round 5; the row-major
+    // layout [centroid][chunk] put lanes 12-15 and 20-23 of a service group on the same banks: 34 % of the LDS cycles)
+    uint4* whi = reinterpret_cast<uint4*>(buf) + (size_t)(tid >> 5) * (KP / 8) * 32 + (tid & 31);
+    uint4* wlo = reinterpret_cast<uint4*>(buf + RC_K * KP * 2) + (size_t)(tid >> 5) * (KP / 8) * 32 + (tid & 31);
     uint4* cn3 = reinterpret_cast<uint4*>(buf + RC_K * KP * 4);
     float* wmax = reinterpret_cast<float*>(buf + RC_K * KP * 4 + RC_K * 16);
     float nrm = 0.f;
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(256) void assign_prep_kernel(const float* __restric
                 nrm = __builtin_fmaf(v.w, v.w, nrm);
             }
         }
-        whi[g] = make_uint4(h[0], h[1], h[2], h[3]);
-        wlo[g] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        whi[g * 32] = make_uint4(h[0], h[1], h[2], h[3]);
+        wlo[g * 32] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
     {   // ||c||^2 = p0 + p1 + p2 exactly (3 x 8 significant bits); it enters the tile as one more MFMA against ones
         unsigned p01, r01, p2, dummy;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void 
         auto load_a = [&](afrag& A, int kt) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int idx = (kt * 32 + col) * (KP / 8) + 2 * ks + half;
+                const int idx = (kt * (KP / 8) + 2 * ks + half) * 32 + col;      // [tile][chunk][centroid in tile]
                 A.h[ks] = __builtin_bit_cast(mf_bf16x8, whi[idx]);
                 A.l[ks] = __builtin_bit_cast(mf_bf16x8, wlo[idx]);
             }

@@ -628,6 +628,10 @@ def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Op
     return image
 
 
+SEARCH_SCREEN_M = frozenset((8, 12, 16, 24, 32, 48, 64, 96))      # widths of the screened flat search (csrc/adc_search.hip)
+_warned_slow_m = set()
+
+
 class PendingSearch:
     """A search that has been enqueued but whose status word has not been read yet (`adc_search(..., defer=True)`).
     `result()` synchronises and reads the status.  In the rare case that the sampled threshold admitted too few or too
@@ -735,6 +739,17 @@ def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k:
     if D != M * c.shape[2]:
         raise ValueError("query width does not match the centroid table")
     lib, h, s, dev = _ctx(q)
+    if M not in SEARCH_SCREEN_M and nq and N:
+        # a width without a screening kernel (the reference's IndexPQ takes any M, evaluate_repconc.py:81): the exact scan with a
+        # run-time width answers — correct and complete, an order of magnitude slower than the screened search
+        global _warned_slow_m
+        if M not in _warned_slow_m:
+            _warned_slow_m.add(M)
+            import logging
+            logging.getLogger(__name__).warning("adc_search: MCQ_M = %d has no screening kernel (%s have); using the exact scan",
+                                                M, sorted(SEARCH_SCREEN_M))
+        got = adc_search_exact(codes, c, q, k, id_offset)
+        return PendingSearch(None, got[0], got[1], None, None, 0.0, 0) if defer else got
     scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
     if nq == 0 or N == 0:

@@ -21,6 +21,15 @@ def test_bench_legs_do_not_shadow_contract_keys():
     assert '"roofline": roofline' in head and 'out["cpu_baseline"]' in src
 
 
+def test_bench_measures_what_survey_8d_asks_for():
+    """SURVEY 8d / VERDICT r4 item 4: a second ADC leg on codes from the index build (with the screen's survivors per query),
+    the `import faiss` probe with the port as fall-back, CPU baselines of kind port / torch / faiss on a first-touched copy."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for needle in ('["index_built_codes"]', "screen_survivors_per_query", "import faiss", '"kind": "torch"', '"kind": "faiss"',
+                   "first_touch_copy", "adc_search(sl, cent, qc, k, tile=0)", "rc_solve_num_chains_on"):
+        assert needle in src, needle
+
+
 def test_bench_has_the_contract_flags():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):

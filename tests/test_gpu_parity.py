@@ -1012,6 +1012,41 @@ def test_c_index_handle_api_matches_oracle():
         assert lib.rc_index_destroy(idx) == 0
 
 
+@pytest.mark.parametrize("M", [128, 6, 1])
+def test_search_at_a_width_without_a_screening_kernel(M):
+    """a model warmed up with MCQ_M = 128, 6 or 1 (the constructor and the training kernels take every divisor of the
+    hidden size, as the reference does: modeling_repconc.py:41) must also evaluate.  The screened search is compiled for
+    eight widths; every other one is answered by the exact scan with a run-time width — through ops.adc_search, PQIndex and the
+    stateful C index alike: ids and score bits of the brute-force oracle."""
+    import ctypes
+    from repconc_amd import _lib, ops
+    from repconc_amd.index import PQIndex
+    N, nq, k = 30011, 5, 40
+    C, codes, q = _adc_case(M, N, nq, seed=4100 + M)
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    gs, gi = ops.adc_search(_t(codes), _t(C), _t(q), k)
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gs.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    index = PQIndex(768, M, device=torch.device(DEV))
+    index.set_centroids(_t(C))
+    index.add_codes(_t(codes[:20000]))
+    index.add_codes(_t(codes[20000:]))
+    ps, pi = index.search(q, k)                                     # numpy in, numpy out (evaluate_repconc.py:182)
+    assert np.array_equal(pi, wi) and np.array_equal(ps.view(np.uint32), ws.view(np.uint32))
+    lib, h = _lib.load(), _lib.handle(0)
+    idx = ctypes.c_void_p()
+    assert lib.rc_index_create(h, 768, M, 256, ctypes.byref(idx)) == 0
+    try:
+        dq, dC, dcodes = _t(q), _t(C), _t(codes)
+        sc = torch.empty((nq, k), dtype=torch.float32, device=DEV)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=DEV)
+        assert lib.rc_index_set_centroids(idx, dC.data_ptr(), None) == 0
+        assert lib.rc_index_add_codes(idx, dcodes.data_ptr(), N, None) == 0
+        assert lib.rc_index_search(idx, dq.data_ptr(), nq, k, sc.data_ptr(), ids.data_ptr(), None) == 0
+        assert np.array_equal(ids.cpu().numpy(), wi) and np.array_equal(sc.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    finally:
+        assert lib.rc_index_destroy(idx) == 0
+
+
 def test_index_build_scale_properties():
     """Index-build path at scale (2 M x 768, M = 48, a quarter of the BASELINE corpus per pass): the MFMA-screened codes
     equal the exact-order kernel's, and coding is idempotent — re-assigning decode(codes) returns the same codes
