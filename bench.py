@@ -224,10 +224,25 @@ def main():
         elif os.environ.get("RC_COMM", "auto").lower() in ("ipc", "rccl"):
             candidates = [os.environ["RC_COMM"].lower()]
         else:
-            candidates = ["ipc"] if share_gpu else ["ipc", "rccl"]     # RCCL refuses two ranks on one device
+            # "ipc" = the exchange fused into the sweep kernels (round 5: peer stores from the sweep's reducer, the wait in the next
+            # sweep's prologue); "ipc-kernels" = the same transport with the push + wait kernels of rounds 3-4 (RC_IPC_XSWEEP=0),
+            # tried only when the fused form does not pass on this node; RCCL refuses two ranks on one device
+            candidates = ["ipc", "ipc-kernels"] if share_gpu else ["ipc", "ipc-kernels", "rccl"]
         os.environ["RC_COMM_STRICT"] = "1"                  # "ipc" means ipc here: no silent fall-back inside comm_init
         import subprocess
-        for ti, transport in enumerate(candidates):
+        XSWEEP_ENV = os.environ.get("RC_IPC_XSWEEP")
+
+        def transport_env(label):
+            """(RC_COMM value, RC_IPC_XSWEEP value or None) of a candidate"""
+            return ("ipc", "0") if label == "ipc-kernels" else (label, XSWEEP_ENV)
+        for ti, label in enumerate(candidates):
+            if label == "ipc-kernels" and "ipc" in measured:
+                continue                                     # the fused form works here: nothing to fall back from
+            transport, xs = transport_env(label)
+            if xs is None:
+                os.environ.pop("RC_IPC_XSWEEP", None)
+            else:
+                os.environ["RC_IPC_XSWEEP"] = xs
             # the probe's exchange waits give up after 8 s (RC_FLAG_COMM), the probe itself after 150 s: a transport that does
             # not work on this node costs minutes at most, never the run
             env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 17 + ti), RC_COMM=transport,
@@ -242,7 +257,7 @@ def main():
                 child.wait()
                 prc = -9
             if not all_ranks(prc == 0):
-                notes[transport] = f"out-of-process probe failed (exit {prc} on this rank)"
+                notes[label] = f"out-of-process probe failed (exit {prc} on this rank)"
                 continue
             os.environ["RC_DIST_NATIVE"], os.environ["RC_COMM"] = "1", transport
             ok, why = True, ""
@@ -254,7 +269,7 @@ def main():
             except Exception as e:                           # transport set-up failure: reported, not hidden
                 ok, why = False, f"{type(e).__name__}: {e}"
             if not all_ranks(ok):
-                notes[transport] = why or "failed on another rank"
+                notes[label] = why or "failed on another rank"
                 try:
                     ops.comm_destroy()
                 except Exception:
@@ -292,7 +307,7 @@ def main():
                 by_chains[split] = max_over_ranks(time.perf_counter() - tt0) * 1e3 / 3
             split_best = min(by_chains, key=lambda k: by_chains[k])
             ms_step = by_chains[split_best]
-            measured[transport] = {"us_per_allgather": round(us_ag, 2), "ms_per_step": round(ms_step, 3),
+            measured[label] = {"us_per_allgather": round(us_ag, 2), "ms_per_step": round(ms_step, 3),
                                    "us_per_iteration": round(ms_step * 1e3 / ITERS, 2),
                                    "chains": 2 if split_best == "1" else 1,
                                    "ms_per_step_two_chains": round(by_chains["1"], 3),
@@ -305,7 +320,12 @@ def main():
                 pass
         if measured:                                         # the faster one runs the timed region (same choice on every rank:
             chosen = min(measured, key=lambda t: measured[t]["ms_per_step"])     # ms_per_step is a max over ranks)
-            os.environ["RC_DIST_NATIVE"], os.environ["RC_COMM"] = "1", chosen
+            c_transport, c_xs = transport_env(chosen)
+            os.environ["RC_DIST_NATIVE"], os.environ["RC_COMM"] = "1", c_transport
+            if c_xs is None:
+                os.environ.pop("RC_IPC_XSWEEP", None)
+            else:
+                os.environ["RC_IPC_XSWEEP"] = c_xs
             os.environ["RC_DIST_SPLIT"] = "1" if measured[chosen]["chains"] == 2 else "0"
         native_all = chosen is not None
         os.environ["RC_DIST_NATIVE"] = "1" if native_all else "0"
@@ -891,8 +911,9 @@ def main():
             torch.cuda.synchronize()
             kg = e0.elapsed_time(e1) / 10 * 1e-3
             ks_sizes[rows] = {"rows": rows, "ms": round(kg * 1e3, 4), "value": round(rows / kg, 1), "unit": "vectors/s",
-                              "roofline": {"kernel": "kmeans_stats_fx_kernel<0, 8> (integer split of the fp32 bits, 64-bit LDS "
-                                                     "accumulators, plain per-strip partials; the whole rc_kmeans_stats call is timed)",
+                              "roofline": {"kernel": "kmeans_stats_px_kernel<0> (+ <1>: the finish, <2>: the idle repeat pass; integer split of "
+                                                     "the fp32 bits, 64-bit LDS accumulators, 128-byte row pieces; the whole "
+                                                     "rc_kmeans_stats call is timed)",
                                            "bound": "hbm", "achieved": round(rows * (D * 4 + M) / kg / 1e9, 1),
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": round(rows * (D * 4 + M) / kg / 1e9 / HBM_PEAK_GBS, 4),

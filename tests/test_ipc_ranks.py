@@ -120,7 +120,7 @@ def test_bench_gpus2_typed_as_is_on_a_shared_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0
     chk = d["multi_gpu_check"]
-    assert chk["sharded_equals_unsharded"] is True and chk["transport"] in ("ipc", "rccl") and chk["native_equals_staged"] is True
+    assert chk["sharded_equals_unsharded"] is True and chk["transport"] in ("ipc", "ipc-kernels", "rccl") and chk["native_equals_staged"] is True
     assert d["exchange"]["us_per_allgather"] > 0
 
 

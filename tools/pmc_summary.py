@@ -16,14 +16,14 @@ ALG = {  # SURVEY 8(d) per-unit bytes x units per launch
     "sk_sweep_kernel": ("sk_sweep2_kernel<2, true>", B * M * K * 4),
     "adc_screen_q16_kernel": ("adc_screen_q16_kernel<48>", NQ * NC * M),
     "assign_mfma_kernel": ("assign_mfma_kernel<16>", NB * (768 * 4 + M)),
-    "kmeans_stats_fx_kernel": ("kmeans_stats_fx_kernel<0, 8>", NB * (768 * 4 + M)),   # 2^20-row launches only (kmeans_raw.json)
+    "kmeans_stats_kernel": ("kmeans_stats_px_kernel<0>", NB * (768 * 4 + M)),   # launch A, 2^20-row launches only (kmeans_raw.json)
 }
 out = {"_how": "tools/pmc_collect.sh: rocprofv3 --pmc <group> --kernel-trace, one pass per counter group, over "
                "`python bench.py --steps 1 --warmup 1 --no-cpu --no-per-rank --no-opq --adc-batches 1`; means per launch. FETCH_SIZE/WRITE_SIZE are "
                "KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md. " + note}
 for key, (kname, alg) in ALG.items():
     src = raw
-    if key == "kmeans_stats_fx_kernel":
+    if key == "kmeans_stats_kernel":
         if km_raw is None:
             continue                                       # no size-pure counters: no row (a mixed mean is worse than none)
         src = km_raw
