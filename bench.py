@@ -528,16 +528,16 @@ def main():
                          "frac": round(lds_ach / lds_peak, 4), "lds_bytes_per_launch": lds_bytes,
                          "avg_launch_ms": round(scan_ms, 3), "launches_timed": n_l.value,
                          "measured_gather_roof": {
-                             "lds_alone_cycles_per_b128_gather_per_cu": 4.05, "with_screen_address_and_mfma_cycles": 5.55,
-                             "note": "tools/ubench_lds_gather.hip, round 3 (profiles/r03a_ubench_lds_gather.txt; whole-launch "
-                                     "timing at a measured 2.3-2.4 GHz - the round-2 table timed wave 0 only and was wrong): "
-                                     "random conflict-free ds_read_b128 gathers with precomputed addresses run at 4.05 "
-                                     "cycles per wave-instruction per CU = 253 B/clk = the nominal roof used in `frac`; with "
-                                     "the screen's two address instructions and one i8 MFMA per gather the same loop needs "
-                                     "5.55 cycles (instruction issue, not the LDS array); the kernel itself runs at ~12 per "
-                                     "gather: a timing experiment without the phase-change barrier (wrong results) ran at "
-                                     "3.6 ms per launch against 9.1 ms - the synchronised table hand-over between the two "
-                                     "LDS buffers is what is left (DESIGN.md 4.3)"},
+                             "lds_alone_cycles_per_b128_gather_per_cu": 4.05, "with_one_instruction_address_and_mfma_cycles": 4.79,
+                             "matrix_pipe_cycles_per_gather_per_cu": 4.0,
+                             "note": "tools/ubench_lds_gather.hip (profiles/r03a_ubench_lds_gather.txt, r05a_ubench_lds_gather_perm.txt; "
+                                     "not this run): random conflict-free ds_read_b128 gathers with precomputed addresses run at "
+                                     "4.05 cycles per wave-instruction per CU = 253 B/clk = the nominal roof used in `frac`; with "
+                                     "the screen's one-instruction (v_perm_b32) address and one i8 MFMA per gather 4.79; a "
+                                     "v_mfma_i32_16x16x64_i8 occupies a SIMD's matrix unit for 16 cycles = 4.0 per gather per CU, "
+                                     "so LDS and matrix pipe saturate together at the ideal; the kernel itself runs at ~10 "
+                                     "(M = 32, table phases resident: 7.8): phase barrier 11 %, refill traffic 6 % "
+                                     "(DESIGN.md 4.6, 9.2)"},
                          "hbm_equivalent": {"algorithmic_bytes_per_launch": adc_alg, "achieved_GBs": round(adc_ach, 1),
                                             "note": "N*M code bytes per query (SURVEY 8d) / kernel time: 8 queries share every "
                                                     "code read and tiles are re-read from L2, so this exceeds the HBM peak and is "
@@ -749,7 +749,7 @@ def main():
                          "note": "nprobe = 128, the screen kernel alone (HIP events): one table byte per (probed row, "
                                  "sub-quantiser, query) - an 8-byte entry per task of 8 queries - against the nominal "
                                  "conflict-free ds_read_b64 rate (256 CUs x 256 B/clk x 2.4 GHz).  The 8-query gather engine "
-                                 "itself runs at ~6 cycles per gather (issue/latency, DESIGN 4.2), i.e. 1/3 of that rate; a task "
+                                 "itself runs at ~6 cycles per gather (issue/latency, DESIGN_HISTORY 4.2), i.e. 1/3 of that rate; a task "
                                  "also moves 192 KiB of tables (3.8 GB per 1200-query batch from the memory-side cache) and the "
                                  "sixteen waves of a block meet at one barrier per table phase",
                          "whole_search_equivalent_code_GBs": round(nq_batch * rows128 * M3 / t128 / 1e9, 1)}}
@@ -791,7 +791,7 @@ def main():
                          "note": "far from the HBM roof by construction: 256 candidate distances per (row, sub-quantiser), "
                                  "2.25 VALU instructions each in the pair-folded min/second-min epilogue, the bf16 MFMAs "
                                  "underneath; after round 2 neither pipe is saturated (VALU ~64 %, matrix pipe ~37 %, waves "
-                                 "wait on LDS operand reads and the per-sub-quantiser barrier; DESIGN.md §3.4)"},
+                                 "wait on LDS operand reads and the per-sub-quantiser barrier; DESIGN.md §4.4, §9.4)"},
         }
         del xb
 

@@ -543,7 +543,7 @@ bool want_inwait(rc_handle_t h) {
 }
 // One chain or two (RC_DIST_SPLIT overrides).  A rule every rank evaluates identically (world, transport): two chains exist
 // to hide a collective behind the other chain's sweep and cost 18-20 us per iteration on their own (twice the per-block
-// prologue and hand-over); with the exchange fused into the sweep there is no collective launch left to hide, so
+// prologue and hand-over, DESIGN_HISTORY 9.15); with the exchange fused into the sweep there is no collective launch left to hide, so
 // the IPC transport runs ONE chain at every batch size; RCCL (a ~20-30 us collective per iteration) keeps two.  On one GPU the
 // split buys nothing on top of the rotating wave priority of the sweep (round 4) and makes per-launch timings overlap.
 bool want_split(rc_handle_t h, int world) {

@@ -886,7 +886,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     RC_LAUNCH_CHECK(h);
     RC_HIP_CHECK(h, hipMemsetAsync(w + L.idcnt, 0, L.counters_end - L.idcnt, s));      // idcnt, cnt, stream_cnt
     {
-        auto kern = ivfs_screen_kernel<M, 4>;                 // four loader waves (without them 1.04 vs 0.95 ms at nprobe 128)
+        auto kern = ivfs_screen_kernel<M, 4>;                 // four loader waves (DESIGN_HISTORY 7: without them 1.04 vs 0.95 ms at nprobe 128)
         constexpr int sl = 2 * IVFS_BUF;
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
         adc_ivf_tasks TT = T;

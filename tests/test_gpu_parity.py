@@ -682,7 +682,7 @@ def test_faiss_indexpq_file_round_trip(tmp_path):
                                       (64, 262144, 4, 50), (24, 500000, 11, 200), (12, 262145, 2, 1)])
 def test_adc_integer_screening_path_is_exact(M, N, nq, k):
     """N >= 2^18 takes the 8-bit screening + exact rescoring path; ids and score bits must still equal the
-    brute-force oracle (the integer threshold is a rigorous bound, DESIGN.md §4)."""
+    brute-force oracle (the integer threshold is a rigorous bound, DESIGN.md §4.6)."""
     from repconc_amd import ops
     C, codes, q = _adc_case(M, N, nq, seed=M * 7 + N)
     codes[N // 2: N // 2 + 300] = codes[:300]          # duplicated rows: ties across the candidate boundary
@@ -1415,7 +1415,7 @@ def test_native_rccl_collectives_inside_the_graph_single_rank(monkeypatch):
 
 
 def test_fused_exchange_on_a_one_rank_ipc_transport(monkeypatch):
-    """RC_DIST_FORCE_COLL=1 on a one-rank IPC transport (the proxy bench.py and DESIGN 9.15 time): every iteration's exchange
+    """RC_DIST_FORCE_COLL=1 on a one-rank IPC transport (the proxy bench.py and DESIGN.md §5 time): every iteration's exchange
     runs — the sweep's reducer stores the row sums and the flags into the rank's OWN receive buffer, the next sweep's prologue
     waits for them (no peer shares the device, so the wait is inside the sweep) — eager, captured, replayed, one chain and two,
     and the round-3/4 push + wait kernels; golden codes every time, at a fixture and at the per-rank shape of the 8-GPU recipe."""

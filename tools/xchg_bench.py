@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-rank shape of the 8-GPU recipe (6 144 x 768, M = 48) on ONE GPU with the exchange of every iteration forced
-(RC_DIST_FORCE_COLL=1 on a one-rank IPC transport: the rank pushes to and waits for itself) — the proxy of DESIGN 9.15 /
+(RC_DIST_FORCE_COLL=1 on a one-rank IPC transport: the rank pushes to and waits for itself) — the proxy of DESIGN.md §5 /
 VERDICT r4 item 1.  ms per step (100 iterations), best of 3 x 20 steps, for every form of the exchange, next to the
 stand-alone solve without any exchange.
 
