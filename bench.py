@@ -341,7 +341,8 @@ def main():
                       "transport": chosen, "native_equals_staged": native_all if candidates else None,
                       "transport_notes": notes or None, "sharded_equals_unsharded": unsharded_equal}
         if native_all:
-            exchange = {"transport": chosen, "chains": measured[chosen]["chains"], "bytes_per_rank": (M // 2) * K * 8,
+            exchange = {"transport": chosen, "chains": measured[chosen]["chains"],
+                        "bytes_per_rank": (M // measured[chosen]["chains"]) * K * 8,
                         "us_per_allgather": measured[chosen]["us_per_allgather"],
                         "per_transport": measured,
                         "what": "per transport that passed the probe and reproduced the staged codes: 200 back-to-back "
