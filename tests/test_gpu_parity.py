@@ -1964,6 +1964,47 @@ def test_ivf_list_centric_search_equals_per_query_scan(M):
         assert torch.equal(i3, i2) and torch.equal(s3, s2), (M, nprobe)
 
 
+def test_batch_search_hands_a_list_centric_index_every_query_at_once():
+    """evaluate_repconc.py:188-206 with an IVF index (round 5): `batch_search` passes the WHOLE query set in one call
+    (`IVFPQIndex.whole_query_set`; `index.nprobe` is Faiss's attribute) — the answer is the per-batch one, and the oracle's."""
+    from repconc_amd.ivf import IVFPQIndex
+    from repconc_amd.models.repconc.evaluate_repconc import batch_search
+    M, N, nlist, nq, k = 48, 300000, 97, 301, 20
+    rng = np.random.default_rng(811)
+    codes = synth.uniform_codes(812, N, M)
+    cells = rng.integers(0, nlist, N)
+    C = synth.gaussian(813, (M, 256, 16))
+    coarse = synth.gaussian(814, (nlist, 768))
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(C)
+    ivf.coarse = _t(coarse)
+    ivf.set_lists(_t(codes), _t(cells))
+    ivf.nprobe = 11
+    q = synth.gaussian(815, (nq, 768))
+    corpus_ids = np.arange(N, dtype=np.int64) * 3 + 7
+    qids = np.arange(nq)
+    sc, ids = batch_search(qids, q, corpus_ids, ivf, k, batch_size=64)
+    parts = [ivf.search(q[a:a + 64], k) for a in range(0, nq, 64)]
+    assert np.array_equal(sc.view(np.uint32), np.concatenate([p_[0] for p_ in parts]).view(np.uint32))
+    assert np.array_equal(ids, corpus_ids[np.concatenate([p_[1] for p_ in parts])])
+    ws, wi = pq_oracle.ivf_search(q[:16], C, codes, cells, coarse, k, 11)
+    assert np.array_equal(ids[:16], corpus_ids[wi]) and np.array_equal(sc[:16].view(np.uint32), ws.view(np.uint32))
+
+
+def test_search_reports_the_screens_survivor_counts():
+    """ops.adc_search(stats=...) (rc_adc_search_ws_counts; bench.py prints them per SURVEY 8d-D): per query, rows that passed the
+    8-bit screen >= rows the exact rescoring kept >= k, and far fewer than the index holds."""
+    from repconc_amd import ops
+    M, N, nq, k = 48, 400000, 33, 100
+    C, codes, q = _adc_case(M, N, nq, seed=5151)
+    st = {}
+    s, i = ops.adc_search(_t(codes), _t(C), _t(q), k, stats=st)
+    ws, wi = c_oracle.adc_search(codes, C, q, k)
+    assert np.array_equal(i.cpu().numpy(), wi)
+    surv, cand = st["survivors"].cpu().numpy(), st["candidates"].cpu().numpy()
+    assert surv.shape == (nq,) and (surv >= cand).all() and (cand >= k).all() and surv.max() < N // 20
+
+
 @pytest.mark.parametrize("graph", ["0", "1"])
 def test_opq_training_repeats_with_checked_procrustes_when_a_deferred_check_fails(monkeypatch, graph):
     """train_opq reads the orthogonality checks of all rounds once, after the last; if one is not below 1e-9 (here: forced in
