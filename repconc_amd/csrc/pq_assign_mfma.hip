@@ -127,7 +127,12 @@ template <int DSUB>
 struct mf_geom {
     static constexpr int KP = (DSUB + 15) / 16 * 16;     // reduction length padded to the MFMA's 16
     static constexpr int KS = KP / 16;                   // MFMA k-steps
-    static constexpr int NBUF = (DSUB <= 32) ? 2 : 1;    // LDS centroid buffers
+    // LDS centroid buffers.  Rounds 2-4 double-buffered the narrow widths (the next sub-quantiser's centroids arrived by LDS-DMA
+    // during the tile loop).  Round 5 measured the single buffer — barrier, DMA, wait, barrier between two sub-quantisers, the
+    // other two blocks of the CU computing meanwhile — FASTER for every width: ms per 2^20 rows, M = 48 / 96 / 64 / 32 / 24:
+    // 2.19 -> 1.97, 4.42 -> 4.17, 3.17 -> 2.79, 3.08 -> 2.67, 1.99 -> 1.87 (the DMA's LDS writes no longer compete with the
+    // A-fragment reads of the loop, and a block needs 32 KiB instead of 52).
+    static constexpr int NBUF = 1;
     static constexpr int BUF_BYTES = RC_K * KP * 2 * 2 + RC_K * 16 + 32;  // hi | lo | cn pieces | wave maxima
 };
 
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(256) void assign_prep_kernel(const float* __restric
 // maxima[8] } | code tile [256][M].
 // NBUF = 2: sub-quantiser m+1's centroids are fetched into registers before the tile loop of m and written to the other
 // buffer after it, so one barrier per m and no exposed L2 latency.
+// (four waves per SIMD — __launch_bounds__(256, 4) — spills 120-144 bytes per lane at 128 VGPRs: 3.0-3.1 ms against 2.2, round 5)
 template <int DSUB>
 __global__ __launch_bounds__(256, (DSUB <= 16 ? 3 : (DSUB <= 32 ? 2 : 1))) void assign_mfma_kernel(const float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ C, int64_t B, int M,
