@@ -208,13 +208,17 @@ class ReplicatedIVFPQIndex:
             same = index.device.index == d and not any(p is index for p in self.parts)
             self.parts.append(index if same else index.to(torch.device("cuda", d)))
         self.device, self.d, self.M, self.nlist = index.device, index.d, index.M, index.nlist
+        self.nprobe = getattr(index, "nprobe", 8)         # Faiss's attribute: cells probed when search() is not told
+        self.whole_query_set = True                       # batch_search: every query in one call (each replica takes its slice)
         self._pool = ThreadPoolExecutor(max_workers=len(self.parts))
 
     @property
     def ntotal(self):
         return self.parts[0].ntotal
 
-    def search(self, x, k: int, nprobe: int, method: str = "auto"):
+    def search(self, x, k: int, nprobe: Optional[int] = None, method: str = "auto"):
+        if nprobe is None:
+            nprobe = self.nprobe
         as_numpy = not isinstance(x, torch.Tensor)
         q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if as_numpy else x.float()
         nq, G = q.shape[0], len(self.parts)
