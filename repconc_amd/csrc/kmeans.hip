@@ -102,12 +102,13 @@ __global__ __launch_bounds__(256) void kmeans_stats_reduce_kernel(const double* 
 // the previous call + one bit), every block tracks max|x| and inexact splits while it works, and the (normally idle,
 // device-gated) second pass repeats the work with the tight bound of THIS data when the hint was exceeded or a part had
 // to be rounded.  The answer is a pure function of the data either way.
-// Non-finite input (max|x| = inf / NaN) takes the strip kernels, which propagate it as the reference would.
+// (Rounds 3-4 sent non-finite input through the strip kernels; round 5 keeps it on this path, see below.  The strip kernels
+// remain for rows that are not float4-addressable, widths that are not multiples of 4, and 2^24 rows or more per call.)
 #define KM_FX_LO_BITS 38
 #define KM_FX_U 4                                       // rows in flight per thread
 #define KM_FX_EB0 4                                     // first hint of a handle: |x| < 16
 //
-// Round 5 (0.34 of the roof at M = 64 at every size; six launches per call, four of them idle):
+// Round 5 (0.34 of the roof at M = 64 at every size; seven launches per call, four of them idle):
 //  * a block's share of a row is a PIECE of 32 consecutive floats at a 128-byte boundary whatever the sub-vector width — whole
 //    cache lines for every M (dsub = 12 / 24 / 48 used to give 96- or 64-byte pieces: each line fetched by two blocks); lane q of
 //    a piece (one float4) belongs to sub-quantiser (32 p + 4 q) / dsub and adds into the LDS accumulators of ITS code;
