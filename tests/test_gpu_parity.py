@@ -1453,6 +1453,18 @@ def test_fused_exchange_on_a_one_rank_ipc_transport(monkeypatch):
             if want6 is None:
                 want6, _ = c_oracle.quantize(x6, C6, True, EPS, ITERS)
             assert int(flags.item()) == 0 and np.array_equal(codes.cpu().numpy(), want6), (xsweep, inwait, split)
+        # a chain moves [M, 256] fp64 through a 256 KiB slot — MCQ_M = 192 in ONE chain is refused before anything is
+        # enqueued (with the way out in the message); as two chains of 96 it runs and gives the oracle's codes
+        xw = synth.clustered_embeddings(4250, 1024)
+        Cw = synth.sample_centroids(4251, xw, 192)
+        monkeypatch.setenv("RC_IPC_XSWEEP", "1")
+        monkeypatch.setenv("RC_IPC_INWAIT", "1")
+        monkeypatch.setenv("RC_DIST_SPLIT", "0")
+        with pytest.raises(_lib.RepconcHipError, match="RC_COMM=rccl"):
+            ops.assign_sinkhorn_dist(_t(xw), _t(Cw), EPS, ITERS, torch.uint8)
+        monkeypatch.setenv("RC_DIST_SPLIT", "1")
+        codes, flags = ops.assign_sinkhorn_dist(_t(xw), _t(Cw), EPS, ITERS, torch.uint8)
+        assert int(flags.item()) == 0 and np.array_equal(codes.cpu().numpy(), c_oracle.quantize(xw, Cw, True, EPS, ITERS)[0])
         ops.comm_check()
     finally:
         try:
