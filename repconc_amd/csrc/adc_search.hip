@@ -892,6 +892,7 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     adc_i32x4v acc[PACK ? 1 : R];
     unsigned accp[PACK ? R : 1][2];                           // PACK: (acc0 | acc1 << 16), (acc2 | acc3 << 16)
     int buf = 0;
+    int held[2] = {phase_of(0), -1};                         // block-uniform: the phase each table buffer holds (or is being sent)
     // per-wave survivor list in LDS: entries (row in tile << 4 | query column); flushed to the per-query id lists (one
     // global atomic per entry, all of a flush in flight together) when 64 more might not fit, and at the end
     constexpr int SCAP = ADC_Q16_SCAP;
@@ -939,8 +940,15 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             buf ^= 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) offb[j] = off[j] + (unsigned)buf * (unsigned)BUF;
+            // the buffer just vacated gets the table of the segment after this one - unless it still holds it: with the phases
+            // visited 0 .. P-1 | P-1 .. 0 | ... the segment before and the segment after a turning point are the same phase
+            // (M = 48: every other segment is phase 1 and phase 1 never leaves buffer 1: one 64 KiB refill per round instead of
+            // two).  The refill's LDS writes compete with the gathers: 8.2 -> 7.8 ms per 1200 queries at M = 48.
             const int nx = next_change(it);
-            if (nx < nsteps) stage(phase_of(nx), buf ^ 1);   // the buffer just vacated
+            if (nx < nsteps && phase_of(nx) != held[buf ^ 1]) {
+                stage(phase_of(nx), buf ^ 1);
+                held[buf ^ 1] = phase_of(nx);
+            }
             }
         }
         if (it + 1 < nsteps) load_step(it + 1, wn);
@@ -1049,7 +1057,10 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     __syncthreads();
     if constexpr (NPH > 2) {
         const int nx = next_change(0);
-        if (nx < nsteps) stage(phase_of(nx), 1);
+        if (nx < nsteps) {
+            stage(phase_of(nx), 1);
+            held[1] = phase_of(nx);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) offb[j] = off[j];
