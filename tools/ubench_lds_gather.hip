@@ -197,6 +197,23 @@ int main(int argc, char** argv) {
         run<24, 0, true, 1024>("b64 cf 24 + 12 MFMA", 256);
         return 0;
     }
+    if (argc > 2 && !strcmp(argv[2], "depth")) {             // round 5: gathers in flight per wave x waves per CU (one-instruction address + MFMA)
+        run<4, 2, true, 1024, 2>("b128 cf 4 + 4 MFMA", 256);
+        run<8, 2, true, 1024, 2>("b128 cf 8 + 8 MFMA", 256);
+        run<12, 2, true, 1024, 2>("b128 cf 12 + 12 MFMA", 256);
+        run<16, 2, true, 1024, 2>("b128 cf 16 + 16 MFMA", 256);
+        run<4, 2, true, 768, 2>("b128 cf 4 + 4 MFMA", 256);
+        run<8, 2, true, 768, 2>("b128 cf 8 + 8 MFMA", 256);
+        run<12, 2, true, 768, 2>("b128 cf 12 + 12 MFMA", 256);
+        run<16, 2, true, 768, 2>("b128 cf 16 + 16 MFMA", 256);
+        run<4, 2, true, 512, 2>("b128 cf 4 + 4 MFMA", 256);
+        run<8, 2, true, 512, 2>("b128 cf 8 + 8 MFMA", 256);
+        run<12, 2, true, 512, 2>("b128 cf 12 + 12 MFMA", 256);
+        run<16, 2, true, 512, 2>("b128 cf 16 + 16 MFMA", 256);
+        run<8, 2, false, 1024, 2>("b128 cf 8, no MFMA", 256);
+        run<4, 2, false, 1024, 2>("b128 cf 4, no MFMA", 256);
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "b96")) {               // the question of the 12-query single-phase screen only
         run<12, 2, true, 1024>("b128 conflict-free 12 + 12 MFMA", 256);
         run<12, 3, false, 1024>("b96 dense rows, random codes 12", 256);
