@@ -536,9 +536,9 @@ def main():
                                      "4.05 cycles per wave-instruction per CU = 253 B/clk = the nominal roof used in `frac`; with "
                                      "the screen's one-instruction (v_perm_b32) address and one i8 MFMA per gather 4.79; a "
                                      "v_mfma_i32_16x16x64_i8 occupies a SIMD's matrix unit for 16 cycles = 4.0 per gather per CU, "
-                                     "so LDS and matrix pipe saturate together at the ideal; the kernel itself runs at ~9.8 "
+                                     "so LDS and matrix pipe saturate together at the ideal; the kernel itself runs at ~9.4 "
                                      "(M = 32, table phases resident: 7.9); on an index with identical table phases the M = 48 "
-                                     "kernel without barriers and refills takes 6.9 ms against 7.96: the hand-over is 14 % "
+                                     "kernel without barriers and refills took 6.9 ms against 7.96 (7.6 since the rolling code loads) "
                                      "(profiles/r05p_adc_phase_change.txt, DESIGN.md 4.6, 9.2)"},
                          "hbm_equivalent": {"algorithmic_bytes_per_launch": adc_alg, "achieved_GBs": round(adc_ach, 1),
                                             "note": "N*M code bytes per query (SURVEY 8d) / kernel time: 8 queries share every "
