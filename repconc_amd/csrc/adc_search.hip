@@ -942,7 +942,11 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             // my pieces have landed: everything but the last step's NV code loads, which are younger (round 5: vmcnt(0) also
             // waited for those)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");
-            __syncthreads();                                 // everybody's have, and everybody is done with the old buffer
+            // everybody's have, and everybody is done with the old buffer (every LDS read of the step has returned: its last
+            // gather_wait is lgkmcnt(0)).  The bare instruction: __syncthreads() is fence + barrier, and the fence is
+            // s_waitcnt vmcnt(0) — it would wait for the code loads issued a few chunks ago after all (M = 64 / 96: -1 %).
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             buf ^= 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) offb[j] = off[j] + (unsigned)buf * (unsigned)BUF;
