@@ -43,14 +43,14 @@ def load_case(name):
     return g, x, C
 
 
-def load_headline(kind):
-    """tests/golden/headline_b49152_m48_<kind>.npz (oracle/gen_golden.py --headline): the REFERENCE's codes of one whole
-    49 152 x 768 training batch at M = 48 (BASELINE configs[1]), run as four column slices of twelve sub-quantisers.
-    Returns (x, C, constrained codes, nearest codes)."""
+def load_headline(kind, M=48):
+    """tests/golden/headline_b49152_m<M>_<kind>.npz (oracle/gen_golden.py --headline [--headline-m M]): the REFERENCE's codes
+    of one whole 49 152 x 768 training batch at M = 48 (BASELINE configs[1]) or M = 24 (c5), run as four column slices of
+    192 columns.  Returns (x, C, constrained codes, nearest codes)."""
     import zlib
     import numpy as np
     from oracle import synth
-    g = np.load(os.path.join(GOLDEN, f"headline_b49152_m48_{kind}.npz"))
+    g = np.load(os.path.join(GOLDEN, f"headline_b49152_m{M}_{kind}.npz"))
     B, M = int(g["B"]), int(g["M"])
     x = synth.clustered_embeddings(int(g["x_seed"]), B, n_clusters=int(g["n_clusters"]))
     C = g["centroids"] if "centroids" in g.files else synth.sample_centroids(int(g["c_seed"]), x, M)

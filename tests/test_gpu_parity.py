@@ -1231,6 +1231,21 @@ def test_full_training_batch_against_the_oracle_49152_m48(kind):
     assert np.array_equal(near, c_oracle.quantize(x, C, False)[0])
 
 
+@pytest.mark.parametrize("M", [24, 96])
+def test_full_training_batch_other_widths_against_the_reference(M):
+    """BASELINE c5 / c4 (49 152 x 768 at M = 24, dsub 32, and M = 96, dsub 8) pinned to the REFERENCE like the headline:
+    tests/golden/headline_b49152_m<M>_sample.npz = RepCONC.quantize of /root/reference on four column slices of 192 columns
+    (oracle/gen_golden.py --headline sample --headline-m M).  Every constrained and every nearest code of the HIP path."""
+    from conftest import load_headline
+    from repconc_amd import ops
+    x, C, con, near = load_headline("sample", M)
+    xt, Ct = _t(x), _t(C)
+    got, flags = ops.assign_sinkhorn(xt, Ct, EPS, ITERS, torch.uint8)
+    assert int(flags.item()) == 0
+    assert int((got.cpu().numpy() != con).sum()) == 0
+    assert np.array_equal(ops.assign_nearest(xt, Ct, torch.uint8).cpu().numpy(), near)
+
+
 def test_per_rank_shape_6144_against_the_oracle():
     """BASELINE configs[2] per-rank shape (6144 x 768, M = 48) as a stand-alone batch vs the oracle, default sweep and
     the register-potential variant (the grid of this shape is the one the 8-GPU recipe runs per rank)."""

@@ -51,6 +51,20 @@ def test_c_oracle_on_the_headline_batch_equals_the_reference(kind, m0):
     assert np.array_equal(c_oracle.quantize(xs, Cs, False)[0], near[:, m0:m0 + 4])
 
 
+@pytest.mark.parametrize("M,m0,nm", [(24, 11, 2), (96, 70, 4)])
+def test_c_oracle_on_the_other_full_batches_equals_the_reference(M, m0, nm):
+    """BASELINE c5 / c4 (49 152 x 768, M = 24 / 96) as the reference computed them (gen_golden.py --headline sample
+    --headline-m M): the C restatement on a few sub-quantisers (dsub 32 / 8), constrained and nearest."""
+    from conftest import load_headline
+    x, C, con, near = load_headline("sample", M)
+    ds = 768 // M
+    xs = np.ascontiguousarray(x[:, m0 * ds:(m0 + nm) * ds])
+    Cs = np.ascontiguousarray(C[m0:m0 + nm])
+    got, fl = c_oracle.quantize(xs, Cs, True, EPS, ITERS)
+    assert fl == 0 and np.array_equal(got, con[:, m0:m0 + nm])
+    assert np.array_equal(c_oracle.quantize(xs, Cs, False)[0], near[:, m0:m0 + nm])
+
+
 @pytest.mark.parametrize("name", ["m48_b1024_sample", "m8_b2048_sample", "m96_b512_blend", "m48_b1000_ragged"])
 def test_torch_port_matches_reference(name):
     """oracle/torch_port.py — bench.py's torch-CPU baseline (the reference's algorithmic shape on the host's
