@@ -330,7 +330,7 @@ def test_quantize_logs_and_returns_when_the_solve_flags_a_range_problem(caplog):
     assert any("nan/inf" in r.getMessage() for r in caplog.records)
 
 
-def test_config0_exact_shape_10000_m8_against_the_oracle():
+def test_config0_exact_shape_10000_m8_against_the_oracle_and_the_reference():
     """BASELINE configs[0] at its exact shape: x [10 000, 768] seed 20220, M = 8, centroids = rows of x at
     rng(20221).permutation(N)[:256], ONE batch of 10 000 rows, eps 0.003, 100 iterations — constrained and nearest codes
     against the C oracle."""
@@ -345,6 +345,11 @@ def test_config0_exact_shape_10000_m8_against_the_oracle():
     assert np.array_equal(near.cpu().numpy(), c_oracle.quantize(x, C, False)[0])
     hist = np.bincount(got.cpu().numpy()[:, 0], minlength=256)
     assert 30 <= hist.min() and hist.max() <= 48              # 35 .. 43 around the ideal 39.06
+    # ... and against the REFERENCE itself on these inputs (oracle/gen_golden.py --config0)
+    import zlib
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "config0_b10000_m8.npz"))
+    assert zlib.crc32(x.tobytes()) == int(g["x_crc"]) and zlib.crc32(C.tobytes()) == int(g["centroids_crc"])
+    assert np.array_equal(got.cpu().numpy(), g["codes_constrained"]) and np.array_equal(near.cpu().numpy(), g["codes_nearest"])
 
 
 def test_adc_large_index_properties():

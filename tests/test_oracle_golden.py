@@ -1,5 +1,6 @@
 """The oracle pinned against the reference's outputs (tests/golden, made by oracle/gen_golden.py).
 CPU only.  numpy restatement on the small cases, C restatement on every case."""
+import os
 import zlib
 
 import numpy as np
@@ -49,6 +50,20 @@ def test_c_oracle_on_the_headline_batch_equals_the_reference(kind, m0):
     got, fl = c_oracle.quantize(xs, Cs, True, EPS, ITERS)
     assert fl == 0 and np.array_equal(got, con[:, m0:m0 + 4])
     assert np.array_equal(c_oracle.quantize(xs, Cs, False)[0], near[:, m0:m0 + 4])
+
+
+def test_c_oracle_on_config0_equals_the_reference():
+    """BASELINE configs[0] at its exact inputs (oracle/gen_golden.py --config0 ran the reference whole): the C
+    restatement returns the reference's constrained and nearest codes of all 10 000 x 8."""
+    import zlib
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "config0_b10000_m8.npz"))
+    N, M = int(g["B"]), int(g["M"])
+    x = np.random.default_rng(20220).standard_normal((N, 768), dtype=np.float32)
+    C = np.ascontiguousarray(x[np.random.default_rng(20221).permutation(N)[:256]].reshape(256, M, 768 // M).transpose(1, 0, 2))
+    assert zlib.crc32(x.tobytes()) == int(g["x_crc"]) and zlib.crc32(C.tobytes()) == int(g["centroids_crc"])
+    got, fl = c_oracle.quantize(x, C, True, EPS, ITERS)
+    assert fl == 0 and np.array_equal(got, g["codes_constrained"])
+    assert np.array_equal(c_oracle.quantize(x, C, False)[0], g["codes_nearest"])
 
 
 @pytest.mark.parametrize("M,m0,nm", [(24, 11, 2), (96, 70, 4)])
