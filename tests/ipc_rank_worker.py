@@ -1,6 +1,7 @@
 """One rank of the multi-process GPU tests (tests/test_ipc_ranks.py launches `world` of these with tests/mp_util.py).
 
     python tests/ipc_rank_worker.py solve <case> <cut_0> ... <cut_world>     constrained codes of rows [cut_r, cut_r+1)
+    python tests/ipc_rank_worker.py recipe8                                   the 49 152-row headline batch over the ranks
     python tests/ipc_rank_worker.py allgather                                 rc_comm_allgather, several sizes
     python tests/ipc_rank_worker.py timeout                                   a missing peer is reported, not waited for
     python tests/ipc_rank_worker.py timeout_solve                             ... inside a whole solve (fused exchange)
@@ -141,6 +142,29 @@ def main() -> int:
                 print(f"rank {rank}: 7-iteration solve differs between repetitions ({i})")
                 rc = 1
         np.save(os.path.join(out, f"codes7_rank{rank}.npy"), ref.cpu().numpy())
+    elif what == "recipe8":
+        # BASELINE configs[2]: the headline batch of 49 152 rows on `world` ranks (8: 6 144 rows each), default form of the
+        # exchange, eager / captured / replayed; expected = what the REFERENCE returned on eight gloo ranks
+        # (tests/golden/recipe8_b49152_m48_sample.npz: identical to its one-process codes)
+        from conftest import GOLDEN, load_headline
+        x, C, con, _ = load_headline("sample")
+        r8 = np.load(os.path.join(GOLDEN, "recipe8_b49152_m48_sample.npz"))
+        want_all = con ^ r8["codes_xor_one_process"]
+        bl = x.shape[0] // world
+        xl = torch.from_numpy(np.ascontiguousarray(x[rank * bl:(rank + 1) * bl])).to(dev)
+        del x
+        Ct = torch.from_numpy(C).to(dev)
+        want = want_all[rank * bl:(rank + 1) * bl]
+        os.environ.setdefault("RC_IPC_TIMEOUT_MS", "60000")
+        for i, graph in enumerate(("0", "1", "1")):
+            os.environ["RC_GRAPH"] = graph
+            codes, flags = ops.assign_sinkhorn_dist(xl, Ct, EPS, ITERS, torch.uint8)
+            torch.cuda.synchronize()
+            bad = int((codes.cpu().numpy() != want).sum())
+            if int(flags.item()) != 0 or bad:
+                print(f"rank {rank}: pass {i}: flags {int(flags.item())}, {bad} codes differ from the reference's 8-rank run")
+                rc = 1
+        np.save(os.path.join(out, f"codes_rank{rank}.npy"), codes.cpu().numpy())
     elif what == "allgather":
         for n, dtype in ((7, torch.uint8), (48 * 256, torch.float64), (48 * 256 * 17, torch.float64), (0, torch.float32),
                          (1 << 20, torch.int32)):

@@ -38,6 +38,22 @@ def test_native_solve_on_ipc_ranks_equals_golden(name, world, tmp_path):
         assert np.array_equal(got, g["codes_constrained"]), (name, world, i)
 
 
+def test_the_eight_rank_recipe_on_ipc_ranks_equals_the_reference(tmp_path):
+    """BASELINE configs[2] as far as one GPU can go: the 49 152 x 768 headline batch, M = 48, on EIGHT rank processes of
+    6 144 rows each (the 8-GPU recipe's per-rank shape and exchange count), native C loop, default form of the exchange,
+    eager / captured / replayed.  Expected values: what /root/reference returned when eight gloo ranks ran its distributed
+    branch on this batch (oracle/gen_golden.py --recipe8; its codes equal its own one-process codes in all 2 359 296 places)."""
+    import os
+    from conftest import GOLDEN, load_headline
+    r8 = np.load(os.path.join(GOLDEN, "recipe8_b49152_m48_sample.npz"))
+    assert int(r8["world"]) == 8 and not r8["codes_xor_one_process"].any()
+    world = 8
+    assert run_ranks(world, ["recipe8"], str(tmp_path), timeout=900) == [0] * world, rank_logs(str(tmp_path), world)
+    _, _, con, _ = load_headline("sample")
+    got = np.concatenate([np.load(tmp_path / f"codes_rank{r}.npy") for r in range(world)], 0)
+    assert np.array_equal(got, con)
+
+
 def test_seven_iteration_solve_on_ipc_ranks_equals_single_process(tmp_path):
     import torch
     from repconc_amd import ops

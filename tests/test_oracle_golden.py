@@ -52,6 +52,17 @@ def test_c_oracle_on_the_headline_batch_equals_the_reference(kind, m0):
     assert np.array_equal(c_oracle.quantize(xs, Cs, False)[0], near[:, m0:m0 + 4])
 
 
+def test_reference_on_eight_ranks_returns_its_one_process_codes():
+    """tests/golden/recipe8_b49152_m48_sample.npz (gen_golden.py --recipe8): the reference's distributed branch on eight gloo
+    ranks of 6 144 rows gave the codes of its one-process run of the same 49 152-row batch in all 2 359 296 places — "sharded ==
+    unsharded" is the reference's own behaviour at the recipe shape, which is what the multi-rank tests assert of this build."""
+    from conftest import GOLDEN, load_headline
+    r8 = np.load(os.path.join(GOLDEN, "recipe8_b49152_m48_sample.npz"))
+    _, _, con, _ = load_headline("sample")
+    assert int(r8["world"]) == 8 and r8["codes_xor_one_process"].shape == con.shape and not r8["codes_xor_one_process"].any()
+    assert zlib.crc32(con.tobytes()) == int(r8["codes_crc"])
+
+
 def test_c_oracle_on_config0_equals_the_reference():
     """BASELINE configs[0] at its exact inputs (oracle/gen_golden.py --config0 ran the reference whole): the C
     restatement returns the reference's constrained and nearest codes of all 10 000 x 8."""
