@@ -484,6 +484,27 @@ def test_sinkhorn_algorithm_and_centring_api():
     np.testing.assert_allclose(Q.cpu().numpy(), ref, rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("name", ["m8_b300_gauss", "m48_b1024_sample"])
+def test_sinkhorn_algorithm_plan_against_the_references_plan(name):
+    """The floating-point stage on its own output: `sinkhorn_algorithm` (the reference's name and arguments) returns the
+    transport plan; 4096 sampled entries and every column's argmax are compared with what the REFERENCE's sinkhorn_algorithm
+    returned on the same centred table (tests/golden/plan_<case>.npz, gen_golden.py --plan).  Tolerance, stated here: the
+    product carries potentials and rebuilds Q = softmax_k(out / eps + f) instead of normalising Q in place 100 times, so entries
+    agree to 1e-9 relative (+ 1e-30 absolute for entries that underflow towards zero); the argmax is exact."""
+    from repconc_amd.models.repconc import RepCONC, sinkhorn_algorithm
+    g, x, C = load_case(name)
+    p = np.load(os.path.join(os.path.dirname(__file__), "golden", f"plan_{name}.npz"))
+    from repconc_amd import ops
+    d, _ = ops.dist_table(_t(x), _t(C))
+    dc = RepCONC.center_distance_for_constraint(d)
+    Q = sinkhorn_algorithm(-dc.double().transpose(1, 2), EPS, ITERS, False)          # [M,K,B]
+    assert tuple(Q.shape) == (int(p["M"]), 256, int(p["B"]))
+    Qn = Q.cpu().numpy()
+    assert np.array_equal(Qn.argmax(1).astype(np.uint8), p["argmax"])
+    np.testing.assert_allclose(Qn.reshape(-1)[p["sample_index"]], p["sample_q"], rtol=1e-9, atol=1e-30)
+    np.testing.assert_allclose(Qn.sum(1), 1.0, rtol=1e-12)
+
+
 def test_index_build_and_search_api():
     from types import SimpleNamespace
     from repconc_amd.models.repconc import evaluate_repconc as ev

@@ -52,6 +52,23 @@ def test_c_oracle_on_the_headline_batch_equals_the_reference(kind, m0):
     assert np.array_equal(c_oracle.quantize(xs, Cs, False)[0], near[:, m0:m0 + 4])
 
 
+@pytest.mark.parametrize("name", ["m8_b300_gauss", "m48_b1024_sample"])
+def test_numpy_oracle_plan_equals_the_references_plan(name):
+    """The transport plan itself, not only its argmax: tests/golden/plan_<case>.npz holds 4096 sampled entries of what the
+    reference's sinkhorn_algorithm returned on the case's centred table (gen_golden.py --plan).  oracle/pq_oracle.sinkhorn_q is
+    the same sequence of fp64 operations: relative difference below 1e-12 (numpy and torch reduce sums in different orders),
+    identical column argmax."""
+    g, x, C = load_case(name)
+    p = np.load(os.path.join(os.path.dirname(__file__), "golden", f"plan_{name}.npz"))
+    d = pq_oracle.dist_table(x, C)
+    dc = pq_oracle.centre(d, *pq_oracle.minmax_per_m(d))
+    Q = pq_oracle.sinkhorn_q([-(dc.astype(np.float64)).transpose(0, 2, 1)], EPS, ITERS)[0]
+    assert np.array_equal(Q.argmax(1).astype(np.uint8), p["argmax"])
+    got, want = Q.reshape(-1)[p["sample_index"]], p["sample_q"]
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
+    assert np.array_equal(p["argmax"].T, g["codes_constrained"])          # the plan's argmax IS the fixture's codes
+
+
 def test_reference_on_eight_ranks_returns_its_one_process_codes():
     """tests/golden/recipe8_b49152_m48_sample.npz (gen_golden.py --recipe8): the reference's distributed branch on eight gloo
     ranks of 6 144 rows gave the codes of its one-process run of the same 49 152-row batch in all 2 359 296 places — "sharded ==
