@@ -148,6 +148,10 @@ def test_decode_forward_backward():
     ops.decode(codes.long(), Cp).backward(go)
     want = pq_oracle.decode_bwd(g["codes_constrained"], go.cpu().numpy(), 48, 256)
     np.testing.assert_allclose(Cp.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # ... and against the gradient the REFERENCE's autograd produced for these inputs (gen_golden.py --aux); fp32 atomic
+    # scatter-add in any order against a sequential index_put: 1e-5
+    aux = np.load(os.path.join(os.path.dirname(__file__), "golden", "aux_m48_b1024.npz"))
+    np.testing.assert_allclose(Cp.grad.cpu().numpy(), aux["decode_grad"], rtol=1e-5, atol=1e-5)
     # numpy variant of the module-level decode
     from repconc_amd.models.repconc import decode
     assert zlib.crc32(np.ascontiguousarray(decode(g["codes_constrained"], C)).tobytes()) == int(g["decode_crc"])
@@ -189,6 +193,8 @@ def test_normalize_centroids():
     C = synth.gaussian(3, (48, 256, 16))
     got = ops.normalize_centroids_(_t(C).clone()).cpu().numpy()
     np.testing.assert_allclose(got, pq_oracle.normalize_centroids(C), rtol=1e-6, atol=1e-7)
+    aux = np.load(os.path.join(os.path.dirname(__file__), "golden", "aux_m48_b1024.npz"))      # the reference's normalize_centrodis
+    np.testing.assert_allclose(got, aux["normalized"], rtol=1e-6, atol=1e-7)
 
 
 # ------------------------------------------------------------------------------------------- ADC

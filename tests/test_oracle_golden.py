@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_cases, load_case
-from oracle import c_oracle, pq_oracle
+from oracle import c_oracle, pq_oracle, synth
 
 EPS, ITERS = 0.003, 100
 SMALL = [c for c in golden_cases() if "b6144" not in c]
@@ -67,6 +67,17 @@ def test_numpy_oracle_plan_equals_the_references_plan(name):
     got, want = Q.reshape(-1)[p["sample_index"]], p["sample_q"]
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
     assert np.array_equal(p["argmax"].T, g["codes_constrained"])          # the plan's argmax IS the fixture's codes
+
+
+def test_numpy_oracle_decode_gradient_and_normalisation_equal_the_references():
+    """tests/golden/aux_m48_b1024.npz (gen_golden.py --aux): the gradient the reference's autograd sends to the centroids
+    through `decode` (modeling_repconc.py:168-175) and its `normalize_centrodis` (:112-116) — pq_oracle.decode_bwd /
+    normalize_centroids restate them (fp32 sums of <= a few dozen terms in another order: 1e-5; one division: 1e-6)."""
+    g, x, C = load_case("m48_b1024_sample")
+    a = np.load(os.path.join(os.path.dirname(__file__), "golden", "aux_m48_b1024.npz"))
+    go = synth.gaussian(5, (1024, 768))
+    np.testing.assert_allclose(pq_oracle.decode_bwd(g["codes_constrained"], go, 48, 256), a["decode_grad"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pq_oracle.normalize_centroids(synth.gaussian(3, (48, 256, 16))), a["normalized"], rtol=1e-6, atol=1e-7)
 
 
 def test_reference_on_eight_ranks_returns_its_one_process_codes():
