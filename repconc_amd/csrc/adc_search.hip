@@ -898,7 +898,9 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     constexpr int SCAP = ADC_Q16_SCAP;
     unsigned* sbuf = reinterpret_cast<unsigned*>(smem + 2 * BUF) + wv * SCAP;
     int scount = 0;                                          // wave-uniform
+    bool flushed = false;                                    // wave-uniform: this wave issued stores / atomics since the last phase change
     auto flush_survivors = [&]() {
+        flushed = flushed || scount > 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's list writes are in the LDS (in-order queue)
         for (int i = l; i < scount; i += 64) {
             const unsigned e = sbuf[i];
@@ -939,9 +941,13 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
                 for (int j = 0; j < 4; ++j) offb[j] = off[j] + (unsigned)buf * (unsigned)BUF;
             } else {
             // phase change: this phase's tables were requested into the other buffer one segment ago
-            // my pieces have landed: everything but the last step's NV code loads, which are younger (round 5: vmcnt(0) also
-            // waited for those)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");
+            // my pieces have landed: everything but the NV code loads of the step just finished, which are younger than any table
+            // piece (a piece is requested at a phase change, the codes after it) — round 5: vmcnt(0) also waited for those
+            // (vmcnt counts loads in order; a flush's stores and atomics may complete out of order with respect to them, and the
+            // tile's last step follows a step that requested no codes: both cases wait for everything)
+            if (it + 1 < nsteps && !flushed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            flushed = false;
             // everybody's have, and everybody is done with the old buffer (every LDS read of the step has returned: its last
             // gather_wait is lgkmcnt(0)).  The bare instruction: __syncthreads() is fence + barrier, and the fence is
             // s_waitcnt vmcnt(0) — it would wait for the code loads issued a few chunks ago after all (M = 64 / 96: -1 %).
