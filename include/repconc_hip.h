@@ -19,7 +19,10 @@
  *     M may be any divisor of D (modeling_repconc.py:41): dsub = D/M in {8,12,16,24,32,48,64,96} (the recipes' widths)
  *     runs on specialised kernels, any other width on run-time-width kernels with the same arithmetic — the fp32
  *     summation order of the torch-CPU oracle, SURVEY.md §8 a-1, pinned for all 18 divisors of 768;
- *     the ADC / IVF search entries need M in {8,12,16,24,32,48,64,96};
+ *     search: rc_index_search, rc_adc_search_exact and the Python boundary serve ANY M (round 5); the raw screening
+ *     entries rc_adc_search / _img / _q have kernels for M in {8,12,16,24,32,48,64,96} and return RC_ESHAPE for any other M
+ *     BEFORE anything is enqueued — the caller's route is then rc_adc_search_exact (same results, exact scan with a
+ *     run-time width), which is what rc_index_search does itself; the list-centric IVF entries need M in {16,32,48,64,96};
  *   - fp32 arithmetic follows the reference bit for bit (no FMA contraction, IEEE division);
  *     the fp64 Sinkhorn stage is evaluated with potentials and is specified
  *     on its OUTPUT, the codes.
@@ -49,7 +52,7 @@ extern "C" {
 #define RC_FLAG_NONFINITE 1 /* a row/column sum became 0, inf or NaN — the reference's   */
                             /* "Sinkhorn Algorithm returns nan/inf values" warning,      */
                             /* models/repconc/modeling_repconc.py:64-65                  */
-#define RC_FLAG_COMM 4      /* IPC transport: a peer's signal did not arrive within RC_IPC_TIMEOUT_MS (default 30 s):  */
+#define RC_FLAG_COMM 4      /* IPC transport: a peer's signal did not arrive within RC_IPC_TIMEOUT_MS (default 600000): */
                             /* the wait gave up instead of hanging the GPU; the codes of this call are garbage       */
 #define RC_FLAG_RANGE 2     /* |(L + f) N/ln2| left the range the sweep's integer split  */
                             /* covers (eps < ~3e-4 on centred distances: the reference's */
@@ -164,9 +167,12 @@ int rc_pq_assign_sinkhorn(rc_handle_t h, const float* x, int64_t ldx, const floa
 /* ------------------------------------------------------------------ a-1 … a-4, one call, N ranks
  * RepCONC.quantize with use_constraint=True in the dist.is_initialized() branch (modeling_repconc.py:47-67 with
  * :78-80 and :149-157): every rank passes its equal row block of the batch and receives the codes of its rows; the
- * uniform-assignment constraint is over the global batch.  Collectives run on RCCL inside the call (all-reduce
- * MAX/MIN of the distance range, one all-gather of the [M,256] fp64 row sums per iteration), the sub-quantisers
- * are solved as two independent chains on two streams so the all-gathers overlap sweeps (comm.hip).
+ * uniform-assignment constraint is over the global batch.  The exchanges (MAX/MIN of the distance range once, one
+ * all-gather of the [M,256] fp64 row sums per iteration) run inside the call on the transport the handle was given:
+ * IPC peer stores (below; the default of the Python boundary) — ONE chain of all M sub-quantisers, the exchange fused
+ * into the sweep kernel — or RCCL (rc_comm_init), where the sub-quantisers are solved as TWO independent chains on two
+ * streams so that one chain's all-gather overlaps the other's sweep (comm.hip; RC_DIST_SPLIT=0/1 overrides the rule,
+ * rc_solve_num_chains_on says what a call will use).
  *
  * rc_comm_unique_ids: fill ids_host[2*128] on ONE rank (ncclGetUniqueId x2); the caller broadcasts the 256 bytes.
  * rc_comm_init: every rank, same ids; creates two communicators on the handle's device.  RC_ECOMM if RCCL
@@ -185,7 +191,7 @@ int rc_comm_world(rc_handle_t h);
  * and bumps the peer's arrival counter (system-scope release), followed by a one-thread kernel that waits for the local
  * counter and re-arms it: no library call, no communicator, capturable in a hipGraph like any kernel; buffers and
  * counters alternate between two parities so consecutive exchanges need no further handshake.  The wait gives up after
- * RC_IPC_TIMEOUT_MS (flags |= RC_FLAG_COMM) instead of hanging the device when a peer has died.
+ * RC_IPC_TIMEOUT_MS (default 600000; flags |= RC_FLAG_COMM) instead of hanging the device when a peer has died.
  * Round 5: inside rc_pq_assign_sinkhorn_dist the per-iteration exchange (modeling_repconc.py:155-157) is part of the
  * sweep kernel itself — the block that finishes a sub-quantiser's row sums stores them and a sequence-numbered flag at
  * every peer, the next sweep's blocks of that sub-quantiser wait for the peers' flags in their prologue (after their

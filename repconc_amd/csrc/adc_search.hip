@@ -928,6 +928,10 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             }
         }
     };
+    // ONE global_load_dwordx4 per call, and the phase change's `s_waitcnt vmcnt(NV)` counts exactly the NV calls of a step as
+    // the youngest loads in flight: the immediate of that wait IS NV (same constant), the type is 16 bytes (one instruction),
+    // and the loads must stay behind the asm waits (they are volatile asm with a memory clobber; the loads are plain C++).
+    static_assert(sizeof(adc_u32x4v) == 16 && NV == R / 4, "vmcnt(NV) at the phase change counts one dwordx4 load per load_quad");
     auto load_quad = [&](int it, int v) {
         return *reinterpret_cast<const adc_u32x4v*>(tile + ((size_t)phase_of(it) * (TILE * 16) + (size_t)(it / NPH) * (ROUND * 16) +
                                                             lane_at + 16 * v));

@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256) void xchg_flagwait_kernel(const unsigned long 
     if (i >= M * world) return;
     const unsigned long long* fp = xflags + (size_t)(i / world) * RC_IPC_MAX_WORLD + (i % world);
     const unsigned long long want = *seq_base + (unsigned long long)t + 1ull;
-    if (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return;
+    // the flag is read with ACQUIRE at system scope (pairs with the pusher's RELEASE store): the row sums behind it are visible
+    // to whatever this rank reads afterwards, by the HIP memory model and not only by the sc0 sc1 bits of gfx942 / gfx950
+    if (__hip_atomic_load(fp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return;
     if (ipc_broken(status)) { atomicOr(flags, RC_FLAG_COMM); return; }
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(256) void xchg_flagwait_kernel(const unsigned long 
             return;
         }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);               // system scope
 }
 // a rank without rows: block m stores `rows` (zeros) [M][K] and the flags exactly as a sweep's reducer would
 __global__ __launch_bounds__(RC_K) void xchg_rowpush_kernel(const double* __restrict__ rows, int M, int t, const sk_xchg x,
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(RC_K) void xchg_rowpush_kernel(const double* __rest
     __syncthreads();
     if (tid < x.world)
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(x.peers[tid] + x.push_flag_off) + (size_t)m * RC_IPC_MAX_WORLD + x.rank,
-                           *x.seq_base + (unsigned long long)t + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                           *x.seq_base + (unsigned long long)t + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // distance range over ranks: gathered [world][2M] (max then min per rank) -> minmax [2M]
@@ -724,7 +727,10 @@ int rc_solve_chains(rc_handle_t h, const float* x, int64_t ldx, const float* C, 
     const bool use_ipc = coll && ipc;
     const bool xsweep = use_ipc && want_xsweep(h);
     solve_ctx cx = {h, n, &L, w, d, minmax, B, M, G, eps, own_flags, {s0, s0}, fuse_centre, coll, use_ipc,
-                    {h->ipc.seq[0], h->ipc.seq[1]}, xsweep, xsweep && want_inwait(h), iters};
+                    {h->ipc.seq[0], h->ipc.seq[1]}, xsweep, xsweep && want_inwait(h) && L.nch == 1, iters};
+    // (prologue waits only with ONE chain: with two, blocks of chain 0's sweep t + 1 spinning for a peer's chain-0 push can
+    // hold the CU slots that peer's chain-1 sweep needs to get to ITS push while this rank's chain-1 blocks queue behind the
+    // spinners — a cross-chain stall that only RC_IPC_TIMEOUT_MS ends.  Two chains use the flag-wait kernels.)
     if (use_ipc) {   // this solve's exchanges are numbered base .. base + iters - 1 on each channel it uses
         h->ipc.seq[0] += (unsigned long long)iters;
         if (L.nch == 2) h->ipc.seq[1] += (unsigned long long)iters;

@@ -210,8 +210,10 @@ __device__ __forceinline__ unsigned km_px_row(const float4 v, int k, int q, int 
     const int shmin = min(min(sh[0], sh[1]), min(sh[2], sh[3]));
     const int shmax = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
     unsigned what = 0u;
-    if (shmin >= 0 && shmax <= 40) {
-        emax = max(emax, max(max(e[0], e[1]), max(e[2], e[3])));
+    const unsigned e4 = max(max(e[0], e[1]), max(e[2], e[3]));
+    // (e4 != 0xFF: with a very large hint an inf / NaN would pass the shift test and be added as a finite significand)
+    if (shmin >= 0 && shmax <= 40 && e4 != 0xFFu) {
+        emax = max(emax, e4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int sig = (int)((b[i] & 0x7FFFFFu) | ((e[i] ? 1u : 0u) << 23));
@@ -377,6 +379,10 @@ __global__ __launch_bounds__(1024) void kmeans_stats_px_kernel(const float* __re
             if ((rd >> 16) == seq)                          // launch B repeated this piece: its partials are the new ones
                 km_px_finish_share(p, strip, strips, D, M, dsub, P, 61 - log2n - ((int)(rd & 0xFFFFull) - 32768), sstride, cstride, phi,
                                    plo, pcnt, pnf, sfl, sums, counts);
+            // every wave of this block has read ctl->seq / hint / its piece's redo word (and done its finish share) before
+            // the block counts as arrived: the last arriver advances seq, and a wave that loaded it afterwards would take the
+            // piece for one of the NEXT call and skip its share
+            __syncthreads();
             if (tid == 0 && __hip_atomic_fetch_add(&ctl->carrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
                 // the last block of the call's last launch (every other one has read hint and seq): the bound of this call's
                 // data (all pieces) + one bit becomes the next call's hint; then the call is closed

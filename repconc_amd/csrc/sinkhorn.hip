@@ -42,6 +42,12 @@
 #ifndef SK_RED_INFLIGHT
 #define SK_RED_INFLIGHT 24               // partial loads in flight in the last-block reducer
 #endif
+// memory order of the fused exchange's flag store (system scope).  RELEASE: the flag publishes the row sums stored before the
+// block barrier by the HIP memory model; RELAXED was the round-5 form, correct on gfx942 / gfx950 only because its
+// data stores are write-through system-scope atomics drained with s_waitcnt vmcnt(0).  -DSK_XCHG_FLAG_ORDER=__ATOMIC_RELAXED for A/B.
+#ifndef SK_XCHG_FLAG_ORDER
+#define SK_XCHG_FLAG_ORDER __ATOMIC_RELEASE
+#endif
 #define SK_MAX_CPB 512                 // columns per block (LDS holds their integer column exponents)
 #define SK_LN2 0.69314718055994530942
 
@@ -460,7 +466,10 @@ __device__ __forceinline__ void sk_setprio(int p) {     // s_setprio takes an im
 // neither waits nor pushes (peers time out instead of reading half an exchange).
 __device__ __forceinline__ bool sk_xchg_wait_flag(const unsigned long long* __restrict__ fp, unsigned long long want,
                                                   const sk_xchg& x, int* __restrict__ flags) {
-    if (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
+    // ACQUIRE at system scope on the load that sees the flag (pairs with the pusher's RELEASE store below): the peers' row sums
+    // are visible to the loads that follow the block barrier — by the HIP memory model, not only because relaxed system-scope
+    // accesses carry sc0 sc1 on gfx942 / gfx950.  One cache invalidate per polling wave.
+    if (__hip_atomic_load(fp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
     if (__hip_atomic_load(x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & RC_FLAG_COMM) {
         atomicOr(flags, RC_FLAG_COMM);
         return false;
@@ -474,6 +483,7 @@ __device__ __forceinline__ bool sk_xchg_wait_flag(const unsigned long long* __re
             return false;
         }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);               // system scope
     return true;
 }
 
@@ -682,7 +692,7 @@ __global__ __launch_bounds__(SK_THREADS, (MODE == 2 && !FKLDS) ? 3 : 4) void sk_
                     if (tid_e < x.world)
                         __hip_atomic_store(reinterpret_cast<unsigned long long*>(x.peers[tid_e] + x.push_flag_off) +
                                                (size_t)m * RC_IPC_MAX_WORLD + x.rank,
-                                           *x.seq_base + (unsigned long long)t + 1ull, __ATOMIC_RELAXED,
+                                           *x.seq_base + (unsigned long long)t + 1ull, SK_XCHG_FLAG_ORDER,
                                            __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }

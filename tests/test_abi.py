@@ -93,3 +93,19 @@ def test_adc_conflict_free_layout_properties():
     for MM in (16, 32, 48, 64):
         q16 = lib.rc_adc_q16_describe(MM, 0, 0, C.byref(slot))
         assert q16 in (0, 1) and lib.rc_adc_scan_image_bytes(1000, MM) == (32768 * MM if q16 else 1000 * MM)
+
+
+def test_numeric_defaults_quoted_in_the_header_match_the_code():
+    """The header is the contract: every `RC_<KNOB> (default <n>` it quotes must be the default the sources pass to
+    rc_env_int / read for that knob (round 5's header said 30 s for RC_IPC_TIMEOUT_MS while the code used 600000)."""
+    import glob
+    hdr = open(os.path.join(ROOT, "include", "repconc_hip.h")).read()
+    quoted = re.findall(r"\b(RC_[A-Z0-9_]+)\s*\(default\s+(-?\d+)", hdr)
+    assert quoted, "the header quotes no numeric default at all: the check below would be empty"
+    code = {}
+    for f in glob.glob(os.path.join(ROOT, "repconc_amd", "csrc", "*")):
+        for name, dflt in re.findall(r'rc_env_int\("([A-Z0-9_]+)",\s*(-?\d+)\)', open(f).read()):
+            code.setdefault(name, set()).add(int(dflt))
+    for name, dflt in quoted:
+        assert name in code, f"{name}: quoted in the header, not read by any source through rc_env_int"
+        assert code[name] == {int(dflt)}, f"{name}: header says {dflt}, the sources use {sorted(code[name])}"
