@@ -340,6 +340,59 @@ def main():
                                  "python-staged torch.distributed loop"),
                       "transport": chosen, "native_equals_staged": native_all if candidates else None,
                       "transport_notes": notes or None, "sharded_equals_unsharded": unsharded_equal}
+        # (3) the recipe's own batch against the REFERENCE: the 49 152-row batch of
+        # tests/golden/headline_b49152_m48_sample.npz, `world` equal row blocks through the driver chosen above, compared with
+        # what the reference's distributed branch returned on eight gloo ranks (recipe8_b49152_m48_sample.npz — identical to
+        # its one-process codes, so the expected codes do not depend on the number of ranks)
+        golden = os.path.join(ROOT, "tests", "golden")
+        try:
+            import zlib
+            from oracle import synth                         # input synthesis from seeds (shared with the fixtures), no arithmetic
+            hg = np.load(os.path.join(golden, "headline_b49152_m48_sample.npz"))
+            r8 = np.load(os.path.join(golden, "recipe8_b49152_m48_sample.npz"))
+            Bh = int(hg["B"])
+            if Bh % world == 0:
+                xh = synth.clustered_embeddings(int(hg["x_seed"]), Bh, n_clusters=int(hg["n_clusters"]))
+                Ch = hg["centroids"] if "centroids" in hg.files else synth.sample_centroids(int(hg["c_seed"]), xh, M)
+                assert zlib.crc32(np.ascontiguousarray(Ch).tobytes()) == int(hg["centroids_crc"])
+                want = hg["codes_constrained"] ^ r8["codes_xor_one_process"]
+                blh = Bh // world
+                xh_l = torch.from_numpy(np.ascontiguousarray(xh[rank * blh:(rank + 1) * blh])).to(dev)
+                del xh
+                ch_l, fl_h = assign_sinkhorn_sharded(xh_l, torch.from_numpy(np.ascontiguousarray(Ch)).to(dev), EPS, ITERS, comm,
+                                                     dtype=torch.uint8)
+                torch.cuda.synchronize()
+                bad_h = int((ch_l.cpu().numpy() != want[rank * blh:(rank + 1) * blh]).sum()) + (0 if int(fl_h.item()) == 0 else 1)
+                dist_check["recipe_batch_equals_the_references_8_rank_run"] = all_ranks(bad_h == 0)
+                dist_check["recipe_batch"] = f"{Bh} x 768, M=48: {blh} rows per rank on {world} ranks, every code compared"
+                del xh_l, ch_l
+        except FileNotFoundError as e:
+            dist_check["recipe_batch_equals_the_references_8_rank_run"] = None
+            dist_check["recipe_batch"] = f"fixture missing: {e}"
+        # (4) who sits where: one line per rank (device index, PCI bus id), and whether every rank has a device of its own — an
+        # IPC transport that passed above between ranks on DISTINCT devices has mapped a peer device's buffer
+        # (hipIpcOpenMemHandle across devices) and exchanged through it
+        prop = torch.cuda.get_device_properties(dev)
+        ident = f"{local_rank}:{getattr(prop, 'pci_bus_id', '?')}:{getattr(prop, 'pci_device_id', '?')}:{getattr(prop, 'uuid', '')}"
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        distinct = len(set(idents)) == world
+        dist_check["rank_devices"] = idents
+        dist_check["one_device_per_rank"] = distinct
+        dist_check["ipc_between_peer_devices"] = (bool(distinct and any(t.startswith("ipc") for t in measured)) if candidates else None)
+        # (5) the ceiling of this rank count: this rank's share of the batch solved stand-alone (no exchange at all)
+        for _ in range(2):
+            ops.assign_sinkhorn(pool[0], C, EPS, ITERS, torch.uint8)
+        barrier()
+        tt0 = time.perf_counter()
+        for i in range(3):
+            ops.assign_sinkhorn(pool[i % n_pool], C, EPS, ITERS, torch.uint8)
+        barrier()
+        alone_ms = max_over_ranks(time.perf_counter() - tt0) * 1e3 / 3
+        dist_check["standalone_share"] = {"rows": bl, "ms_per_step": round(alone_ms, 3),
+                                          "ceiling_vectors_per_sec": round(B / (alone_ms * 1e-3), 1),
+                                          "what": "every rank solves its own rows with NO exchange (a different problem: the "
+                                                  "constraint is per rank): the time a sharded step cannot beat"}
         if native_all:
             exchange = {"transport": chosen, "chains": measured[chosen]["chains"],
                         "bytes_per_rank": (M // measured[chosen]["chains"]) * K * 8,
@@ -680,10 +733,52 @@ def main():
         torch.cuda.synchronize()
         cu_ms = e0.elapsed_time(e1) / 5
         del xc, cu_ws, cu_cent, cu_assign
-        codes3 = torch.randint(0, 256, (N_CORPUS, M3), dtype=torch.uint8, device=dev, generator=g3)
-        ivf.set_lists(codes3, torch.randint(0, nlist, (N_CORPUS,), device=dev, generator=g3))
-        del codes3
-        qi = q_all[:nq_batch]
+        # ---- the index ("IVF measured as retrieval, not as a scan"): a clustered synthetic corpus (512 Gaussian
+        # clusters, weaker than the flat leg's: 0.5 centre + 0.5 noise; 8 841 823 rows, generated chunk by chunk), PQ centroids Lloyd-refined on its first 65 536
+        # rows, the coarse quantiser TRAINED on its first 2^20 rows (10 Lloyd iterations of rc_ivf_coarse_assign /
+        # rc_ivf_coarse_update, Faiss's default for an IVF coarse quantiser), every row coded (nearest codes) and sent to its
+        # L2-nearest cell.  Queries = noisy copies of corpus rows: the copied row is the query's one relevant passage.
+        gcl3 = torch.Generator(device=dev).manual_seed(20230)
+        centers3 = torch.randn((512, D), device=dev, generator=gcl3)
+
+        def corpus_chunk3(i, rows):
+            gi = torch.Generator(device=dev).manual_seed(20231 + i)
+            a_ = torch.randint(0, centers3.shape[0], (rows,), device=dev, generator=gi)
+            return (0.5 * centers3[a_] + 0.5 * torch.randn((rows, D), device=dev, generator=gi)).contiguous()
+        chunk3 = 1 << 20
+        x0 = corpus_chunk3(0, chunk3)
+        perm3 = torch.randperm(1 << 16, device=dev, generator=gcl3)[:K]
+        C3 = x0[perm3].reshape(K, M3, D // M3).transpose(0, 1).contiguous()
+        for _ in range(4):
+            cb3 = ops.assign_nearest(x0[:1 << 16], C3, torch.uint8)
+            sb3, nb3 = ops.kmeans_stats(x0[:1 << 16], cb3)
+            ops.kmeans_update_(sb3, nb3, C3)
+        ivf.set_centroids(C3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        from repconc_amd.ivf import coarse_kmeans
+        ivf.coarse = coarse_kmeans(x0, nlist, iters=10)
+        torch.cuda.synchronize()
+        coarse_train_s = time.perf_counter() - t0
+        nq_dev = 6980
+        rel = torch.from_numpy(np.sort(np.random.default_rng(20232).permutation(chunk3)[:nq_dev]).copy()).to(dev)   # rows of chunk 0
+        q_dev = (x0[rel] + 1.0 * torch.randn((nq_dev, D), device=dev, generator=gcl3)).contiguous()
+        codes3 = torch.empty((N_CORPUS, M3), dtype=torch.uint8, device=dev)
+        cells3 = torch.empty((N_CORPUS,), dtype=torch.int64, device=dev)
+        t0 = time.perf_counter()
+        for ci, a0 in enumerate(range(0, N_CORPUS, chunk3)):
+            rows = min(chunk3, N_CORPUS - a0)
+            xc_ = x0 if ci == 0 else corpus_chunk3(ci, rows)
+            codes3[a0:a0 + rows] = ops.assign_nearest(xc_[:rows], C3, torch.uint8)
+            cells3[a0:a0 + rows] = coarse_assign(xc_[:rows], ivf.coarse)
+            del xc_
+        torch.cuda.synchronize()
+        ivf_build_s = time.perf_counter() - t0
+        del x0
+        ivf.set_lists(codes3, cells3)
+        cell_sizes = (ivf.list_off[1:] - ivf.list_off[:-1]).float()
+        del codes3, cells3
+        qi = q_dev[:nq_batch]
         sweep3 = {}
         for nprobe in (8, 32, 128):
             for _ in range(2):                                   # the first calls size the allocator's workspace blocks
@@ -691,30 +786,53 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for bi in range(args.adc_batches):                   # the 1200-query batches of the flat leg
-                ivf.search(q_all[bi * nq_batch:(bi + 1) * nq_batch], k, nprobe)
+                b0 = min(bi * nq_batch, nq_dev - nq_batch)
+                ivf.search(q_dev[b0:b0 + nq_batch], k, nprobe)
             torch.cuda.synchronize()
             sweep3[f"nprobe{nprobe}"] = round(args.adc_batches * nq_batch / (time.perf_counter() - t0), 1)
         # the evaluation's own call (batch_search hands a list-centric index every query it has): the 6 980 MS MARCO dev queries
-        # in ONE call — a probed cell is scanned once for all the queries that probe it
-        q_dev = torch.randn((6980, D), device=dev, generator=g3)
-        sweep3_all = {}
-        for nprobe in (8, 32, 128):
+        # in ONE call — a probed cell is scanned once for all the queries that probe it — with the retrieval quality of every
+        # nprobe against the flat search of the same index: recall@10 / recall@1000 (overlap of the id sets) and MRR@10 of the
+        # planted relevant passage (`north_star`: MRR@10 within +-0.001)
+        flat3 = PQIndex(D, M3, device=dev)
+        flat3.set_centroids(C3)
+        flat3.add_codes(ivf.codes)
+        f_ids = torch.cat([ivf.ids[flat3.search(q_dev[i:i + nq_batch], k)[1]] for i in range(0, nq_dev, nq_batch)])
+
+        def mrr10(ids_):
+            hit = (ids_[:, :10] == rel[:, None])
+            rr = (hit.float() / torch.arange(1, 11, device=dev, dtype=torch.float32)[None, :]).sum(1)
+            return float(rr.mean())
+
+        def overlap(a_, b_, kk):
+            a_, b_ = a_[:, :kk].contiguous(), b_[:, :kk].contiguous()
+            return float((a_[:, :, None] == b_[:, None, :]).any(2).float().mean()) if kk <= 10 else \
+                float(torch.stack([torch.isin(a_[i], b_[i]).float().mean() for i in range(0, a_.shape[0], 7)]).mean())
+        mrr_flat = mrr10(f_ids)
+        sweep3_all, retrieval = {}, {}
+        for nprobe in (8, 32, 128, 512):
             ivf.search(q_dev, k, nprobe)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(3):
-                ivf.search(q_dev, k, nprobe)
+                _, i_ids = ivf.search(q_dev, k, nprobe)
             torch.cuda.synchronize()
-            sweep3_all[f"nprobe{nprobe}"] = round(3 * 6980 / (time.perf_counter() - t0), 1)
-        del q_dev
+            sweep3_all[f"nprobe{nprobe}"] = round(3 * nq_dev / (time.perf_counter() - t0), 1)
+            retrieval[f"nprobe{nprobe}"] = {"recall_at_10_vs_flat": round(overlap(i_ids, f_ids, 10), 4),
+                                            f"recall_at_{k}_vs_flat": round(overlap(i_ids, f_ids, k), 4),
+                                            "mrr_at_10": round(mrr10(i_ids), 5),
+                                            "mrr_at_10_minus_flat": round(mrr10(i_ids) - mrr_flat, 5)}
+        within = [int(n_[6:]) for n_, r_ in retrieval.items() if abs(r_["mrr_at_10_minus_flat"]) <= 0.001]
+        retrieval_summary = {"mrr_at_10_flat": round(mrr_flat, 5),
+                             "smallest_nprobe_with_mrr_within_0.001_of_flat": min(within) if within else None,
+                             "mrr_at_10": {n_: r_["mrr_at_10"] for n_, r_ in retrieval.items()},
+                             "recall_at_10": {n_: r_["recall_at_10_vs_flat"] for n_, r_ in retrieval.items()}}
+        del f_ids
         # nprobe = nlist scans every row: must equal the flat search (checked on 64 queries)
-        flat3 = PQIndex(D, M3, device=dev)
-        flat3.set_centroids(C3)
-        flat3.add_codes(ivf.codes)
         fs, fi = flat3.search(qi[:64], 100)
         s3, i3 = ivf.search(qi[:64], 100, nlist)
         same3 = bool(torch.equal(fs, s3) and float((ivf.ids[fi] == i3).float().mean()) > 0.999)   # ids may swap inside exact score ties
-        rows128 = N_CORPUS * 128 // nlist
+        rows128 = float(cell_sizes[ivf.probe(qi, 128, ordered=False).long()].sum(1).mean())   # probed rows per query, measured
         t128 = nq_batch / sweep3["nprobe128"]
         # the screen kernel alone (HIP events around its launch), nprobe = 128: against the measured LDS gather roof
         lib.rc_profile_enable(h, 1)
@@ -726,8 +844,17 @@ def main():
         ivf_gather = nq_batch * rows128 * M3 / (ivf_scan_ms * 1e-3) / 1e9 if n_l.value else 0.0   # 1 B per (row, m, query)
         out["ivf"] = {
             "metric": "ivf_adc_queries_per_sec", "unit": "queries/s", "k": k, "nlist": nlist, "M": M3,
-            "index": f"{N_CORPUS} x {M3} B uniform codes in {nlist} uniformly filled cells (no residual coding)",
+            "index": f"{N_CORPUS} x {M3} B: nearest codes of a clustered synthetic corpus (512 Gaussian clusters, 0.5 centre + 0.5 noise) in {nlist} cells of "
+                     "a coarse quantiser trained on its first 2^20 rows (10 Lloyd iterations), rows in their L2-nearest cell, no "
+                     "residual coding",
+            "cells": {"rows_min": int(cell_sizes.min()), "rows_max": int(cell_sizes.max()),
+                      "rows_mean": round(float(cell_sizes.mean()), 1), "empty": int((cell_sizes == 0).sum())},
+            "build": {"coarse_training_s": round(coarse_train_s, 3), "coding_and_cell_assignment_s": round(ivf_build_s, 3),
+                      "what": "coarse_kmeans on 2^20 rows; then nearest codes + nearest cell of all rows in 2^20-row chunks "
+                              "(wall time incl. generating the synthetic rows)"},
+            "queries": "6980 noisy copies (sigma 1.0 per coordinate: |noise| = 1.4 x |row|) of corpus rows; the copied row is the one relevant passage",
             "queries_per_sec": sweep3_all, "queries_per_call": 6980,
+            "retrieval": retrieval, "retrieval_summary": retrieval_summary,
             "queries_per_sec_1200_query_calls": sweep3, "nprobe_equals_nlist_matches_flat_search": same3,
             "coarse_assign": {"value": round((1 << 18) / cdt, 1), "unit": "vectors/s", "rows": 1 << 18,
                               "roofline": {"kernel": "ivf_coarse_assign_kernel (v_mfma_f32_32x32x2_f32, fused argmin)",
@@ -755,7 +882,7 @@ def main():
                                  "also moves 192 KiB of tables (3.8 GB per 1200-query batch from the memory-side cache) and the "
                                  "sixteen waves of a block meet at one barrier per table phase",
                          "whole_search_equivalent_code_GBs": round(nq_batch * rows128 * M3 / t128 / 1e9, 1)}}
-        del ivf, flat3
+        del ivf, flat3, q_dev, centers3
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ index-build leg (nearest codes, a-1/a-5)
@@ -790,6 +917,7 @@ def main():
                          "traffic": pmc_traffic("assign_mfma_kernel"),
                          "traffic_source": "profiles/pmc_summary.json, not this run",
                          "algorithmic_bytes_per_launch": nb * bytes_per_vec,
+                         "valu_issue_bound": _valu_bound(nb, M, K, ib["mfma"][1]),
                          "note": "far from the HBM roof by construction: 256 candidate distances per (row, sub-quantiser), "
                                  "2.25 VALU instructions each in the pair-folded min/second-min epilogue, the bf16 MFMAs "
                                  "underneath; after round 2 neither pipe is saturated (VALU ~64 %, matrix pipe ~37 %, waves "
@@ -925,7 +1053,15 @@ def main():
         out["kmeans_stats"] = {"metric": "kmeans_sufficient_statistics_vectors_per_sec", "value": big["value"],
                                "unit": "vectors/s", "rows": big["rows"], "ms": big["ms"], "roofline": big["roofline"],
                                "warmup_size_65536": ks_sizes[1 << 16],
-                               "note": "4 D + M bytes per vector (SURVEY 8d), HIP events around 10 calls"}
+                               "note": "4 D + M bytes per vector (SURVEY 8d), HIP events around 10 calls",
+                               "warmup_size_floor": "65 536 rows = 204 MB: three launches (profiles/r05h_kmeans_phases.txt) - A rows -> "
+                                                    "per-strip partials 47 us (the rows at 5-7 TB/s 29-39 us, + 34 MB of 64-bit "
+                                                    "partial accumulators written: 8 us), B the finish on every CU 10.8 us (34 MB "
+                                                    "read back, integer sum over the strips, one rounding), C closes the call 7.4 us; "
+                                                    "a one-launch form with the finish in the last-arriving block measured 103-108 us "
+                                                    "(DESIGN 9.3).  The rows alone at the achievable 6.3 TB/s are 32 us = 0.49 of the "
+                                                    "call: the fixed ~27 us of partials + finish + close is what a 204 MB input "
+                                                    "cannot amortise (2^20 rows: 0.52-0.61)"}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     if world == 1 and not args.no_cpu:
@@ -1071,8 +1207,66 @@ def main():
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:
+        # the LAST key of the line (what a tail of the output keeps): the second headline metric and the other legs in one
+        # compact object — the full objects are `adc`, `ivf`, `index_build`, `kmeans_stats` above
+        out["headline2"] = _headline2(out)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.close(real_stdout)
+
+
+def _valu_bound(rows, M, K, measured_ms):
+    """The bound the index-build screen actually hits: vector-ALU issue.  Per candidate distance the kernel
+    issues 2.25 VALU lane-instructions in its epilogue (tag 1 + pair-folded min / second-min 1.25; 36 wave-instructions per tile
+    of 32 centroids x 32 documents, counted in the ISA) and 3.5 counting every VALU instruction of the tile loop (280 wave-instructions
+    per 5 tiles besides the 20 MFMAs: fragment
+    conversion, addressing, the running-minimum bookkeeping); the chip issues 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz."""
+    lane_rate = 256 * 4 * 16 * 2.4e9
+    cand = rows * M * K
+    floor_ms = cand * 2.25 / lane_rate * 1e3
+    loop_ms = cand * 3.5 / lane_rate * 1e3
+    pmc = None
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["assign_mfma_kernel"]
+        pmc = {"valu_busy_frac": sq.get("valu_busy_frac"), "mfma_busy_frac": sq.get("mfma_busy_frac"),
+               "source": "profiles/pmc_summary.json (an earlier profiled run of this command), not this run"}
+    except Exception:
+        pass
+    return {"bound": "valu-issue", "epilogue_floor_ms": round(floor_ms, 3), "frac_of_epilogue_floor": round(floor_ms / measured_ms, 3),
+            "all_loop_valu_ms": round(loop_ms, 3), "frac": round(loop_ms / measured_ms, 3), "pmc": pmc,
+            "what": "candidates x VALU lane-instructions per candidate / (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz): 2.25 per candidate "
+                    "for the min / second-min epilogue alone, 3.5 with every VALU instruction of the tile loop; `frac` = the "
+                    "latter over the measured kernel time = the share of the kernel in which the vector ALUs issue (the PMC "
+                    "counter SQ_ACTIVE_INST_VALU says the same: `pmc.valu_busy_frac`)"}
+
+
+def _headline2(out):
+    """Compact summary of the legs beyond the constrained assignment, placed last in the JSON line."""
+    h = {}
+    a = out.get("adc")
+    if a:
+        rf = a.get("roofline", {})
+        h.update({"metric": "adc_queries_per_sec", "value": a.get("value"), "unit": "queries/s",
+                  "config": f"8841823 x 48 B flat ADC, {a.get('query_batch')}-query batches, k={a.get('k')}",
+                  "screen_kernel_ms": rf.get("avg_launch_ms"), "screen_frac_of_lds_gather_roof": rf.get("frac"),
+                  "frac_note": "1 table byte per (row, sub-quantiser, query) against 256 CUs x 256 B/clk x 2.4 GHz; against SURVEY "
+                               "8d's 4 B per lookup the same kernel is at 4 x this fraction (8-bit screen + exact rescoring)",
+                  "ids_equal_cpu_port": a.get("gpu_ids_identical"), "score_bits_equal_cpu_port": a.get("gpu_score_bits_identical"),
+                  "checked": a.get("checked_against_cpu_port"),
+                  "index_built_codes_qps": (a.get("index_built_codes") or {}).get("value"),
+                  "cpu_port_qps": (a.get("cpu_baseline") or {}).get("value"), "cpu_cores": (a.get("cpu_baseline") or {}).get("cores")})
+    v = out.get("ivf")
+    if v:
+        h["ivf_m96_nlist5000"] = {"queries_per_sec": v.get("queries_per_sec"), "retrieval": v.get("retrieval_summary"),
+                                  "screen_frac": (v.get("roofline") or {}).get("frac")}
+    b = out.get("index_build")
+    if b:
+        h["index_build_vectors_per_sec"] = b.get("value")
+        h["index_build_frac"] = {"hbm": (b.get("roofline") or {}).get("frac"),
+                                 "valu_issue": ((b.get("roofline") or {}).get("valu_issue_bound") or {}).get("frac")}
+    km = out.get("kmeans_stats")
+    if km:
+        h["kmeans_stats_frac"] = km.get("summary_frac") or (km.get("roofline") or {}).get("frac")
+    return h
 
 
 def _count_stats(st):

@@ -154,6 +154,21 @@ int rc_sk_argmax(rc_handle_t h, const float* d, const double* rows_prev, int G, 
                  int M, int K, double eps, int t, uint8_t* codes_u8, int64_t* codes_i64, int* flags,
                  rc_stream_t stream);
 
+/* ------------------------------------------------------------------ a-3 for ANY fp64 cost tensor (module boundary)
+ * `sinkhorn_algorithm(out, epsilon, sinkhorn_iterations, use_distrib_train)` (modeling_repconc.py:137-165) takes any fp64
+ * tensor out[M,K,B]; RepCONC.quantize passes the negated centred fp32 table, which the streaming sweep above serves.  A
+ * tensor that is NOT exactly representable in fp32 is served by these two entries on the caller's fp64 data (log-domain
+ * potentials, every log-sum-exp max-subtracted; deterministic; not a hot path):
+ *   rc_sk64_rows: lse[m,k] = log sum_b exp(out[m,k,b]/eps + g[m,b])      (g = NULL: zeros)            (:155)
+ *   rc_sk64_cols: f[m,k] = -log sum_r exp(lse_gathered[r,m,k])  (ranks in order: the all-reduce of :157),
+ *                 g_out[m,b] = -log sum_k exp(out[m,k,b]/eps + f[m,k])  (NULL: potentials only)        (:158-163)
+ * T iterations = rows, (cols, rows) x (T-1), cols(g_out = NULL); the plan is Q[:,:,b] = softmax_k(out/eps + f).
+ * out: [M,K,B] fp64 contiguous (this rank's columns), lse / f: [M,K] fp64, g: [M,B] fp64, lse_gathered: [G,M,K] fp64. */
+int rc_sk64_rows(rc_handle_t h, const double* out, const double* g, int64_t B, int M, int K, double eps, double* lse,
+                 rc_stream_t stream);
+int rc_sk64_cols(rc_handle_t h, const double* out, const double* lse_gathered, int G, int64_t B, int M, int K, double eps,
+                 double* f_out, double* g_out, rc_stream_t stream);
+
 /* ------------------------------------------------------------------ a-1 … a-4, one call
  * RepCONC.quantize with use_constraint=True on ONE rank (modeling_repconc.py:47-67,
  * dist.is_initialized()==False): distance table -> centring -> `iters` Sinkhorn iterations ->

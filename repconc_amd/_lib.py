@@ -42,6 +42,8 @@ PROTOTYPES = {
     "rc_sk_ws_bytes": (_sz, [_i64, _i, _i]),
     "rc_sk_sweep": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _d, _i, _vp, _vp, _sz, _vp]),
     "rc_sk_argmax": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
+    "rc_sk64_rows": (_i, [_vp, _vp, _vp, _i64, _i, _i, _d, _vp, _vp]),
+    "rc_sk64_cols": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _d, _vp, _vp, _vp]),
     "rc_pq_assign_sinkhorn_ws_bytes": (_sz, [_i64, _i, _i]),
     "rc_pq_assign_sinkhorn": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_comm_unique_ids": (_i, [_vp]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librepconc_hip.so")
-SOURCES = ["pq_distance.hip", "pq_assign_mfma.hip", "sinkhorn.hip", "pq_misc.hip", "kmeans.hip", "adc_search.hip", "ivf_lists.hip", "ivf_search.hip", "index.hip", "comm.hip"]
+SOURCES = ["pq_distance.hip", "pq_assign_mfma.hip", "sinkhorn.hip", "sinkhorn_f64.hip", "pq_misc.hip", "kmeans.hip", "adc_search.hip", "ivf_lists.hip", "ivf_search.hip", "index.hip", "comm.hip"]
 # -ffp-contract=off: the fp32 distance arithmetic must round every sub/mul/add separately
 # (bit parity with the torch-CPU oracle); fused multiply-adds are written explicitly where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

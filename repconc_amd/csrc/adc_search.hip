@@ -750,6 +750,9 @@ __global__ __launch_bounds__(RC_K) void adc_qstats_kernel(const float* __restric
 #ifndef ADC_Q16_PACK
 #define ADC_Q16_PACK 0             // 1: accumulators kept as int16 pairs between phases (more chunks per wave in 128 VGPRs)
 #endif
+#ifndef ADC_Q16_LATE_TEST
+#define ADC_Q16_LATE_TEST 1        // 1: a round's survivor test runs one step later, pair by pair, in front of the MFMAs that restart the sums
+#endif
 #define ADC_Q16_SCAP 256           // survivor entries per wave held in LDS between flushes
 __host__ __device__ constexpr int adc_q16_pos(int h32) {
     return (h32 < 4) ? h32 : (h32 < 12) ? h32 - 4 : (h32 < 16) ? h32 - 8 : (h32 < 20) ? h32 - 8 : (h32 < 28) ? h32 - 12 : h32 - 16;
@@ -825,7 +828,8 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     constexpr int NV = R / 4;                                 // 16-byte code loads per lane and step
     constexpr bool PACK = ADC_Q16_PACK != 0;                  // accumulators as int16 pairs between phases (|sum| <= 128 M)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+    // wv in an SGPR: everything derived from it (table pieces, code addresses, survivor list) is scalar + lane offset
+    const int tid = threadIdx.x, l = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = l & 15, g = l >> 4;
     const unsigned xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3;
     unsigned group, btile;
@@ -912,7 +916,16 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
         scount = 0;
     };
     // survivor test of one chunk's sums (D[row = 4 g + e][column = r]); survivors go to the wave's LDS list
+    // survivor test of one chunk's sums (D[row = 4 g + e][column = r]); survivors go to the wave's LDS list.  Round 6: this path
+    // is not rare — ~9 k survivors per query of 8.84 M rows at k = 1000 = 0.25 per chunk of 16 rows x 16 queries, one chunk in
+    // five has one — and with it compiled out the kernel is 5-10 % (M = 48) to 15 % (M = 32) faster.  A branch-free form (four
+    // compares into scalar masks, one capacity check, range test only for the index's last chunks) measured 4 % SLOWER than
+    // this one (128 VGPRs, the masks of all four sums computed for every tested chunk): profiles/r06c_adc_keep_chunk.txt.
     auto test_chunk = [&](const adc_i32x4v& v, unsigned rbase) {
+#ifdef ADC_EXP_NOSURV          // A/B timing only (tools/adc_ab.sh): the sums are consumed by one cheap instruction, no test
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        return;
+#endif
         const int top = max(max(v[0], v[1]), max(v[2], v[3]));
         if (__ballot(top >= tq)) {
 #pragma unroll
@@ -922,7 +935,9 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
                 const unsigned long long mask = __ballot(hit);
                 if (mask) {                                       // wave-uniform
                     if (scount + 64 > SCAP) flush_survivors();
-                    if (hit) sbuf[scount + __popcll(mask & ((1ull << l) - 1ull))] = (n << 4) | (unsigned)r;
+                    // position among the hits below this lane: v_mbcnt (no lane-mask registers kept live through the chunk loop)
+                    if (hit) sbuf[scount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] =
+                        (n << 4) | (unsigned)r;
                     scount += (int)__popcll(mask);
                 }
             }
@@ -996,10 +1011,24 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             if (more_in_flight) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
         };
-        auto fold = [&](int c, const adc_u32x4v (&e)[4]) {
+        auto fold = [&](int c, adc_u32x4v (&e)[4], bool more_in_flight) {
+            (void)more_in_flight;
             if constexpr (!PACK) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+#ifdef ADC_EXP_WAIT1            // A/B: every MFMA waits for its own gather only (lgkmcnt counts down one at a time)
+                    if (more_in_flight) {
+                        if (j == 0) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(e[0]));
+                        else if (j == 1) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(e[1]));
+                        else if (j == 2) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(e[2]));
+                        else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[3]));
+                    } else {
+                        if (j == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(e[0]));
+                        else if (j == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[1]));
+                        else if (j == 2) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(e[2]));
+                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[3]));
+                    }
+#endif
                     const adc_i32x4v a = {(int)e[j][0], (int)e[j][1], (int)e[j][2], (int)e[j][3]};
                     acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
                 }
@@ -1026,7 +1055,8 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
         // A round's sums start from explicitly cleared accumulators (32 v_mov per 96 gathers): round 3 gave the round's first
         // MFMA a literal-zero C instead, which put a scalar branch into every chunk and the MFMAs into basic blocks of their
         // own — the loop body is straight-line now (8.62 -> 8.38 ms per 1200 queries at M = 48; with the hand-counted waits 8.26).
-        if constexpr (!PACK) {
+        constexpr bool LATE = ADC_Q16_LATE_TEST != 0 && !PACK;
+        if constexpr (!PACK && !LATE) {
             if (first) {
 #pragma unroll
                 for (int c = 0; c < R; ++c) acc[c] = adc_i32x4v{0, 0, 0, 0};
@@ -1050,18 +1080,46 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             // of chunks c - 2 .. c + 1 are used up, so the same chunks' codes of the step after next go there.  No extra
             // registers, and the phase change no longer waits for a load issued at the start of the step it ends:
             // 7.95 -> 7.62 ms per 1200 queries at M = 48 (M = 96: -3 %; M = 32, which has no phase change: unchanged).
+#ifndef ADC_EXP_NOLOAD          // A/B timing only: the step's codes are reused for every later step
             if ((c & 3) == 2 && it + 2 < nsteps) w[c >> 2] = load_quad(it + 2, c >> 2);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LATE) {
+                // Round 6.  The survivor test of a round used to follow its last MFMAs directly: every wave then sat through the
+                // matrix pipe's latency (four dependent MFMAs per chunk, queued behind the SIMD's other waves) with no gather in
+                // flight, once per round.  Now the sums of chunks c, c + 1 of the PREVIOUS round are tested here, in the
+                // round's first step, behind the gathers just issued and right before the MFMAs that restart them from zero:
+                // their MFMAs are a whole step old, nothing is waited for, and the test's VALU work overlaps LDS latency.
+                // Worth 1-2 % (M = 48: 7.41 -> 7.28, 7.50 -> 7.38 ms; M = 96: 14.7 -> 14.4; profiles/r06b_adc_late_test.txt):
+                // the cost of the survivor path is its instructions (see test_chunk), not this wait.
+                if (first) {                                      // block-uniform
+                    if (it > 0) {
+                        const int top = max(max(max(acc[c][0], acc[c][1]), max(acc[c][2], acc[c][3])),
+                                            max(max(acc[c + 1][0], acc[c + 1][1]), max(acc[c + 1][2], acc[c + 1][3])));
+                        if (__ballot(top >= tq)) {
+                            test_chunk(acc[c], r0 - (unsigned)ROUND + 16u * c);
+                            test_chunk(acc[c + 1], r0 - (unsigned)ROUND + 16u * (c + 1));
+                        }
+                    }
+                    acc[c] = adc_i32x4v{0, 0, 0, 0};
+                    acc[c + 1] = adc_i32x4v{0, 0, 0, 0};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifndef ADC_EXP_WAIT1
             gather_wait(ea, true);
-            fold(c, ea);
+#endif
+            fold(c, ea, true);
             __builtin_amdgcn_sched_barrier(0);
             if (c + 2 < R) gather(c + 2, ea);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef ADC_EXP_WAIT1
             gather_wait(eb, c + 2 < R);
-            fold(c + 1, eb);
+#endif
+            fold(c + 1, eb, c + 2 < R);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!PACK) {
+        if constexpr (!PACK && !LATE) {
             if (last) {
                 // A wave's round holds 128 rows x 16 queries: about every third round has a survivor (2e-4 per pair), so the
                 // test is made per CHUNK (one max3 pair + compare + ballot each) and only a chunk that has one is scanned.
@@ -1092,6 +1150,13 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     for (int it = 0; it < nsteps; it += 2) {                 // block-uniform
         run_step(it, wa);                                    // even steps live in wa, odd ones in wb
         if (it + 1 < nsteps) run_step(it + 1, wb);
+    }
+    if constexpr (ADC_Q16_LATE_TEST != 0 && !PACK) {        // the tile's last round has no next step to be tested in
+        if (nsteps > 0) {
+            const unsigned rl = (unsigned)(nrounds - 1) * ROUND + (unsigned)(wv * R * 16);
+#pragma unroll
+            for (int c = 0; c < R; ++c) test_chunk(acc[c], rl + 16u * c);
+        }
     }
     flush_survivors();
 }

@@ -153,14 +153,23 @@ class RepCONC(nn.Module):
 def sinkhorn_algorithm(out: Tensor, epsilon: float, sinkhorn_iterations: int, use_distrib_train: bool) -> Tensor:
     """Transport plan Q [M,K,B] fp64 whose columns sum to 1 — modeling_repconc.py:137-165.
 
-    `out` must hold fp32-representable values (it does in RepCONC.quantize, which passes
-    `-centred.double().transpose(1,2)`): the kernels stream the fp32 table.  The plan is rebuilt
-    from the row potentials f after `sinkhorn_iterations` iterations: Q[:,:,b] = softmax_k(out/eps + f)."""
+    The plan is rebuilt from the row potentials f after `sinkhorn_iterations` iterations:
+    Q[:,:,b] = softmax_k(out/eps + f).  A tensor of fp32-representable values (what RepCONC.quantize passes:
+    `-centred.double().transpose(1,2)`) runs on the streaming sweep over the fp32 table; any other fp64
+    tensor on the general fp64 kernels (rc_sk64_rows / rc_sk64_cols) — same potentials, the caller's data."""
     if out.dim() != 3:
         raise ValueError("out must be [M, K, B]")
+    distributed = bool(use_distrib_train and dist.get_world_size() > 1)
     d = (-out).transpose(1, 2).contiguous().float()
-    if not torch.equal(d.double(), (-out).transpose(1, 2)):
-        raise NotImplementedError("sinkhorn_algorithm: the cost matrix must be exactly representable in fp32")
+    exact32 = torch.equal(d.double(), (-out).transpose(1, 2)) if d.numel() else True
+    if distributed:       # every rank must take the same route
+        t = torch.tensor([0.0 if exact32 else 1.0], dtype=torch.float64, device=out.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exact32 = float(t.item()) == 0.0
+    if not exact32:
+        o64 = out.double().contiguous()
+        f = ops.sinkhorn_potentials_f64(o64, epsilon, sinkhorn_iterations, TorchDistComm().allgather if distributed else None)
+        return torch.softmax(o64 / epsilon + f[:, :, None], dim=1)
     # the sweeps take a centred table (|d| <= 1, as center_distance_for_constraint produces): a wider one is rescaled
     # together with eps by a power of two — L = d/eps is unchanged, bit for bit
     amax = float(d.abs().max()) if d.numel() else 0.0

@@ -145,6 +145,37 @@ def centre_(d: torch.Tensor, minmax: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- Sinkhorn stages
+def sinkhorn_potentials_f64(out: torch.Tensor, eps: float, iters: int, allgather=None) -> torch.Tensor:
+    """Row potentials f [M,K] (fp64) of `iters` Sinkhorn iterations on ANY fp64 cost tensor out [M,K,B] (this rank's columns) —
+    rc_sk64_rows / rc_sk64_cols, modeling_repconc.py:137-165.  `allgather(t[M,K]) -> [G,M,K]` moves the row values between
+    ranks (None: one rank).  The plan is softmax_k(out / eps + f)."""
+    _need_cuda(out)
+    if out.dtype != torch.float64 or out.dim() != 3 or out.shape[1] != K:
+        raise _lib.RepconcHipError(f"out must be fp64 [M, {K}, B], got {out.dtype} {tuple(out.shape)}")
+    out = out.contiguous()
+    M, _, B = out.shape
+    lib, h, s, _ = _ctx(out)
+    dev = out.device
+    lse = torch.empty((M, K), dtype=torch.float64, device=dev)
+    f = torch.empty((M, K), dtype=torch.float64, device=dev)
+    g = torch.empty((M, max(B, 1)), dtype=torch.float64, device=dev)
+    gather = allgather if allgather is not None else (lambda t: t.unsqueeze(0))
+
+    def rows(gp):
+        _lib.check(lib.rc_sk64_rows(h, _p(out), _p(gp), B, M, K, float(eps), _p(lse), s), "rc_sk64_rows", h)
+
+    def cols(want_g):
+        lg = gather(lse).contiguous()
+        _lib.check(lib.rc_sk64_cols(h, _p(out), _p(lg), lg.shape[0], B, M, K, float(eps), _p(f), _p(g if want_g else None), s),
+                   "rc_sk64_cols", h)
+    rows(None)
+    for _ in range(1, int(iters)):
+        cols(True)
+        rows(g)
+    cols(False)
+    return f
+
+
 class SinkhornState:
     """Device buffers of one rank's Sinkhorn solve over a centred table d [M,B,K] (staged C ABI).
 

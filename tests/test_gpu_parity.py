@@ -1,5 +1,6 @@
 """Parity of the HIP path (through the C ABI) with the reference's golden vectors and the oracle.
 Bit-exact for codes and for the fp32 distance / centring stage."""
+import ctypes
 import os
 import zlib
 
@@ -393,6 +394,23 @@ def test_adc_large_index_properties():
     assert bool(((s > kth).sum(1) <= inside).all())
 
 
+@pytest.mark.parametrize("M", [48, 96])
+def test_adc_full_size_index_against_the_oracle(M):
+    """The flat search at the BASELINE index size (8 841 823 rows, k = 1000; M = 48: headline 2, M = 96: configs[3]'s flat
+    leg) against the C restatement of Faiss's IndexPQ search over the WHOLE index: ids and score bits of 8 queries
+    (the full-size tests compared properties only; the oracle comparison lived in bench.py)."""
+    from repconc_amd import ops
+    N, nq, k = 8841823, 8, 1000
+    C = synth.gaussian(3100 + M, (M, 256, 768 // M))
+    gen = torch.Generator(device=DEV).manual_seed(3200 + M)
+    codes = torch.randint(0, 256, (N, M), dtype=torch.uint8, device=DEV, generator=gen)
+    q = synth.gaussian(3300 + M, (nq, 768))
+    scores, ids = ops.adc_search(codes, _t(C), _t(q), k)
+    want_s, want_i = c_oracle.adc_search(codes.cpu().numpy(), C, q, k)
+    assert np.array_equal(ids.cpu().numpy(), want_i)
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), want_s.view(np.uint32))
+
+
 def test_ivf_baseline_size_properties():
     """BASELINE configs[3] at its full size (8.84 M x 96 B in 5000 cells, nprobe 128, k = 1000): the list-centric search
     (pipelined 8-bit screen, streams, bucket pass, exact rescoring) equals the per-query exact scan — an independent
@@ -420,6 +438,12 @@ def test_ivf_baseline_size_properties():
     assert bool((s1[:, :-1] >= s1[:, 1:]).all()) and int(i1[0, 0]) == victim
     hit_cells = cells[i1.reshape(-1)].reshape(nq, k)
     assert bool((hit_cells.unsqueeze(2) == probes.long().unsqueeze(1)).any(2).all())
+    # ... and against the ORACLE at this size (brute-force restatement: its own probe selection, flat ADC arithmetic over the
+    # rows of the probed cells, (score desc, id asc)): ids and score bits of 4 queries
+    want_s, want_i = pq_oracle.ivf_search(q[:4].cpu().numpy(), C.cpu().numpy(), codes.cpu().numpy(), cells.cpu().numpy(),
+                                          ivf.coarse.cpu().numpy(), k, nprobe)
+    assert np.array_equal(i1[:4].cpu().numpy(), want_i)
+    assert np.array_equal(s1[:4].cpu().numpy().view(np.uint32), want_s.view(np.uint32))
 
 
 # ------------------------------------------------------------------------------------------- model API
@@ -509,6 +533,58 @@ def test_sinkhorn_algorithm_plan_against_the_references_plan(name):
     assert np.array_equal(Qn.argmax(1).astype(np.uint8), p["argmax"])
     np.testing.assert_allclose(Qn.reshape(-1)[p["sample_index"]], p["sample_q"], rtol=1e-9, atol=1e-30)
     np.testing.assert_allclose(Qn.sum(1), 1.0, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["m6_b384_eps003", "m3_b1000_eps05"])
+def test_sinkhorn_algorithm_on_a_cost_tensor_that_is_not_fp32_representable(name):
+    """`sinkhorn_algorithm` takes ANY fp64 tensor (modeling_repconc.py:137-141); round 5 raised NotImplementedError unless the
+    values were fp32-representable.  out = uniform(-1, 1) in fp64 goes through rc_sk64_rows / rc_sk64_cols; the plan is compared
+    with what the REFERENCE's sinkhorn_algorithm returned on the same tensor (tests/golden/plan64_<case>.npz, gen_golden.py
+    --plan64): every column's argmax exact, 4096 sampled entries to 1e-9 relative (+ 1e-300 absolute) — log-domain potentials
+    against the reference's in-place normalisations —, columns sum to 1.  Then the same solve as TWO ranks (column shards, the
+    [2,M,K] row values exchanged by hand between the raw C entries in lockstep): potentials equal the one-rank ones to 1e-12."""
+    from repconc_amd import _lib, ops
+    from repconc_amd.models.repconc import sinkhorn_algorithm
+    p = np.load(os.path.join(os.path.dirname(__file__), "golden", f"plan64_{name}.npz"))
+    M, B, eps, iters = int(p["M"]), int(p["B"]), float(p["eps"]), int(p["iters"])
+    out = np.random.default_rng(int(p["seed"])).uniform(-1.0, 1.0, (M, 256, B))
+    assert zlib.crc32(out.tobytes()) == int(p["out_crc"])
+    ot = torch.from_numpy(out).to(DEV)
+    Q = sinkhorn_algorithm(ot, eps, iters, False)
+    Qn = Q.cpu().numpy()
+    assert Q.dtype == torch.float64 and Qn.shape == (M, 256, B)
+    assert np.array_equal(Qn.argmax(1).astype(np.uint8), p["argmax"])
+    np.testing.assert_allclose(Qn.reshape(-1)[p["sample_index"]], p["sample_q"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(Qn.sum(1), 1.0, rtol=1e-12)
+    # two ranks in lockstep through the raw entries
+    f1 = ops.sinkhorn_potentials_f64(ot, eps, iters)
+    lib, h = _lib.load(), _lib.handle(0)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cut = B // 3
+    sh = [ot[:, :, :cut].contiguous(), ot[:, :, cut:].contiguous()]
+    lse = torch.empty((2, M, 256), dtype=torch.float64, device=DEV)
+    f = [torch.empty((M, 256), dtype=torch.float64, device=DEV) for _ in range(2)]
+    g = [torch.empty((M, x.shape[2]), dtype=torch.float64, device=DEV) for x in sh]
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    def rows(gs):
+        for r in range(2):
+            _lib.check(lib.rc_sk64_rows(h, P(sh[r]), P(gs[r]) if gs else None, sh[r].shape[2], M, 256, eps, P(lse[r]), s), "rows", h)
+    def cols(want_g):
+        for r in range(2):
+            _lib.check(lib.rc_sk64_cols(h, P(sh[r]), P(lse), 2, sh[r].shape[2], M, 256, eps, P(f[r]), P(g[r]) if want_g else None, s),
+                       "cols", h)
+    rows(None)
+    for _ in range(1, iters):
+        cols(True)
+        rows(g)
+    cols(False)
+    assert torch.equal(f[0], f[1])
+    np.testing.assert_allclose(f[0].cpu().numpy(), f1.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    # a tensor that IS fp32-representable still takes the streaming sweep and agrees with the general kernels
+    o32 = ot.float().double()
+    np.testing.assert_allclose(sinkhorn_algorithm(o32, eps, iters, False).cpu().numpy(),
+                               torch.softmax(o32 / eps + ops.sinkhorn_potentials_f64(o32, eps, iters)[:, :, None], dim=1).cpu().numpy(),
+                               rtol=1e-9, atol=1e-300)
 
 
 def test_index_build_and_search_api():

@@ -69,6 +69,23 @@ def test_numpy_oracle_plan_equals_the_references_plan(name):
     assert np.array_equal(p["argmax"].T, g["codes_constrained"])          # the plan's argmax IS the fixture's codes
 
 
+@pytest.mark.parametrize("name", ["m6_b384_eps003", "m3_b1000_eps05"])
+def test_numpy_oracle_plan_on_a_general_fp64_cost_tensor_equals_the_references(name):
+    """tests/golden/plan64_<case>.npz (gen_golden.py --plan64): the reference's `sinkhorn_algorithm` on out = uniform(-1, 1) in
+    fp64 — NOT fp32-representable, the generality of modeling_repconc.py:137-141 — against pq_oracle.sinkhorn_q (same sequence of
+    fp64 operations: 1e-12 relative) and, as two column shards, its rank-ordered restatement of :149-157."""
+    import zlib
+    p = np.load(os.path.join(os.path.dirname(__file__), "golden", f"plan64_{name}.npz"))
+    M, B, eps, iters = int(p["M"]), int(p["B"]), float(p["eps"]), int(p["iters"])
+    out = np.random.default_rng(int(p["seed"])).uniform(-1.0, 1.0, (M, 256, B))
+    assert zlib.crc32(out.tobytes()) == int(p["out_crc"])
+    Q = pq_oracle.sinkhorn_q([out.copy()], eps, iters)[0]
+    assert np.array_equal(Q.argmax(1).astype(np.uint8), p["argmax"])
+    np.testing.assert_allclose(Q.reshape(-1)[p["sample_index"]], p["sample_q"], rtol=1e-12, atol=1e-300)
+    Q2 = np.concatenate(pq_oracle.sinkhorn_q([out[:, :, :B // 2].copy(), out[:, :, B // 2:].copy()], eps, iters), axis=2)
+    np.testing.assert_allclose(Q2, Q, rtol=1e-11, atol=1e-300)
+
+
 def test_numpy_oracle_decode_gradient_and_normalisation_equal_the_references():
     """tests/golden/aux_m48_b1024.npz (gen_golden.py --aux): the gradient the reference's autograd sends to the centroids
     through `decode` (modeling_repconc.py:168-175) and its `normalize_centrodis` (:112-116) — pq_oracle.decode_bwd /

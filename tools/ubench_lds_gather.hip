@@ -27,7 +27,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int NG, int KIND, bool MFMA, int THREADS, int ADDR>
 __global__ __launch_bounds__(THREADS) void k(unsigned* out, long long* cyc, unsigned seed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    for (int i = threadIdx.x; i < 128 * 1024 / 16; i += THREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(i, i * 3, i * 5, i * 7);
+    constexpr int SMEM = (KIND == 5) ? 147456 : 128 * 1024;
+    for (int i = threadIdx.x; i < SMEM / 16; i += THREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(i, i * 3, i * 5, i * 7);
     __syncthreads();
     const int l = threadIdx.x & 63;
     unsigned rnd = seed + threadIdx.x * 2654435761u + blockIdx.x * 40503u;
@@ -54,7 +55,81 @@ __global__ __launch_bounds__(THREADS) void k(unsigned* out, long long* cyc, unsi
         unsigned w[NG / 4];
 #pragma unroll
         for (int j = 0; j < NG / 4; ++j) { rnd = __umul24(rnd, 0x6255u) + 0x3c6ef35fu + j; w[j] = rnd; }   // 1-2 full-rate VALU per 4 gathers
-        if constexpr (KIND == 3) {
+        if constexpr (KIND == 4) {
+            // round 6: ds_read_b96 at 16-BYTE ALIGNED addresses ([code][16 slots][16 B], the b128 layout, 12 of 16 bytes read):
+            // the guide's table says 8 lane groups of 8 = 8 LDS cycles per wave-instruction; measured here
+            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+            u32x3 e[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const unsigned addr = __builtin_amdgcn_perm(w[g >> 2], base + (unsigned)(g & 1) * 65536u + (unsigned)((pos128 + g) & 15) * 16u,
+                                                            0x03020000u | ((4u + (unsigned)(g & 3)) << 8));
+                e[g] = *reinterpret_cast<const u32x3 __attribute__((address_space(3)))*>(addr);
+            }
+            if constexpr (MFMA) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const i32x4 a = {(int)e[g].x, (int)e[g].y, (int)e[g].z, 0};
+                    macc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, macc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { acc0 ^= e[g].x ^ e[g].z; acc1 += e[g].y; }
+            }
+        } else if constexpr (KIND == 5) {
+            // round 6: the 12-query ALL-RESIDENT candidate at M = 48 (48 x 256 x 12 B = 144 KiB) without ds_read_b96: two planes,
+            // [code][16 slots][8 B] (queries 0-7, rows of 128 B, ds_read_b64) + [code][16 slots][4 B] (queries 8-11, rows of 64 B,
+            // ds_read_b32); three blocks of 16 sub-quantisers = 3 x (32 + 16) KiB.  Rows shorter than 256 B: whether two lanes of a
+            // service group collide depends on their codes.
+            uint2 e8[NG]; unsigned e4[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const unsigned code = (w[g >> 2] >> (8 * (g & 3))) & 255u;
+                const unsigned slot = (unsigned)((pos128 + g) & 15);
+                const unsigned blk = (unsigned)(g % 3) * 49152u;
+                const unsigned a8 = base + blk + code * 128u + slot * 8u;
+                const unsigned a4 = base + blk + 32768u + code * 64u + slot * 4u;
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 v = *reinterpret_cast<const u32x2 __attribute__((address_space(3)))*>(a8);
+                e8[g] = make_uint2(v.x, v.y);
+                e4[g] = *reinterpret_cast<const unsigned __attribute__((address_space(3)))*>(a4);
+            }
+            if constexpr (MFMA) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const i32x4 a = {(int)e8[g].x, (int)e8[g].y, (int)e4[g], 0};
+                    macc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, macc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { acc0 ^= e8[g].x ^ e4[g]; acc1 += e8[g].y; }
+            }
+        } else if constexpr (KIND == 6) {
+            // round 6: the 6-bit candidate WITHOUT the matrix pipe — 16-query b128 gathers of 6-bit entries (one byte each); four
+            // gathers are added as packed bytes (4 x 63 < 256: one v_add_u32 per dword), then widened to 16-bit pairs and added to
+            // eight packed accumulators (v_and / v_lshr + v_and, two v_pk_add_u16 per dword): 4 + 5 VALU per gather
+            uint4 e[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const unsigned addr = __builtin_amdgcn_perm(w[g >> 2], base + (unsigned)(g & 1) * 65536u + (unsigned)((pos128 + g) & 15) * 16u,
+                                                            0x03020000u | ((4u + (unsigned)(g & 3)) << 8));
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = *reinterpret_cast<const u32x4 __attribute__((address_space(3)))*>(addr);
+                e[g] = make_uint4(v.x & 0x3F3F3F3Fu, v.y & 0x3F3F3F3Fu, v.z & 0x3F3F3F3Fu, v.w & 0x3F3F3F3Fu);   // (the real table holds 6-bit bytes)
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g += 4) {
+                unsigned sx = e[g].x + e[g + 1].x + e[g + 2].x + e[g + 3].x, sy = e[g].y + e[g + 1].y + e[g + 2].y + e[g + 3].y;
+                unsigned sz = e[g].z + e[g + 1].z + e[g + 2].z + e[g + 3].z, sw = e[g].w + e[g + 1].w + e[g + 2].w + e[g + 3].w;
+                // widen: even / odd bytes -> u16 pairs, packed adds (carry-free: 48 x 63 < 65536)
+                acc0 += (sx & 0x00FF00FFu) + (sy & 0x00FF00FFu);
+                acc1 += ((sx >> 8) & 0x00FF00FFu) + ((sy >> 8) & 0x00FF00FFu);
+                macc[0] += (int)(sz & 0x00FF00FFu);
+                macc[1] += (int)((sz >> 8) & 0x00FF00FFu);
+                macc[2] += (int)(sw & 0x00FF00FFu);
+                macc[3] += (int)((sw >> 8) & 0x00FF00FFu);
+            }
+        } else if constexpr (KIND == 3) {
             // ds_read_b96: dense 12-byte entries, [block of 16 sub-quantisers][code][16 slots][12 B] (192-byte rows: a code
             // shifts the banks by 48 mod 64, so lanes with different codes can collide - what does that cost?)
             typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
@@ -156,18 +231,19 @@ void run(const char* name, int blocks) {
     unsigned* out; long long* cyc;
     hipMalloc(&out, (size_t)blocks * THREADS * 4); hipMalloc(&cyc, (size_t)blocks * 16);
     auto kern = k<NG, KIND, MFMA, THREADS, ADDR>;
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    constexpr int SMEM = (KIND == 5) ? 147456 : 128 * 1024;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     // one launch to size the warm-up
     hipEventRecord(a, 0);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(THREADS), 128 * 1024, 0, out, cyc, 1u);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(THREADS), SMEM, 0, out, cyc, 1u);
     hipEventRecord(b, 0); hipEventSynchronize(b);
     float ms0; hipEventElapsedTime(&ms0, a, b);
     const int nwarm = (int)(g_warm_ms / (ms0 > 0.01f ? ms0 : 0.01f)) + 1;
-    for (int i = 0; i < nwarm; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(THREADS), 128 * 1024, 0, out, cyc, 3u + i);
+    for (int i = 0; i < nwarm; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(THREADS), SMEM, 0, out, cyc, 3u + i);
     const int nrep = 20;
     hipEventRecord(a, 0);
-    for (int i = 0; i < nrep; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(THREADS), 128 * 1024, 0, out, cyc, 2u);
+    for (int i = 0; i < nrep; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(THREADS), SMEM, 0, out, cyc, 2u);
     hipEventRecord(b, 0);
     const std::string sclk = sysfs_sclk();            // sampled while the queue above is still running
     hipEventSynchronize(b);
@@ -175,7 +251,7 @@ void run(const char* name, int blocks) {
     std::vector<long long> hc(2 * blocks); hipMemcpy(hc.data(), cyc, (size_t)blocks * 16, hipMemcpyDeviceToHost);
     double cy = 0, wl = 0; for (int i = 0; i < blocks; ++i) { cy += hc[2 * i]; wl += hc[2 * i + 1]; } cy /= blocks; wl /= blocks;
     const double instr_per_cu = (THREADS / 64.0) * ITERS * NG;    // wave-instructions per CU (one block per CU)
-    const double bytes = (KIND == 2 ? 1024.0 : KIND == 3 ? 768.0 : 512.0);
+    const double bytes = ((KIND == 2 || KIND == 6) ? 1024.0 : (KIND == 3 || KIND == 4 || KIND == 5) ? 768.0 : 512.0);
     const double ghz = cy / (wl * 10.0);                          // wall_clock64 ticks are 10 ns
     const double ns = ms * 1e6 / instr_per_cu;
     printf("%-34s %s blk %3d thr %4d | launch %.3f ms (cold %.3f) | %5.2f ns = %5.2f cyc per gather per CU (wave 0 alone: %4.2f) | clock %.2f GHz (sysfs %s) | %5.1f B/clk/CU | chip %5.1f TB/s\n",
@@ -212,6 +288,18 @@ int main(int argc, char** argv) {
         run<16, 2, true, 512, 2>("b128 cf 16 + 16 MFMA", 256);
         run<8, 2, false, 1024, 2>("b128 cf 8, no MFMA", 256);
         run<4, 2, false, 1024, 2>("b128 cf 4, no MFMA", 256);
+        return 0;
+    }
+    if (argc > 2 && !strcmp(argv[2], "r6")) {                // round 6: the all-resident candidates of VERDICT r5 (12 queries; 6-bit without MFMA)
+        run<12, 2, true, 1024, 2>("b128 16q (shipped loop) 12 + 12 MFMA", 256);
+        run<12, 2, false, 1024, 2>("b128 16q, no MFMA", 256);
+        run<12, 4, false, 1024, 2>("b96 aligned 12q, no MFMA", 256);
+        run<12, 4, true, 1024, 2>("b96 aligned 12q 12 + 12 MFMA", 256);
+        run<12, 3, true, 1024>("b96 dense 12-byte rows 12 + 12 MFMA", 256);
+        run<12, 5, false, 1024, 2>("b64+b32 planes 12q, no MFMA", 256);
+        run<12, 5, true, 1024, 2>("b64+b32 planes 12q 12 + 12 MFMA", 256);
+        run<12, 6, false, 1024, 2>("b128 16q 6-bit, packed adds, no MFMA", 256);
+        run<24, 6, false, 1024, 2>("b128 16q 6-bit, packed adds (24)", 256);
         return 0;
     }
     if (argc > 2 && !strcmp(argv[2], "b96")) {               // the question of the 12-query single-phase screen only
