@@ -734,7 +734,7 @@ def main():
         cu_ms = e0.elapsed_time(e1) / 5
         del xc, cu_ws, cu_cent, cu_assign
         # ---- the index ("IVF measured as retrieval, not as a scan"): a clustered synthetic corpus (512 Gaussian
-        # clusters, weaker than the flat leg's: 0.5 centre + 0.5 noise; 8 841 823 rows, generated chunk by chunk), PQ centroids Lloyd-refined on its first 65 536
+        # clusters, weaker than the flat leg's: 0.3 centre + 0.5 noise; 8 841 823 rows, generated chunk by chunk), PQ centroids Lloyd-refined on its first 65 536
         # rows, the coarse quantiser TRAINED on its first 2^20 rows (10 Lloyd iterations of rc_ivf_coarse_assign /
         # rc_ivf_coarse_update, Faiss's default for an IVF coarse quantiser), every row coded (nearest codes) and sent to its
         # L2-nearest cell.  Queries = noisy copies of corpus rows: the copied row is the query's one relevant passage.
@@ -744,7 +744,7 @@ def main():
         def corpus_chunk3(i, rows):
             gi = torch.Generator(device=dev).manual_seed(20231 + i)
             a_ = torch.randint(0, centers3.shape[0], (rows,), device=dev, generator=gi)
-            return (0.5 * centers3[a_] + 0.5 * torch.randn((rows, D), device=dev, generator=gi)).contiguous()
+            return (0.3 * centers3[a_] + 0.5 * torch.randn((rows, D), device=dev, generator=gi)).contiguous()
         chunk3 = 1 << 20
         x0 = corpus_chunk3(0, chunk3)
         perm3 = torch.randperm(1 << 16, device=dev, generator=gcl3)[:K]
@@ -762,7 +762,7 @@ def main():
         coarse_train_s = time.perf_counter() - t0
         nq_dev = 6980
         rel = torch.from_numpy(np.sort(np.random.default_rng(20232).permutation(chunk3)[:nq_dev]).copy()).to(dev)   # rows of chunk 0
-        q_dev = (x0[rel] + 1.0 * torch.randn((nq_dev, D), device=dev, generator=gcl3)).contiguous()
+        q_dev = (x0[rel] + 2.0 * torch.randn((nq_dev, D), device=dev, generator=gcl3)).contiguous()
         codes3 = torch.empty((N_CORPUS, M3), dtype=torch.uint8, device=dev)
         cells3 = torch.empty((N_CORPUS,), dtype=torch.int64, device=dev)
         t0 = time.perf_counter()
@@ -844,7 +844,7 @@ def main():
         ivf_gather = nq_batch * rows128 * M3 / (ivf_scan_ms * 1e-3) / 1e9 if n_l.value else 0.0   # 1 B per (row, m, query)
         out["ivf"] = {
             "metric": "ivf_adc_queries_per_sec", "unit": "queries/s", "k": k, "nlist": nlist, "M": M3,
-            "index": f"{N_CORPUS} x {M3} B: nearest codes of a clustered synthetic corpus (512 Gaussian clusters, 0.5 centre + 0.5 noise) in {nlist} cells of "
+            "index": f"{N_CORPUS} x {M3} B: nearest codes of a clustered synthetic corpus (512 Gaussian clusters, 0.3 centre + 0.5 noise) in {nlist} cells of "
                      "a coarse quantiser trained on its first 2^20 rows (10 Lloyd iterations), rows in their L2-nearest cell, no "
                      "residual coding",
             "cells": {"rows_min": int(cell_sizes.min()), "rows_max": int(cell_sizes.max()),
@@ -852,7 +852,7 @@ def main():
             "build": {"coarse_training_s": round(coarse_train_s, 3), "coding_and_cell_assignment_s": round(ivf_build_s, 3),
                       "what": "coarse_kmeans on 2^20 rows; then nearest codes + nearest cell of all rows in 2^20-row chunks "
                               "(wall time incl. generating the synthetic rows)"},
-            "queries": "6980 noisy copies (sigma 1.0 per coordinate: |noise| = 1.4 x |row|) of corpus rows; the copied row is the one relevant passage",
+            "queries": "6980 noisy copies (sigma 2.0 per coordinate: |noise| = 3.4 x |row|) of corpus rows; the copied row is the one relevant passage",
             "queries_per_sec": sweep3_all, "queries_per_call": 6980,
             "retrieval": retrieval, "retrieval_summary": retrieval_summary,
             "queries_per_sec_1200_query_calls": sweep3, "nprobe_equals_nlist_matches_flat_search": same3,

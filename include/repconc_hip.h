@@ -317,6 +317,14 @@ int rc_adc_scan_image_rows(rc_handle_t h, const uint8_t* codes, int64_t n0, int6
  * = byte offset of codes[n][m] in it, -1 for arguments out of range: image[at(n, m)] == codes[n][m] is the whole contract. */
 size_t rc_adc_scan_image_rows_bytes(int64_t N, int M);
 int64_t rc_adc_scan_image_rows_at(int M, int64_t n, int m);
+/* Round 6: the image of the 16-QUERY list-centric screen (rc_ivf_search_probes_q16).  Same blocking by chunks of 16 rows, but a
+ * chunk holds [phase p16 = m / 16][lane = (n mod 16) + 16 g][step j] = codes[n][16 p16 + slot(lane, j)] — the order in which the
+ * lanes of a ds_read_b128 gather visit the sub-quantisers (rc_adc_q16_describe), 4 bytes per lane and phase.
+ * rc_adc_scan_image_rows16_bytes(N, M) bytes; rc_adc_scan_image_rows16_at = byte offset of codes[n][m] (host only). */
+int rc_adc_scan_image_rows16(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
+                             rc_stream_t stream);
+size_t rc_adc_scan_image_rows16_bytes(int64_t N, int M);
+int64_t rc_adc_scan_image_rows16_at(int M, int64_t n, int m);
 /* Round 3: for the M whose flat search runs the 16-query screen (adc_screen_q16_kernel; M = 48 and 96 unless RC_ADC_Q16
  * says otherwise — read once per process) the flat-search image is [n / 32768][phase = m / 16][n % 32768][16 bytes], the 16
  * bytes of a (row, phase) ordered [lane quarter g][step j] = code of sub-quantiser 16 phase + slot(lane = (n & 15) + 16 g, j).
@@ -439,6 +447,16 @@ int rc_ivf_search_probes_q(rc_handle_t h, const uint8_t* codes, const uint8_t* i
                            const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
                            int keep_all_rows, float* scores, int64_t* out_ids, int* status, int* qstatus, void* ws,
                            size_t ws_bytes, rc_stream_t stream);
+/* The same search on the 16-query screen (round 6; evaluate_repconc.py:180-206 with a list-centric index and whole-query-set
+ * calls): tasks of up to 16 queries per probed cell, one ds_read_b128 gather + one i8 MFMA per (16 rows, 4 sub-quantisers,
+ * 16 queries) — per query the same table bytes as the 8-query screen and half the gathers.  image16: rc_adc_scan_image_rows16.
+ * Same workspace (rc_ivf_search_probes_ws_bytes), status bits and RESULTS as rc_ivf_search_probes_q; it pays when a probed
+ * cell is shared by more than ~8 queries of the call (nq x nprobe / nlist). */
+int rc_ivf_search_probes_q16(rc_handle_t h, const uint8_t* codes, const uint8_t* image16, const int64_t* list_off,
+                             const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
+                             const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
+                             int keep_all_rows, float* scores, int64_t* out_ids, int* status, int* qstatus, void* ws,
+                             size_t ws_bytes, rc_stream_t stream);
 size_t rc_ivf_search_ws_bytes(int nq, int64_t stride);
 int rc_ivf_search(rc_handle_t h, const uint8_t* codes, const int64_t* list_off, const int64_t* ids, int64_t N,
                   int M, int K, const float* lut, const int* probes, const int* base, const int* count, int nq,

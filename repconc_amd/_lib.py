@@ -75,6 +75,9 @@ PROTOTYPES = {
     "rc_adc_scan_image_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp]),
     "rc_adc_scan_image_rows_bytes": (_sz, [_i64, _i]),
     "rc_adc_scan_image_rows_at": (_i64, [_i, _i64, _i]),
+    "rc_adc_scan_image_rows16": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp]),
+    "rc_adc_scan_image_rows16_bytes": (_sz, [_i64, _i]),
+    "rc_adc_scan_image_rows16_at": (_i64, [_i, _i64, _i]),
     "rc_adc_search_img_ws_bytes": (_sz, [_i64, _i, _i, _i, _i]),
     "rc_adc_search_ws_counts": (_i, [_i64, _i, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "rc_adc_search_img": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i64, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -94,6 +97,8 @@ PROTOTYPES = {
                                   _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_ivf_search_probes_q": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _i, _d, _i,
                                     _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rc_ivf_search_probes_q16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _i, _d, _i,
+                                      _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_ivf_search_ws_bytes": (_sz, [_i, _i64]),
     "rc_ivf_search": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rc_adc_lut": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

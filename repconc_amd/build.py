@@ -36,7 +36,7 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "rc_common.h"), os.path.join(CSRC, "adc_common.h"),
+    headers = [os.path.join(CSRC, "rc_common.h"), os.path.join(CSRC, "adc_common.h"), os.path.join(CSRC, "ivfs_screen16.h"),
                os.path.join(os.path.dirname(HERE), "include", "repconc_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:

@@ -217,10 +217,18 @@ typedef int adc_i32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned adc_u32x2v __attribute__((ext_vector_type(2)));
 
 // Tasks of the list-centric IVF search: a task = (coarse cell, up to 8 of the queries that probe it)
+// 16-query gathers (ds_read_b128; adc_search.hip 4b'', ivfs_screen16.h): position of a lane inside its service group of 16
+// lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32), and the sub-quantiser (within its phase of 16) = LDS slot
+// that lane `lane` of a wave reads in step j — distinct inside every service group, the four lanes of a row cover all 16
+__host__ __device__ constexpr int adc_q16_pos(int h32) {
+    return (h32 < 4) ? h32 : (h32 < 12) ? h32 - 4 : (h32 < 16) ? h32 - 8 : (h32 < 20) ? h32 - 8 : (h32 < 28) ? h32 - 12 : h32 - 16;
+}
+__host__ __device__ constexpr int adc_q16_slot(int lane, int j) { return (adc_q16_pos(lane & 31) + j + 4 * (lane >> 5)) & 15; }
+
 struct adc_ivf_tasks {
     const int* task_list;        // [tasks] cell of the task
     const int* task_qstart;      // [tasks] first entry of the task's queries in sorted_q
-    const int* task_qcnt;        // [tasks] 1 .. 8 queries
+    const int* task_qcnt;        // [tasks] 1 .. 8 queries (1 .. 16 for the 16-query screen)
     const int* sorted_q;         // query ids ordered by probed cell
     const int64_t* list_off;     // [nlist + 1] row ranges of the cells
     const uint8_t* qbyte;        // [nq][NP][256][PM] per-query byte tables, one byte per sub-quantiser

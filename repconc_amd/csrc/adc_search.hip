@@ -754,11 +754,7 @@ __global__ __launch_bounds__(RC_K) void adc_qstats_kernel(const float* __restric
 #define ADC_Q16_LATE_TEST 1        // 1: a round's survivor test runs one step later, pair by pair, in front of the MFMAs that restart the sums
 #endif
 #define ADC_Q16_SCAP 256           // survivor entries per wave held in LDS between flushes
-__host__ __device__ constexpr int adc_q16_pos(int h32) {
-    return (h32 < 4) ? h32 : (h32 < 12) ? h32 - 4 : (h32 < 16) ? h32 - 8 : (h32 < 20) ? h32 - 8 : (h32 < 28) ? h32 - 12 : h32 - 16;
-}
-// sub-quantiser (within its phase of 16) = LDS slot that lane `lane` of a wave reads in step j
-__host__ __device__ constexpr int adc_q16_slot(int lane, int j) { return (adc_q16_pos(lane & 31) + j + 4 * (lane >> 5)) & 15; }
+// adc_q16_pos / adc_q16_slot: adc_common.h (shared with the 16-query IVF screen)
 
 // Image of rows n0 <= n < n0 + cnt.  Inside a (tile, phase) block of T x 16 bytes the bytes are ordered the way the
 // kernel's waves consume them: [round of 2048 rows][wave][lane = r + 16 g][chunk c][step j], row = 2048 round + 128 wave +

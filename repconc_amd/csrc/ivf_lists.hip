@@ -665,6 +665,8 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
     if (l == 0) stream_cnt[blockIdx.x * IVFS_WAVES + (unsigned)wv] = woff;
 }
 
+#include "ivfs_screen16.h"
+
 // Deal the waves' (query, row) streams to the per-query id lists.  An atomic on one address takes ~0.2 us and the atomics
 // of one address do not overlap: 2.4 M runs (one per wave, task and query) on 1200 counters cost 0.44 ms however many waves
 // issue them.  The sixteen streams of ONE screen block hold the same (task, query) pairs, so one bucket block takes them
@@ -854,7 +856,7 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
                 int64_t N, const float* lut, int nq, const int* probes, const int* sbase, const int* scount,
                 const int* rows, const int* rank, int nprobe, int64_t sstride, int ss, const adc_ivf_tasks& T, int ntasks,
                 int k, float* scores, int64_t* out_ids, int* status, char* w, const ivfl_ws& L, hipStream_t s,
-                int* qstatus = nullptr) {
+                int* qstatus = nullptr, int width = 8) {
     float* sample = (float*)(w + L.sample);
     float* thr = (float*)(w + L.thr);
     int* tint = (int*)(w + L.tint);
@@ -886,7 +888,9 @@ int ivfl_launch(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const
     RC_LAUNCH_CHECK(h);
     RC_HIP_CHECK(h, hipMemsetAsync(w + L.idcnt, 0, L.counters_end - L.idcnt, s));      // idcnt, cnt, stream_cnt
     {
-        auto kern = ivfs_screen_kernel<M, 4>;                 // four loader waves (DESIGN_HISTORY 7: without them 1.04 vs 0.95 ms at nprobe 128)
+        // four loader waves (DESIGN_HISTORY 7: without them 1.04 vs 0.95 ms at nprobe 128); width 16: the 16-query screen
+        // (ivfs_screen16.h; `image` is then the rows16 image and the tasks hold up to 16 queries)
+        auto kern = width == 16 ? ivfs_screen16_kernel<M, 4> : ivfs_screen_kernel<M, 4>;
         constexpr int sl = 2 * IVFS_BUF;
         RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
         adc_ivf_tasks TT = T;
@@ -1078,12 +1082,12 @@ __global__ __launch_bounds__(256) void ivf_plan_query_kernel(const int64_t* __re
 // One block: exclusive prefix sums over the cells of (queries probing the cell) and of (tasks of the cell).
 __global__ __launch_bounds__(256) void ivf_plan_cells_kernel(const int* __restrict__ per_cell, int nlist,
                                                              int* __restrict__ cell_start, int* __restrict__ first_task,
-                                                             int* __restrict__ ntasks) {
+                                                             int* __restrict__ ntasks, int tw) {
     __shared__ int s_wave[4];
     int cq = 0, ct = 0;
     for (int b0 = 0; b0 < nlist; b0 += 256) {
         const int c = b0 + (int)threadIdx.x;
-        const int n = c < nlist ? per_cell[c] : 0, t = (n + 7) / 8;
+        const int n = c < nlist ? per_cell[c] : 0, t = (n + tw - 1) / tw;     // tw = queries per task (8 | 16)
         int tq, tt;
         const int eq = ivfp_block_scan256(n, s_wave, tq);
         const int et = ivfp_block_scan256(t, s_wave, tt);
@@ -1109,7 +1113,7 @@ __global__ __launch_bounds__(256) void ivf_plan_scatter_kernel(const int* __rest
 __global__ __launch_bounds__(256) void ivf_plan_tasks_kernel(const int* __restrict__ per_cell, const int* __restrict__ cell_start,
                                                              const int* __restrict__ first_task, const int* __restrict__ ntasks,
                                                              int nlist, int64_t ub, int* __restrict__ task_list,
-                                                             int* __restrict__ task_qstart, int* __restrict__ task_qcnt) {
+                                                             int* __restrict__ task_qstart, int* __restrict__ task_qcnt, int tw) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ub) return;
     int cell = 0, qs = 0, qc = 0;
@@ -1121,9 +1125,9 @@ __global__ __launch_bounds__(256) void ivf_plan_tasks_kernel(const int* __restri
         }
         cell = lo;
         const int within = (int)t - first_task[cell];
-        qs = cell_start[cell] + 8 * within;
-        qc = per_cell[cell] - 8 * within;
-        qc = qc > 8 ? 8 : qc;
+        qs = cell_start[cell] + tw * within;
+        qc = per_cell[cell] - tw * within;
+        qc = qc > tw ? tw : qc;
     }
     task_list[t] = cell;
     task_qstart[t] = qs;
@@ -1241,11 +1245,11 @@ extern "C" int rc_ivf_search_probes(rc_handle_t h, const uint8_t* codes, const u
 // min(k, rows probed) candidates, bit 1 = its id list overflowed.  The other queries' results stand: a caller answers only
 // the flagged ones again (IVFPQIndex.search: by the per-query exact scan).  A survivor STREAM that filled up (status bit 2)
 // is not attributable to a query and may have dropped anybody's rows: repeat the call with less slack.
-extern "C" int rc_ivf_search_probes_q(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
-                                      const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
-                                      const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
-                                      int keep_all_rows, float* scores, int64_t* out_ids, int* status, int* qstatus, void* ws,
-                                      size_t ws_bytes, rc_stream_t stream) {
+static int ivf_search_probes_w(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
+                               const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
+                               const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
+                               int keep_all_rows, float* scores, int64_t* out_ids, int* status, int* qstatus, void* ws,
+                               size_t ws_bytes, rc_stream_t stream, int width) {
     rc_device_guard device_guard_(h);
     if (!h || !codes || !image || !list_off || !rowmap || !lut || !probes || !scores || !out_ids || !status || N <= 0 ||
         nq < 0 || nprobe <= 0 || nlist <= 0 || nprobe > nlist || sstride <= 0 || ss <= 0 || k <= 0)
@@ -1264,23 +1268,68 @@ extern "C" int rc_ivf_search_probes_q(rc_handle_t h, const uint8_t* codes, const
                        keep_all_rows, I(P.sbase), I(P.scount), I(P.rows), I(P.rank), I(P.per_cell));
     RC_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(ivf_plan_cells_kernel, dim3(1), dim3(256), 0, s, (const int*)I(P.per_cell), nlist, I(P.cell_start),
-                       I(P.first_task), I(P.ntasks));
+                       I(P.first_task), I(P.ntasks), width);
     RC_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(ivf_plan_scatter_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, probes, pairs, nprobe,
                        (const int*)I(P.cell_start), I(P.cursor), I(P.sorted_q));
     RC_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(ivf_plan_tasks_kernel, dim3((unsigned)((P.ub + 255) / 256)), dim3(256), 0, s, (const int*)I(P.per_cell),
                        (const int*)I(P.cell_start), (const int*)I(P.first_task), (const int*)I(P.ntasks), nlist, P.ub,
-                       I(P.task_list), I(P.task_qstart), I(P.task_qcnt));
+                       I(P.task_list), I(P.task_qstart), I(P.task_qcnt), width);
     RC_LAUNCH_CHECK(h);
     adc_ivf_tasks T = {I(P.task_list), I(P.task_qstart), I(P.task_qcnt), I(P.sorted_q), list_off, nullptr, I(P.ntasks)};
     switch (M) {
 #define IVFP_CASE(MM)                                                                                                  \
         case MM: return ivfl_launch<MM>(h, codes, image, list_off, rowmap, N, lut, nq, probes, I(P.sbase), I(P.scount),  \
                                         I(P.rows), I(P.rank), nprobe, sstride, ss, T, (int)P.ub, k, scores, out_ids,  \
-                                        status, w, L, s, qstatus);
+                                        status, w, L, s, qstatus, width);
         IVFP_CASE(16) IVFP_CASE(32) IVFP_CASE(48) IVFP_CASE(64) IVFP_CASE(96)
 #undef IVFP_CASE
         default: return RC_ESHAPE;
     }
+}
+extern "C" int rc_ivf_search_probes_q(rc_handle_t h, const uint8_t* codes, const uint8_t* image, const int64_t* list_off,
+                                      const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
+                                      const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
+                                      int keep_all_rows, float* scores, int64_t* out_ids, int* status, int* qstatus, void* ws,
+                                      size_t ws_bytes, rc_stream_t stream) {
+    return ivf_search_probes_w(h, codes, image, list_off, rowmap, N, nlist, M, K, lut, nq, probes, nprobe, sstride, ss, k, sel_slack,
+                               keep_all_rows, scores, out_ids, status, qstatus, ws, ws_bytes, stream, 8);
+}
+// The same search on the 16-QUERY screen (round 6, ivfs_screen16.h): tasks of up to 16 queries per probed cell, one
+// ds_read_b128 gather per (16 rows, 4 sub-quantisers, 16 queries).  `image16`: rc_adc_scan_image_rows16 of the cell-major codes
+// (rc_adc_scan_image_rows16_bytes(N, M) bytes).  Same workspace, status bits and RESULTS as rc_ivf_search_probes_q; pays when a
+// probed cell is shared by more than ~8 queries of the call (nq x nprobe / nlist; IVFPQIndex.search decides).
+extern "C" int rc_ivf_search_probes_q16(rc_handle_t h, const uint8_t* codes, const uint8_t* image16, const int64_t* list_off,
+                                        const int64_t* rowmap, int64_t N, int nlist, int M, int K, const float* lut, int nq,
+                                        const int* probes, int nprobe, int64_t sstride, int ss, int k, double sel_slack,
+                                        int keep_all_rows, float* scores, int64_t* out_ids, int* status, int* qstatus, void* ws,
+                                        size_t ws_bytes, rc_stream_t stream) {
+    return ivf_search_probes_w(h, codes, image16, list_off, rowmap, N, nlist, M, K, lut, nq, probes, nprobe, sstride, ss, k,
+                               sel_slack, keep_all_rows, scores, out_ids, status, qstatus, ws, ws_bytes, stream, 16);
+}
+extern "C" size_t rc_adc_scan_image_rows16_bytes(int64_t N, int M) {
+    if (!adc_cf_supported(M) || N < 0) return 0;
+    return (size_t)((N + 15) / 16 * 16) * M;
+}
+// host-side description of that image (no GPU involved): byte offset of codes[n][m], or -1
+extern "C" int64_t rc_adc_scan_image_rows16_at(int M, int64_t n, int m) {
+    if (!adc_cf_supported(M) || n < 0 || m < 0 || m >= M) return -1;
+    const int p16 = m / 16;
+    for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < 4; ++j)
+            if (adc_q16_slot((int)(n & 15) + 16 * g, j) == m % 16) return ivfs16_image_at(M, n, p16, g, j);
+    return -1;
+}
+extern "C" int rc_adc_scan_image_rows16(rc_handle_t h, const uint8_t* codes, int64_t n0, int64_t n, int M, uint8_t* image,
+                                        rc_stream_t stream) {
+    rc_device_guard device_guard_(h);
+    if (!h || !codes || !image || n0 < 0 || n < 0) return RC_EINVAL;
+    if (!adc_cf_supported(M)) return RC_ESHAPE;
+    if (n == 0) return RC_OK;
+    int64_t blocks = (n * M + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(ivfs16_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, codes, n0, n, M, image);
+    RC_LAUNCH_CHECK(h);
+    return RC_OK;
 }

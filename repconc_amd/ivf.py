@@ -15,6 +15,7 @@ Rows are stored list-major: `codes` [N,M] sorted by cell, `list_off` [nlist+1], 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
@@ -95,6 +96,7 @@ class IVFPQIndex:
         self.codes = torch.empty((0, M), dtype=torch.uint8, device=self.device)
         self.ids = torch.empty((0,), dtype=torch.int64, device=self.device)
         self.image = None            # permuted copy of `codes` for the conflict-free screen (list-centric search)
+        self.image16 = None          # ... for its 16-query form (built on first use: whole-query-set calls at nprobe >= ~16)
         self.list_off = torch.zeros((nlist + 1,), dtype=torch.int64, device=self.device)
         self.ntotal = 0
         self._sizes_desc = np.zeros(0, np.int64)      # cell sizes, descending (host copy; set_lists fills it)
@@ -125,6 +127,7 @@ class IVFPQIndex:
         self.ntotal = codes.shape[0]
         self._sizes_desc = np.sort(cnt.cpu().numpy())[::-1].astype(np.int64)     # host copy: bounds the sample array
         self.image = None
+        self.image16 = None
         if ops.adc_image_supported(self.M) and self.ntotal:
             self.image = torch.empty((ops.adc_image_rows_bytes(self.ntotal, self.M),), dtype=torch.uint8, device=self.device)
             ops.adc_scan_image_(self.codes, self.image, layout="rows")        # blocked by chunks of 16 rows: cells start anywhere
@@ -166,9 +169,12 @@ class IVFPQIndex:
         out.nprobe = self.nprobe
         if self.image is not None:                      # the permutation of row n depends on n mod 16 only: copy, not rebuild
             out.image = self.image.to(device)
+        if self.image16 is not None:
+            out.image16 = self.image16.to(device)
         if device == self.device:                       # same device (virtual replica in the tests): real copies
             out.codes, out.ids, out.list_off = out.codes.clone(), out.ids.clone(), out.list_off.clone()
             out.image = None if out.image is None else out.image.clone()
+            out.image16 = None if out.image16 is None else out.image16.clone()
             out.coarse = None if out.coarse is None else out.coarse.clone()
         return out
 
@@ -198,8 +204,10 @@ class IVFPQIndex:
 
     def search(self, x, k: int, nprobe: Optional[int] = None, method: str = "auto"):
         """nprobe: cells probed per query (default: the index's `nprobe` attribute, as with a Faiss IVF index).
-        method: "lists" = list-centric 8-bit screen (rc_ivf_search_lists: the queries probing a cell share its read,
-        M in {16,32,48,64,96}); "scan" = the per-query exact scan (rc_ivf_search); "auto" = lists where available.
+        method: "lists" = list-centric 8-bit screen (rc_ivf_search_probes_q / _q16: the queries probing a cell share its read,
+        M in {16,32,48,64,96}; tasks of 8 or — when a probed cell is shared by >= WIDE_MIN_SHARE queries of the call — 16
+        queries; "lists8" / "lists16" force the width); "scan" = the per-query exact scan (rc_ivf_search); "auto" = lists
+        where available.
         Both return the same (scores, ids)."""
         as_numpy = not isinstance(x, torch.Tensor)
         q = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if as_numpy else x).to(self.device, torch.float32)
@@ -213,16 +221,18 @@ class IVFPQIndex:
             return (scores.cpu().numpy(), ids.cpu().numpy()) if as_numpy else (scores, ids)
         nprobe = min(int(nprobe), self.nlist)
         probes = self.probe(q, nprobe, ordered=False)
-        if method not in ("auto", "lists", "lists_host_plan", "scan"):
-            raise ValueError("method must be auto|lists|lists_host_plan|scan")
-        if method in ("lists", "lists_host_plan") and self.image is None:
+        if method not in ("auto", "lists", "lists8", "lists16", "lists_host_plan", "scan"):
+            raise ValueError("method must be auto|lists|lists8|lists16|lists_host_plan|scan")
+        if method in ("lists", "lists8", "lists16", "lists_host_plan") and self.image is None:
             raise _lib.RepconcHipError(f"the list-centric search needs M in (16, 32, 48, 64, 96), not {self.M}")
         if method == "auto" and self.image is not None:
             # few probed rows per query: the per-query scan has less fixed work (task list, per-query byte tables)
             method = "lists" if self.ntotal * nprobe / max(self.nlist, 1) * self.M >= self.LISTS_MIN_BYTES else "scan"
-        if method in ("lists", "lists_host_plan") and nq > 0:
-            fn = self._search_lists if method == "lists" else self._search_lists_host_plan
-            scores, ids = fn(q, probes, int(k), nprobe)
+        if method in ("lists", "lists8", "lists16", "lists_host_plan") and nq > 0:
+            if method == "lists_host_plan":
+                scores, ids = self._search_lists_host_plan(q, probes, int(k), nprobe)
+            else:      # "lists": the screen's width by the call's queries per probed cell; lists8 / lists16 force it
+                scores, ids = self._search_lists(q, probes, int(k), nprobe, width={"lists8": 8, "lists16": 16}.get(method))
             return (scores.cpu().numpy(), ids.cpu().numpy()) if as_numpy else (scores, ids)
         sizes = (self.list_off[1:] - self.list_off[:-1])[probes.long()]                      # [nq, nprobe]
         csum = torch.cumsum(sizes, 1)
@@ -290,10 +300,30 @@ class IVFPQIndex:
             ss *= 2
         return ss
 
+    # queries of a call per probed cell (nq x nprobe / nlist) from which the 16-query screen is used: below it most tasks would
+    # hold <= 8 queries and pay the 16-query form's two table phases per 32 sub-quantisers for nothing.  [MI355X] M = 96, 8.84 M
+    # rows in 5000 cells, ms per search 8-query -> 16-query (profiles/r06f_ivf_width_bench.txt): 6 980 queries, nprobe 8 / 32 /
+    # 128 (11 / 45 / 179 queries per cell): 3.32 -> 3.15, 5.06 -> 4.94, 8.95 -> 8.54; 1 200 queries (1.9 / 7.7 / 31): 0.83 ->
+    # 0.88, 1.11 -> 1.10, 1.81 -> 1.66
+    WIDE_MIN_SHARE = 9.0
+
+    def _wide_image(self):
+        if self.image16 is None:
+            self.image16 = torch.empty((ops.adc_image_rows_bytes(self.ntotal, self.M),), dtype=torch.uint8, device=self.device)
+            ops.adc_scan_image_(self.codes, self.image16, layout="rows16")
+        return self.image16
+
     def _search_lists(self, q: torch.Tensor, probes: torch.Tensor, k: int, nprobe: int, sel_slack: float = 6.0,
-                      max_retries: int = 3):
-        """rc_ivf_search_probes: sample layout, ranks and the (cell, <= 8 queries) task list are made on the device."""
+                      max_retries: int = 3, width: Optional[int] = None):
+        """rc_ivf_search_probes_q / _q16: sample layout, ranks and the (cell, <= 8 | 16 queries) task list are made on the
+        device.  width: 8, 16 or None = by the mean number of the call's queries per probed cell (WIDE_MIN_SHARE)."""
         dev, nq = self.device, q.shape[0]
+        if width is None:
+            env = os.environ.get("RC_IVF_WIDTH")
+            width = int(env) if env in ("8", "16") else (16 if nq * nprobe / max(self.nlist, 1) >= self.WIDE_MIN_SHARE else 8)
+        if width not in (8, 16):
+            raise ValueError("width must be 8 or 16")
+        image = self._wide_image() if width == 16 else self.image
         ss = self._sample_step(nprobe)
         top = self._sizes_desc[:nprobe]                                    # the nprobe largest cells bound a query's sample
         sstride = max(4, int((16 * (top // (16 * ss)) + np.minimum(top % (16 * ss), 16)).sum()))
@@ -311,10 +341,10 @@ class IVFPQIndex:
         for attempt in range(max_retries + 1):
             if attempt:
                 flags.zero_()
-            _lib.check(lib.rc_ivf_search_probes_q(h, p(self.codes), p(self.image), p(self.list_off), p(self.ids), self.ntotal,
-                                                  self.nlist, self.M, 256, p(lut), nq, p(probes), nprobe, sstride, ss, int(k),
-                                                  slack, self.KEEP_ALL_ROWS, p(scores), p(ids), p(status), p(qstatus), p(ws),
-                                                  wsb, s), "rc_ivf_search_probes_q", h)
+            fn = lib.rc_ivf_search_probes_q16 if width == 16 else lib.rc_ivf_search_probes_q
+            _lib.check(fn(h, p(self.codes), p(image), p(self.list_off), p(self.ids), self.ntotal, self.nlist, self.M, 256, p(lut),
+                          nq, p(probes), nprobe, sstride, ss, int(k), slack, self.KEEP_ALL_ROWS, p(scores), p(ids), p(status),
+                          p(qstatus), p(ws), wsb, s), "rc_ivf_search_probes_q16" if width == 16 else "rc_ivf_search_probes_q", h)
             st = int(status.item())
             if st == 0:
                 return scores, ids

@@ -635,26 +635,31 @@ def adc_image_rows_at(M: int, n: int, m: int) -> int:
     return int(_lib.load().rc_adc_scan_image_rows_at(int(M), int(n), int(m)))
 
 
+def adc_image_rows16_at(M: int, n: int, m: int) -> int:
+    """Byte offset of codes[n][m] in the image of the 16-query IVF screen (layout "rows16"; host-side description)."""
+    return int(_lib.load().rc_adc_scan_image_rows16_at(int(M), int(n), int(m)))
+
+
 def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Optional[int] = None,
                     layout: str = "flat") -> torch.Tensor:
     """(Re)build rows [n0, n0+n) of the permuted code image of an index: codes uint8 [>=n0+n, M] contiguous; image a
     contiguous uint8 buffer of at least adc_image_bytes(n0+n, M) bytes (layout "flat": what `adc_search` takes — row-major
     for M in {16,32,48,64}, tile-blocked for M = 96) or adc_image_rows_bytes(n0+n, M) bytes (layout "rows": what the
     list-centric IVF search takes, blocked by chunks of 16 rows; `adc_image_rows_at(M, n, m)` is the byte offset of
-    codes[n][m] in it).  See include/repconc_hip.h rc_adc_scan_image."""
+    codes[n][m] in it; layout "rows16": the image of its 16-query screen, same size, `adc_image_rows16_at`).  See include/repconc_hip.h rc_adc_scan_image."""
     _need_cuda(codes, image)
     if codes.dtype != torch.uint8 or image.dtype != torch.uint8 or not codes.is_contiguous() or not image.is_contiguous():
         raise ValueError("codes and image must be contiguous uint8")
-    if layout not in ("flat", "rows"):
-        raise ValueError("layout must be flat|rows")
+    if layout not in ("flat", "rows", "rows16"):
+        raise ValueError("layout must be flat|rows|rows16")
     M = codes.shape[1]
     if n is None:
         n = codes.shape[0] - n0
-    need = adc_image_bytes(n0 + n, M) if layout == "flat" else adc_image_rows_bytes(n0 + n, M)
+    need = adc_image_bytes(n0 + n, M) if layout == "flat" else adc_image_rows_bytes(n0 + n, M)   # rows16: the same size as rows
     if n0 < 0 or n < 0 or n0 + n > codes.shape[0] or adc_image_row_bytes(M) == 0 or image.numel() < need:
         raise ValueError("row range outside the code / image buffers")
     lib, h, s, _ = _ctx(codes)
-    fn = lib.rc_adc_scan_image if layout == "flat" else lib.rc_adc_scan_image_rows
+    fn = {"flat": lib.rc_adc_scan_image, "rows": lib.rc_adc_scan_image_rows, "rows16": lib.rc_adc_scan_image_rows16}[layout]
     _lib.check(fn(h, _p(codes), int(n0), int(n), M, _p(image), s), "rc_adc_scan_image", h)
     return image
 

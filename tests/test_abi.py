@@ -89,6 +89,18 @@ def test_adc_conflict_free_layout_properties():
     for MM in (16, 32, 48, 64, 96):
         at = sorted(lib.rc_adc_scan_image_rows_at(MM, n, m) for n in range(16, 48) for m in range(MM))
         assert at == list(range(16 * MM, 48 * MM)) and lib.rc_adc_scan_image_rows_at(MM, 0, MM) == -1
+        # ... and of the 16-query IVF screen's image (round 6): a bijection onto the chunk's bytes, phase p16 = m / 16 in its own
+        # 256-byte block, the four bytes of a lane = the sub-quantisers its four gather steps read (rc_adc_q16_describe)
+        at16 = sorted(lib.rc_adc_scan_image_rows16_at(MM, n, m) for n in range(16, 48) for m in range(MM))
+        assert at16 == list(range(16 * MM, 48 * MM)) and lib.rc_adc_scan_image_rows16_at(MM, 0, MM) == -1
+        slot = C.c_int(0)
+        for n in (16, 21, 31):
+            for m in range(MM):
+                off = lib.rc_adc_scan_image_rows16_at(MM, n, m) - 16 * MM
+                p16, lane, j = off // 256, (off % 256) // 4, off % 4
+                assert p16 == m // 16 and lane % 16 == n % 16
+                lib.rc_adc_q16_describe(48, lane, j, C.byref(slot))
+                assert slot.value == m % 16
     assert lib.rc_adc_scan_image_bytes(1000, 96) == 32768 * 96 and lib.rc_adc_scan_image_bytes(40000, 96) == 2 * 32768 * 96
     for MM in (16, 32, 48, 64):
         q16 = lib.rc_adc_q16_describe(MM, 0, 0, C.byref(slot))

@@ -444,6 +444,10 @@ def test_ivf_baseline_size_properties():
                                           ivf.coarse.cpu().numpy(), k, nprobe)
     assert np.array_equal(i1[:4].cpu().numpy(), want_i)
     assert np.array_equal(s1[:4].cpu().numpy().view(np.uint32), want_s.view(np.uint32))
+    # both widths of the screen at this size
+    for method in ("lists8", "lists16"):
+        sw, iw = ivf.search(q, k, nprobe, method=method)
+        assert torch.equal(iw, i2) and torch.equal(sw, s2), method
 
 
 # ------------------------------------------------------------------------------------------- model API
@@ -2097,6 +2101,48 @@ def test_ivf_list_centric_search_equals_per_query_scan(M):
         s3, i3 = ivf.search(q, k, nprobe, method="lists_host_plan")       # plan spelled out in torch (rc_ivf_search_lists)
         assert torch.equal(i1, i2) and torch.equal(s1, s2), (M, nprobe)
         assert torch.equal(i3, i2) and torch.equal(s3, s2), (M, nprobe)
+
+
+@pytest.mark.parametrize("M", [16, 32, 48, 64, 96])
+def test_ivf_sixteen_query_screen_equals_the_scan_and_the_oracle(M):
+    """Round 6: the 16-QUERY list-centric screen (rc_ivf_search_probes_q16, ivfs_screen16.h: tasks of up to 16 queries, tables
+    [code][16 slots][16 queries] in phases of 16 sub-quantisers, ds_read_b128 gathers, its own image) against the per-query
+    exact scan and the 8-query screen — ids and score bits — on skewed cells (cells of several rounds, cells smaller than a
+    chunk, empty cells), with more queries per cell than a task holds (several tasks per cell, a ragged last one) and fewer
+    (empty columns), for every M the screen supports; and against the oracle's brute force on the first queries.  The image
+    itself is checked against the library's host-side description (image[at(n, m)] == codes[n][m])."""
+    from repconc_amd import ops
+    from repconc_amd.ivf import IVFPQIndex
+    N, nlist, nq = 150000, 40, 83
+    rng = np.random.default_rng(9100 + M)
+    codes = synth.uniform_codes(9101 + M, N, M)
+    cells = np.minimum((rng.pareto(1.1, N) * 2).astype(np.int64), nlist - 1)      # heavy head (tens of thousands of rows), empty tail
+    cells[rng.integers(0, N, 5)] = nlist - 2                                       # a cell of a handful of rows
+    C = synth.gaussian(9102 + M, (M, 256, 768 // M))
+    coarse = synth.gaussian(9103 + M, (nlist, 768))
+    ivf = IVFPQIndex(768, M, nlist, device=DEV)
+    ivf.set_centroids(_t(C))
+    ivf.coarse = _t(coarse)
+    ivf.set_lists(_t(codes), _t(cells))
+    img = ivf._wide_image().cpu().numpy()
+    lm = ivf.codes.cpu().numpy()
+    rows = np.concatenate([np.arange(0, 64), rng.integers(0, N, 200), np.arange(N - 33, N)])
+    at = np.array([[ops.adc_image_rows16_at(M, int(n), m) for m in range(M)] for n in rows], dtype=np.int64)
+    assert np.array_equal(img[at], lm[rows])
+    q = synth.gaussian(9104 + M, (nq, 768))
+    for nprobe, k in ((2, 10), (9, 300), (nlist, 1000)):
+        s16, i16 = ivf.search(_t(q), k, nprobe, method="lists16")
+        s8, i8 = ivf.search(_t(q), k, nprobe, method="lists8")
+        sc, ic = ivf.search(_t(q), k, nprobe, method="scan")
+        assert torch.equal(i16, ic) and torch.equal(s16, sc), (M, nprobe)
+        assert torch.equal(i8, ic) and torch.equal(s8, sc), (M, nprobe)
+    ws, wi = pq_oracle.ivf_search(q[:6], C, codes, cells, coarse, 300, 9)
+    s16, i16 = ivf.search(_t(q[:6]), 300, 9, method="lists16")               # 6 queries: ten empty columns in every task
+    assert np.array_equal(i16.cpu().numpy(), wi) and np.array_equal(s16.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    # "lists" picks the width by the call's queries per probed cell
+    assert 8 < ivf.WIDE_MIN_SHARE < 18
+    s_auto, i_auto = ivf.search(_t(q), 300, 9, method="lists")               # 83 x 9 / 40 = 18.7 queries per cell: the 16-query screen
+    assert torch.equal(i_auto, ivf.search(_t(q), 300, 9, method="scan")[1])
 
 
 def test_batch_search_hands_a_list_centric_index_every_query_at_once():
