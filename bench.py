@@ -810,7 +810,7 @@ def main():
                 float(torch.stack([torch.isin(a_[i], b_[i]).float().mean() for i in range(0, a_.shape[0], 7)]).mean())
         mrr_flat = mrr10(f_ids)
         sweep3_all, retrieval = {}, {}
-        for nprobe in (8, 32, 128, 512):
+        for nprobe in (8, 32, 128, 512, 2048):
             ivf.search(q_dev, k, nprobe)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -867,20 +867,23 @@ def main():
                                            "unit": "GB/s", "frac": round((1 << 18) * D * 4 / cu_ms / 1e6 / HBM_PEAK_GBS, 4)},
                               "note": "centroid update of one Lloyd iteration of the coarse quantiser, 4 D bytes per row; the "
                                       "whole rc_ivf_coarse_update call (4 kernels), HIP events around 5 calls"},
-            "roofline": {"kernel": "ivfs_screen_kernel<96, 4> (list-centric: one persistent block per CU walks (cell, <= 8 probing "
-                                   "queries) tasks; 64 KiB table phases of 32 sub-quantisers in two LDS buffers, four loader waves fetch and "
-                                   "byte-transpose the next phase's tables into the other buffer while twelve waves gather; conflict-free "
-                                   "ds_read_b64 gathers + i8 MFMA accumulation; survivors to per-wave streams); nprobe < 6 takes "
-                                   "the per-query scan",
+            "roofline": {"kernel": "ivfs_screen16_kernel<96, 4> (round 6; list-centric: one persistent block per CU walks (cell, <= 16 probing "
+                                   "queries) tasks; 64 KiB table phases of 16 sub-quantisers x 16 queries in two LDS buffers, four loader "
+                                   "waves request a phase one stage ahead and byte-transpose it into the other buffer while twelve waves "
+                                   "gather; conflict-free ds_read_b128 gathers + i8 MFMA accumulation; survivors to per-wave streams); "
+                                   "calls with fewer than 9 queries per probed cell run the 8-query form (ivfs_screen_kernel, "
+                                   "ds_read_b64), nprobe < 6 the per-query scan",
                          "bound": "lds-gather", "achieved": round(ivf_gather, 1), "peak": round(256 * 256 * 2.4, 1),
                          "unit": "GB/s", "frac": round(ivf_gather / (256 * 256 * 2.4), 4),
                          "screen_kernel_ms": round(ivf_scan_ms, 3), "nprobe": 128,
-                         "note": "nprobe = 128, the screen kernel alone (HIP events): one table byte per (probed row, "
-                                 "sub-quantiser, query) - an 8-byte entry per task of 8 queries - against the nominal "
-                                 "conflict-free ds_read_b64 rate (256 CUs x 256 B/clk x 2.4 GHz).  The 8-query gather engine "
-                                 "itself runs at ~6 cycles per gather (issue/latency, DESIGN_HISTORY 4.2), i.e. 1/3 of that rate; a task "
-                                 "also moves 192 KiB of tables (3.8 GB per 1200-query batch from the memory-side cache) and the "
-                                 "sixteen waves of a block meet at one barrier per table phase",
+                         "probed_rows_per_query": round(rows128, 1),
+                         "note": "nprobe = 128, 1200-query call, the screen kernel alone (HIP events): one table byte per (probed row, "
+                                 "sub-quantiser, query) against the nominal conflict-free gather rate (256 CUs x 256 B/clk x 2.4 "
+                                 "GHz).  The LDS pipe also takes the tables: a task of 16 queries writes 16 x 96 x 256 B = 384 KiB "
+                                 "(ds_write_b128, ~80 B/clk) for ~1770 rows x 96 x 16 B of gathers - 4.9 k of every 17.6 k LDS cycles "
+                                 "of a task are table stores -, and the sixteen waves of a block meet at one barrier per 64 KiB phase "
+                                 "(six per task): gathers + stores at their nominal rates are 0.4 of the measured time "
+                                 "(DESIGN.md 4.7)",
                          "whole_search_equivalent_code_GBs": round(nq_batch * rows128 * M3 / t128 / 1e9, 1)}}
         del ivf, flat3, q_dev, centers3
         torch.cuda.empty_cache()

@@ -35,7 +35,7 @@ forms = [
     ("stand-alone, two chains (RC_DIST_SPLIT=1)", {SOLO: "1", "RC_DIST_SPLIT": "1"}),
     ("one chain, fused exchange, wait in the prologue", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "0"}),
     ("one chain, fused exchange, flag-wait kernel", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "0", "RC_DIST_SPLIT": "0"}),
-    ("two chains, fused exchange, wait in the prologue", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "1"}),
+    ("two chains, fused exchange (round 6: two chains always use the flag-wait kernels)", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_INWAIT": "1", "RC_DIST_SPLIT": "1"}),
     ("one chain, push + wait kernel (rounds 3-4)", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_XSWEEP": "0", "RC_DIST_SPLIT": "0"}),
     ("two chains, push + wait kernels (rounds 3-4)", {"RC_DIST_FORCE_COLL": "1", "RC_IPC_XSWEEP": "0", "RC_DIST_SPLIT": "1"}),
 ]
