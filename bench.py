@@ -885,7 +885,43 @@ def main():
                                  "(six per task): gathers + stores at their nominal rates are 0.4 of the measured time "
                                  "(DESIGN.md 4.7)",
                          "whole_search_equivalent_code_GBs": round(nq_batch * rows128 * M3 / t128 / 1e9, 1)}}
-        del ivf, flat3, q_dev, centers3
+        del ivf, flat3, centers3
+        torch.cuda.empty_cache()
+        # ---- the scan-rate reference of rounds 2-5, kept for comparability: the same sizes with uniformly random codes in
+        # uniformly filled cells and Gaussian queries (no retrieval quality to speak of: top-10 overlap with flat = nprobe / nlist)
+        gu = torch.Generator(device=dev).manual_seed(20227)
+        ivf_u = IVFPQIndex(D, M3, nlist, device=dev)
+        ivf_u.set_centroids(torch.randn((M3, K, D // M3), device=dev, generator=gu))
+        ivf_u.coarse = torch.randn((nlist, D), device=dev, generator=gu)
+        codes_u = torch.randint(0, 256, (N_CORPUS, M3), dtype=torch.uint8, device=dev, generator=gu)
+        ivf_u.set_lists(codes_u, torch.randint(0, nlist, (N_CORPUS,), device=dev, generator=gu))
+        del codes_u
+        q_u = torch.randn((nq_dev, D), device=dev, generator=gu)
+        uni_all, uni_1200 = {}, {}
+        for nprobe in (8, 32, 128):
+            for qs_, dst in ((q_u, uni_all), (q_u[:nq_batch], uni_1200)):
+                ivf_u.search(qs_, k, nprobe)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    ivf_u.search(qs_, k, nprobe)
+                torch.cuda.synchronize()
+                dst[f"nprobe{nprobe}"] = round(3 * qs_.shape[0] / (time.perf_counter() - t0), 1)
+        lib.rc_profile_enable(h, 1)
+        ivf_u.search(q_u[:nq_batch], k, 128)
+        torch.cuda.synchronize()
+        lib.rc_profile_enable(h, 0)
+        lib.rc_profile_collect(h, _lib.PROF_ADC_SCAN, ctypes.byref(n_l), ctypes.byref(ms_l))
+        u_ms = ms_l.value / max(n_l.value, 1)
+        u_rows = N_CORPUS * 128 / nlist
+        u_gather = nq_batch * u_rows * M3 / (u_ms * 1e-3) / 1e9 if n_l.value else 0.0
+        out["ivf"]["uniform_cells"] = {
+            "index": f"{N_CORPUS} x {M3} B uniform codes in {nlist} uniformly filled cells (the IVF leg of rounds 2-5)",
+            "queries_per_sec": uni_all, "queries_per_call": nq_dev, "queries_per_sec_1200_query_calls": uni_1200,
+            "roofline": {"bound": "lds-gather", "achieved": round(u_gather, 1), "peak": round(256 * 256 * 2.4, 1), "unit": "GB/s",
+                         "frac": round(u_gather / (256 * 256 * 2.4), 4), "screen_kernel_ms": round(u_ms, 3), "nprobe": 128,
+                         "note": "the screen kernel of a 1200-query call at nprobe 128, same definition as rounds 3-5 (0.164 in round 5)"}}
+        del ivf_u, q_u, q_dev
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ index-build leg (nearest codes, a-1/a-5)
@@ -1243,32 +1279,33 @@ def _valu_bound(rows, M, K, measured_ms):
 
 
 def _headline2(out):
-    """Compact summary of the legs beyond the constrained assignment, placed last in the JSON line."""
+    """Compact summary (< 1000 characters) of the legs beyond the constrained assignment, placed LAST in the JSON line so that a
+    2000-character tail of the output keeps it whole; the full objects are `adc`, `ivf`, `index_build`, `kmeans_stats`."""
     h = {}
     a = out.get("adc")
     if a:
         rf = a.get("roofline", {})
-        h.update({"metric": "adc_queries_per_sec", "value": a.get("value"), "unit": "queries/s",
-                  "config": f"8841823 x 48 B flat ADC, {a.get('query_batch')}-query batches, k={a.get('k')}",
-                  "screen_kernel_ms": rf.get("avg_launch_ms"), "screen_frac_of_lds_gather_roof": rf.get("frac"),
-                  "frac_note": "1 table byte per (row, sub-quantiser, query) against 256 CUs x 256 B/clk x 2.4 GHz; against SURVEY "
-                               "8d's 4 B per lookup the same kernel is at 4 x this fraction (8-bit screen + exact rescoring)",
-                  "ids_equal_cpu_port": a.get("gpu_ids_identical"), "score_bits_equal_cpu_port": a.get("gpu_score_bits_identical"),
-                  "checked": a.get("checked_against_cpu_port"),
-                  "index_built_codes_qps": (a.get("index_built_codes") or {}).get("value"),
-                  "cpu_port_qps": (a.get("cpu_baseline") or {}).get("value"), "cpu_cores": (a.get("cpu_baseline") or {}).get("cores")})
+        h.update({"adc_queries_per_sec": a.get("value"), "adc_config": f"8841823x48B flat, {a.get('query_batch')}-query batches, k={a.get('k')}",
+                  "adc_screen_ms": rf.get("avg_launch_ms"), "adc_screen_frac_lds_gather_roof": rf.get("frac"),
+                  "adc_ids_equal_cpu_port": a.get("gpu_ids_identical"), "adc_score_bits_equal_cpu_port": a.get("gpu_score_bits_identical"),
+                  "adc_index_built_codes_qps": (a.get("index_built_codes") or {}).get("value"),
+                  "adc_cpu_port_qps": (a.get("cpu_baseline") or {}).get("value")})
     v = out.get("ivf")
     if v:
-        h["ivf_m96_nlist5000"] = {"queries_per_sec": v.get("queries_per_sec"), "retrieval": v.get("retrieval_summary"),
-                                  "screen_frac": (v.get("roofline") or {}).get("frac")}
+        rs = v.get("retrieval_summary") or {}
+        h["ivf_m96_nlist5000_qps"] = v.get("queries_per_sec")
+        h["ivf_mrr10"] = rs.get("mrr_at_10")
+        h["ivf_mrr10_flat"] = rs.get("mrr_at_10_flat")
+        h["ivf_nprobe_within_0.001_of_flat"] = rs.get("smallest_nprobe_with_mrr_within_0.001_of_flat")
+        h["ivf_screen_frac"] = {"retrieval_index": (v.get("roofline") or {}).get("frac"),
+                                "uniform_cells": ((v.get("uniform_cells") or {}).get("roofline") or {}).get("frac")}
     b = out.get("index_build")
     if b:
         h["index_build_vectors_per_sec"] = b.get("value")
-        h["index_build_frac"] = {"hbm": (b.get("roofline") or {}).get("frac"),
-                                 "valu_issue": ((b.get("roofline") or {}).get("valu_issue_bound") or {}).get("frac")}
+        h["index_build_frac_valu_issue"] = ((b.get("roofline") or {}).get("valu_issue_bound") or {}).get("frac")
     km = out.get("kmeans_stats")
     if km:
-        h["kmeans_stats_frac"] = km.get("summary_frac") or (km.get("roofline") or {}).get("frac")
+        h["kmeans_stats_frac"] = (km.get("roofline") or {}).get("frac")
     return h
 
 

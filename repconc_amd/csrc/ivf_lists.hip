@@ -52,6 +52,11 @@
 #ifndef IVFS_PRIO
 #define IVFS_PRIO 1
 #endif
+#ifndef IVFS_PREFETCH_CODES
+#define IVFS_PREFETCH_CODES 0   // 1: the 8-query screen requests the next stage's codes before its gathers, as the 16-query screen does.
+                                // Twenty registers per set instead of ten: 128 VGPRs + spills, 4.74 -> 5.34 ms per 6 980-query search at
+                                // nprobe 128 (profiles/r06i_ivf8_prefetch_ab.txt): off.
+#endif
 __host__ __device__ constexpr int ivfs_phases(int M) { return (M + 31) / 32; }
 __host__ __device__ constexpr int ivfs_pm(int M, int p) { return (M - 32 * p) >= 32 ? 32 : 16; }
 
@@ -633,6 +638,20 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
                         // (LW = 0) the next tables are requested now and transposed after this stage's gathers
                         if (LW == 0 && has_next) load_tables(PMn{}, PN, nd, dd);
                         const int reff = chunks_of(cur.nrows, rd);
+                        if constexpr (LW > 0 && IVFS_PREFETCH_CODES) {
+                            // round 6 (from the 16-query screen): the codes of the NEXT stage are requested BEFORE this stage's
+                            // gathers into a second register set and copied over afterwards — a stage used to begin by waiting
+                            // 0.7-1 us for codes requested after the previous stage's last gather
+                            unsigned wn[R][2];
+                            if (has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, wn);
+                            gathers(PMc{}, P == 0, w, bufoff, reff);
+                            IVFS_TSTAMP(1);
+                            if constexpr (LASTP) epilogue(cur.t0, cur.row_lo, cur.nrows, rd, tq, myq, reff);
+                            if (has_next) {
+#pragma unroll
+                                for (int c = 0; c < R; ++c) { w[c][0] = wn[c][0]; w[c][1] = wn[c][1]; }
+                            }
+                        } else {
                         gathers(PMc{}, P == 0, w, bufoff, reff);
                         IVFS_TSTAMP(1);
                         // the codes of the next stage go into the registers the gathers just released (last phase: after the
@@ -641,6 +660,7 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen_kernel(const uint
                         if constexpr (LASTP) {
                             epilogue(cur.t0, cur.row_lo, cur.nrows, rd, tq, myq, reff);
                             if (has_next) load_codes(PMn{}, PN, nd.t0, nd.nrows, nrd, w);
+                        }
                         }
                         if (LW == 0 && has_next) write_tables(PMn{}, dd, bufoff ^ (unsigned)IVFS_BUF);
                     }
