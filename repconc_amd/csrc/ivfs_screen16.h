@@ -35,6 +35,22 @@ __global__ __launch_bounds__(256) void ivfs16_image_kernel(const uint8_t* __rest
     }
 }
 
+// Development aid (tools/ivf16_timeline.py builds a variant library with -DRC_IVF_TRACE): wall-clock stamps of every wave at
+// three points of each of a block's first 64 stages.  Off in the shipped library.
+#ifdef RC_IVF_TRACE
+__device__ unsigned long long ivfs16_trace[256 * 64 * 16 * 4];
+extern "C" int rc_debug_ivfs16_trace(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ivfs16_trace), sizeof(ivfs16_trace));
+}
+#define IVFS16_TSTAMP(stage, i)                                                                                          \
+    do {                                                                                                                 \
+        if (l == 0 && (stage) < 64u && blockIdx.x < 256u)                                                                 \
+            ivfs16_trace[((blockIdx.x * 64u + (stage)) * 16u + (unsigned)wv) * 4u + (i)] = wall_clock64();               \
+    } while (0)
+#else
+#define IVFS16_TSTAMP(stage, i) do { } while (0)
+#endif
+
 struct ivfs_task16 {
     int valid;
     int qs, qc;               // the task's queries: sorted_q[qs .. qs + qc), 1 <= qc <= 16
@@ -133,6 +149,44 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen16_kernel(const ui
                     e[gq] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);      // queries 4 gq .. 4 gq + 3 of entry (c, 4 u + i)
                 }
                 *reinterpret_cast<adc_u32x4s*>(smem + (bufoff + item * 64u + i * 16u)) = e;
+            }
+        }
+    };
+    // The loader waves' form (256 threads): thread = code c, all four quads in ONE 16-byte load per query — 16 load instructions per
+    // thread and phase instead of 64.  The wall-clock trace (tools/ivf16_timeline.py, profiles/r06j_ivf16_timeline.txt) showed the
+    // loader waves as the stage's critical path: 1.3 us transposing and storing + 1.5 us ISSUING the 64 dword requests of the next
+    // phase, against 2.2-2.5 us of gathers + hand-over.  The price: a thread's sixteen entries are one whole 256-byte row, so the
+    // eight lanes of a store group can only be spread over FOUR distinct 16-byte slots (rotation l & 3 of the entry inside its quad):
+    // two-way bank conflicts on the 16 stores, 256 instead of 128 LDS cycles per wave and phase.
+    // (Requesting the phase in two 8-byte halves — the half just stored frees its registers for the same half of the phase after
+    // next, so the first request leaves a quarter into the loader's stage — was built and is SLOWER: 32 load instructions per
+    // thread cost the loader 1.2-1.4 us of issue against 0.6 for 16, 6.6 ms against 4.1 per 6 980-query search at nprobe 128
+    // (profiles/r06j_ivf16_timeline_half_sets.txt).  The loader waves stay the stage's critical path at ~2.9 us in the traced build:
+    // ~0.8 us waiting for the phase requested at the end of the previous stage, 1.1 us transposing and storing, 0.6 us requesting.)
+    typedef unsigned adc_u32x4l __attribute__((ext_vector_type(4)));
+    auto fill_load4 = [&](int p16, const unsigned (&so)[16], unsigned c, adc_u32x4l (&a)[16]) {
+        const int y = p16 >> 1, hh = p16 & 1;
+        const unsigned PM = (unsigned)ivfs_pm(M, y);
+        const unsigned voff = (unsigned)(RC_K * 32 * y) + c * PM + 16u * (unsigned)hh;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, voff, so[j], 0);
+    };
+    auto fill_store4 = [&](unsigned bufoff, unsigned c, const adc_u32x4l (&a)[16]) {
+        const unsigned rot4 = (unsigned)l & 3u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned i = ((unsigned)j + rot4) & 3u;
+                const unsigned sel = ((4u + i) << 8) | i;
+                adc_u32x4s e;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const unsigned p01 = __builtin_amdgcn_perm(a[4 * gq + 1][u], a[4 * gq][u], sel);
+                    const unsigned p23 = __builtin_amdgcn_perm(a[4 * gq + 3][u], a[4 * gq + 2][u], sel);
+                    e[gq] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                }
+                *reinterpret_cast<adc_u32x4s*>(smem + (bufoff + c * 256u + (unsigned)(4 * u) * 16u + i * 16u)) = e;
             }
         }
     };
@@ -276,8 +330,7 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen16_kernel(const ui
     // ---- loader waves: their own walk over the stages, two stages ahead with the requests, one with the stores.  Exactly one
     // barrier per stage, as the gathering waves.
     if (wv >= GW) {                                           // wave-uniform
-        using NL = std::integral_constant<unsigned, (unsigned)(LW * 64)>;
-        constexpr int ITEMS = 1024 / (LW * 64);
+        static_assert(LW * 64 == RC_K, "one loader thread per code");
         const unsigned lt = tid - (unsigned)(GW * 64);
         struct pos { ivfs_task16 d; unsigned k; int rd, P; };
         auto next = [&](const pos& p) {
@@ -289,22 +342,28 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen16_kernel(const ui
             }
             return n;
         };
-        unsigned so[16], a[ITEMS][16];
+        unsigned so[16];
+        adc_u32x4l a[16];
         unsigned so_k = 0xFFFFFFFFu;                          // the task `so` belongs to
         auto request = [&](const pos& p) {
             if (p.k != so_k) { task_offsets(p.d, so); so_k = p.k; }
-            fill_load(NL{}, p.P, so, lt, a);
+            fill_load4(p.P, so, lt, a);
         };
         pos p1 = next(pos{first, 0u, 0, 0});                   // the stage AFTER the one that is about to run
         if (p1.d.valid) request(p1);
         unsigned bufoff = (unsigned)IVFS_BUF;                   // where p1's tables go
+        unsigned sidx = 0;
         for (;;) {
             block_sync();                                     // a stage begins: everybody is done with the other buffer
+            IVFS16_TSTAMP(sidx, 0);
             if (!p1.d.valid) break;
-            fill_store(NL{}, bufoff, lt, a);
+            fill_store4(bufoff, lt, a);
+            IVFS16_TSTAMP(sidx, 1);
             p1 = next(p1);
             if (p1.d.valid) request(p1);
+            IVFS16_TSTAMP(sidx, 2);
             bufoff ^= (unsigned)IVFS_BUF;
+            ++sidx;
         }
         return;                                               // (its stream stays empty: stream_cnt was cleared by the host)
     }
@@ -319,6 +378,8 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen16_kernel(const ui
             load_codes(0, cur.t0, cur.nrows, 0, w);
         }
         unsigned k = 0;
+        unsigned sidx = 0;                                    // stage counter (trace builds only)
+        (void)sidx;
         for (;;) {                                            // tasks of this block
             const ivfs_task16 nxt = load_task(k + 1);
             const int nrounds = rounds_of(cur);
@@ -329,6 +390,7 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen16_kernel(const ui
                     constexpr bool LASTP = (P == NPH - 1);
                     constexpr int PN = LASTP ? 0 : P + 1;     // phase of the next stage
                     block_sync();
+                    IVFS16_TSTAMP(sidx, 0);
                     const bool to_next = LASTP && !more;      // block-uniform
                     const bool has_next = !to_next || nxt.valid;
                     const ivfs_task16 nd = to_next ? nxt : cur;
@@ -341,11 +403,14 @@ __global__ __launch_bounds__(IVFS_THREADS, 4) void ivfs_screen16_kernel(const ui
                         unsigned wn[R];
                         if (has_next) load_codes(PN, nd.t0, nd.nrows, nrd, wn);
                         gathers(P == 0, w, reff);
+                        IVFS16_TSTAMP(sidx, 1);
                         if constexpr (LASTP) epilogue(cur.t0, cur.row_lo, cur.nrows, rd, tq, myq, reff);
                         if (has_next) {
 #pragma unroll
                             for (int c = 0; c < R; ++c) w[c] = wn[c];
                         }
+                        IVFS16_TSTAMP(sidx, 2);
+                        ++sidx;
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) off[j] ^= (unsigned)IVFS_BUF;     // the other table buffer (64 KiB-aligned bases)
