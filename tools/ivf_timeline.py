@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave timeline of the pipelined IVF screen (development tool, GPU box): builds a variant of the library with
--DRC_IVF_TRACE (wall-clock stamps at the stage boundaries, csrc/adc_search.hip), runs the BASELINE configs[3] shape at
+-DRC_IVF_TRACE (wall-clock stamps at the stage boundaries of the 8-QUERY screen, csrc/ivf_lists.hip; the 16-query
+screen has tools/ivf16_timeline.py), runs the BASELINE configs[3] shape at
 nprobe = argv[1] (default 128) and prints, per table phase, what the gathering and the loader waves spend where.
     python tools/ivf_timeline.py [nprobe]"""
 import ctypes
@@ -17,9 +18,9 @@ VAR = os.path.join(LIBDIR, "librepconc_hip_trace.so")
 def build_variant():
     from repconc_amd import build as b
     b.build(verbose=False)
-    obj = os.path.join(LIBDIR, "adc_search_trace.o")
-    subprocess.run([b._hipcc(), *b.FLAGS, "-DRC_IVF_TRACE", "-c", os.path.join(b.CSRC, "adc_search.hip"), "-o", obj], check=True)
-    objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES if s != "adc_search.hip"] + [obj]
+    obj = os.path.join(LIBDIR, "ivf_lists_trace.o")
+    subprocess.run([b._hipcc(), *b.FLAGS, "-DRC_IVF_TRACE", "-c", os.path.join(b.CSRC, "ivf_lists.hip"), "-o", obj], check=True)
+    objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES if s != "ivf_lists.hip"] + [obj]
     subprocess.run([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", VAR], check=True)
 
 
@@ -43,7 +44,7 @@ ivf.coarse = torch.randn(nlist, 768, device=dev, generator=g)
 ivf.set_lists(torch.randint(0, 256, (N, M), dtype=torch.uint8, device=dev, generator=g), torch.randint(0, nlist, (N,), device=dev, generator=g))
 q = torch.randn(nq, 768, device=dev, generator=g)
 for _ in range(3):
-    ivf.search(q, k, nprobe, method="lists")
+    ivf.search(q, k, nprobe, method="lists8")
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = np.zeros(256 * 8 * 3 * 16 * 4, dtype=np.uint64)
