@@ -38,6 +38,8 @@ class PQIndex:
         self.is_trained = False
         self.ntotal = 0
         self.id_offset = 0       # global id of local row 0 (row-sharded indexes)
+        self.sel_slack = ops.ADC_SEL_SLACK    # head-room of the sampled candidate threshold, in standard deviations of the rank
+        self.last_search = None
         self._centroids = torch.zeros((M, 256, d // M), dtype=torch.float32, device=self.device)
         self._codes = torch.empty((0, M), dtype=torch.uint8, device=self.device)
         # permuted copy of the codes streamed by the conflict-free ADC screen (csrc/adc_search.hip), kept in step
@@ -107,7 +109,8 @@ class PQIndex:
         q = q.to(self.device, torch.float32, non_blocking=True)
         # prefixes of the row-major buffers are contiguous views: nothing is copied
         pending = ops.adc_search(self._codes[: self.ntotal], self._centroids, q, int(k), id_offset=self.id_offset,
-                                 scan_image=self._image, defer=True, stats=stats)
+                                 scan_image=self._image, defer=True, stats=stats, sel_slack=self.sel_slack)
+        self.last_search = pending           # its .stats say how many queries had to be repeated / answered by the exact path
 
         def finish():
             scores, ids = pending.result()

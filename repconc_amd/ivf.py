@@ -287,6 +287,11 @@ class IVFPQIndex:
 
     # ---- list-centric search
     SAMPLE_STEP = 8                 # every 8th (up to every 64th) row of a probed cell is scored exactly ...
+    # head-room of the sampled threshold (standard deviations of the sample rank; ops.ADC_SEL_SLACK).  Round 6: 6 -> 4.  A query's
+    # sample is ~1/32 of its probed rows (mu = 31 at k = 1000): at 4 no query of 41 880 was answered again by the scan and a 6 980-query
+    # search takes 3.04 / 4.72 / 8.15 ms at nprobe 8 / 32 / 128 instead of 3.23 / 4.82 / 8.32; at 3 a handful are (4-8 of 41 880) and the
+    # extra launches cost more than the smaller lists save (profiles/r06m_ivf_slack.txt)
+    SEL_SLACK = 4.0
     SAMPLE_ROWS = 6144              # ... so that about this many sampled rows per query place the candidate threshold
     CAND_CAP = 16384                # candidate keys per query (ADC_CAND_CAP)
     KEEP_ALL_ROWS = 4096            # queries probing no more rows than this re-score every row (no threshold)
@@ -313,7 +318,7 @@ class IVFPQIndex:
             ops.adc_scan_image_(self.codes, self.image16, layout="rows16")
         return self.image16
 
-    def _search_lists(self, q: torch.Tensor, probes: torch.Tensor, k: int, nprobe: int, sel_slack: float = 6.0,
+    def _search_lists(self, q: torch.Tensor, probes: torch.Tensor, k: int, nprobe: int, sel_slack: Optional[float] = None,
                       max_retries: int = 3, width: Optional[int] = None):
         """rc_ivf_search_probes_q / _q16: sample layout, ranks and the (cell, <= 8 | 16 queries) task list are made on the
         device.  width: 8, 16 or None = by the mean number of the call's queries per probed cell (WIDE_MIN_SHARE)."""
@@ -337,7 +342,7 @@ class IVFPQIndex:
         flags = torch.zeros((1 + nq,), dtype=torch.int32, device=dev)     # [status | per-query status]: one fill
         status, qstatus = flags[:1], flags[1:]
         p = lambda t: C.c_void_p(t.data_ptr())
-        slack = float(sel_slack)
+        slack = float(self.SEL_SLACK if sel_slack is None else sel_slack)
         for attempt in range(max_retries + 1):
             if attempt:
                 flags.zero_()

@@ -665,6 +665,13 @@ def adc_scan_image_(codes: torch.Tensor, image: torch.Tensor, n0: int = 0, n: Op
 
 
 SEARCH_SCREEN_M = frozenset((8, 12, 16, 24, 32, 48, 64, 96))      # widths of the screened flat search (csrc/adc_search.hip)
+# Default head-room of the sampled candidate threshold: the threshold is the r-th best score of the 32 768-row sample,
+# r = floor(mu + slack sqrt(mu + 1) + 4) + 1 with mu = k S / N expected top-k rows in the sample (rc_adc_search_q).  A query whose
+# sample holds MORE than r - 1 of the true top-k keeps too few candidates and is repeated alone (~1 ms, PendingSearch).  Round 6:
+# 6 -> 3.  At k = 1000 over 8.84 M rows (mu = 3.7, r = 22 -> 15) the chance of that is 8e-6 per query instead of 1e-10 — one repeated
+# query per ~100 batches of 1200 — and the screen keeps 6.3 k rows per query instead of 8.7 k, the rescoring 4.0 k instead of 5.7 k:
+# 147.4 -> 154.2 k queries/s; slack 2 (1e-4 per query: 3 of 28 800 repeated) is not faster (profiles/r06m_adc_slack.txt).
+ADC_SEL_SLACK = 3.0
 _warned_slow_m = set()
 
 
@@ -752,7 +759,7 @@ def adc_search_exact(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tens
 
 
 def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k: int, id_offset: int = 0,
-               sel_slack: float = 6.0, max_retries: int = 2, scan_image: Optional[torch.Tensor] = None,
+               sel_slack: Optional[float] = None, max_retries: int = 2, scan_image: Optional[torch.Tensor] = None,
                defer: bool = False, stats: Optional[dict] = None):
     """Top-k inner-product ADC search of `q` [nq,D] against uint8 `codes` [N,M].
     Returns (scores [nq,k] fp32, ids [nq,k] int64), sorted (score desc, id asc).
@@ -763,6 +770,8 @@ def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k:
     the 8-bit screen / that the exact rescoring kept in the FIRST pass (rc_adc_search_ws_counts).
     Never raises on degenerate index content: see `PendingSearch`."""
     _need_cuda(codes, centroids, q, scan_image)
+    if sel_slack is None:
+        sel_slack = ADC_SEL_SLACK
     if codes.dtype != torch.uint8 or not codes.is_contiguous():
         raise ValueError("index codes must be contiguous uint8 [N, M]")
     if scan_image is not None and (scan_image.dtype != torch.uint8 or not scan_image.is_contiguous()
