@@ -343,6 +343,7 @@ class IVFPQIndex:
         status, qstatus = flags[:1], flags[1:]
         p = lambda t: C.c_void_p(t.data_ptr())
         slack = float(self.SEL_SLACK if sel_slack is None else sel_slack)
+        ops._warm_retry_ops(dev)          # the framework operators of the per-query repeat path, once per device
         for attempt in range(max_retries + 1):
             if attempt:
                 flags.zero_()

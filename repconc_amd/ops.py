@@ -726,6 +726,34 @@ class PendingSearch:
         return self._scores, self._ids
 
 
+_retry_ops_warm = set()
+
+
+def _warm_retry_ops(dev):
+    """The torch operators of the retry path (`PendingSearch.result`, `rerun`: nonzero, mask / index selection, index_put,
+    cat) once per device, on eight elements.  A framework operator's first use on a device loads its code object — measured: the
+    FIRST repeated query of a process cost 300 ms, every later one ~1 ms (profiles/r06m_adc_retry_cost.txt).  With the threshold's
+    head-room at 3 standard deviations a 6 980-query evaluation repeats a query with a probability of 5 %: that load belongs to
+    the first search of the process, not to a random batch in the middle of an evaluation."""
+    key = (dev.type, dev.index)
+    if key in _retry_ops_warm:
+        return
+    _retry_ops_warm.add(key)
+    qs = torch.tensor([0, 1, 0, 2, 0, 0, 1, 0], dtype=torch.int32, device=dev)
+    sc = torch.zeros((8, 4), dtype=torch.float32, device=dev)
+    ii = torch.zeros((8, 4), dtype=torch.int64, device=dev)
+    bad = torch.nonzero(qs).flatten()
+    bits = qs[bad]
+    for sel in ((bits & 1) != 0, (bits & 1) == 0):
+        idx = bad[sel]
+        part = sc[idx].contiguous()
+        ok = qs[idx] == 1
+        sc[idx[ok]] = part[ok]
+        ii[idx[ok]] = ii[idx][ok]
+        torch.cat([idx[~ok], idx[ok]])
+    torch.cat([bad, bad])
+
+
 class _nullcontext:
     def __enter__(self):
         return None
@@ -833,6 +861,7 @@ def adc_search(codes: torch.Tensor, centroids: torch.Tensor, q: torch.Tensor, k:
         _, qs = launch(qq, slack, s_, i_)
         return s_, i_, qs
 
+    _warm_retry_ops(q.device)
     status, qstatus = launch(q, float(sel_slack), scores, ids)
     pending = PendingSearch(rerun, scores, ids, status, qstatus, float(sel_slack), max_retries,
                             stream=torch.cuda.current_stream(dev))
