@@ -292,7 +292,12 @@ class IVFPQIndex:
     # search takes 3.04 / 4.72 / 8.15 ms at nprobe 8 / 32 / 128 instead of 3.23 / 4.82 / 8.32; at 3 a handful are (4-8 of 41 880) and the
     # extra launches cost more than the smaller lists save (profiles/r06m_ivf_slack.txt)
     SEL_SLACK = 4.0
-    SAMPLE_ROWS = 6144              # ... so that about this many sampled rows per query place the candidate threshold
+    # ... so that about this many sampled rows per query place the candidate threshold.  Round 6: 6144 -> 1536 — the exact fp32 scoring
+    # of the sample (random 4-byte LDS gathers, two thirds of their cycles bank conflicts) was 1.24 of the 8.9 ms of a 6 980-query search
+    # at nprobe 128; a quarter of the sample costs a few hundred more candidates per query and wins: ms per 6 980-query search at
+    # nprobe 32 / 128: 4.71 -> 4.13, 8.32 -> 7.87; 1 200 queries: 1.08 -> 0.99, 1.59 -> 1.52; no query answered again by the scan
+    # (profiles/r06m_ivf_sample_rows.txt)
+    SAMPLE_ROWS = 1536
     CAND_CAP = 16384                # candidate keys per query (ADC_CAND_CAP)
     KEEP_ALL_ROWS = 4096            # queries probing no more rows than this re-score every row (no threshold)
     MAX_QUERY_BATCH = 16384         # queries per C call (rc_ivf_search_lists / _probes refuse more than 32768)
@@ -344,6 +349,12 @@ class IVFPQIndex:
         p = lambda t: C.c_void_p(t.data_ptr())
         slack = float(self.SEL_SLACK if sel_slack is None else sel_slack)
         ops._warm_retry_ops(dev)          # the framework operators of the per-query repeat path, once per device
+        if not getattr(self, "_scan_path_warm", False):
+            # ... and the path that answers a flagged query (the per-query scan), once per index on one query: its first use in a
+            # process cost ~100 ms of operator loading in the middle of a search (profiles/r06m_ivf_sample_rows.txt, first line of
+            # nprobe 128), every later one well under a millisecond
+            self._scan_path_warm = True
+            self.search(q[:1], min(int(k), 16), nprobe, method="scan")
         for attempt in range(max_retries + 1):
             if attempt:
                 flags.zero_()
