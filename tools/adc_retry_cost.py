@@ -1,4 +1,5 @@
-"""What a repeated query of the flat search costs (development tool, GPU; round 6): sel_slack 2 provokes repeats; per batch the\nenqueue / result times of the batches that repeated a query, then the same repeat in isolation."""
+"""What a repeated query of the flat search costs (development tool, GPU; round 6): sel_slack 2 provokes repeats; per batch the
+enqueue / result times of the batches that repeated a query, then the same repeat in isolation."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from repconc_amd.index import PQIndex

@@ -1,4 +1,5 @@
-"""IVF: size of the per-query sample that places the candidate threshold (development tool, GPU; round 6): ms per search for\nSAMPLE_ROWS in (12288, 6144, 3072, 1536), 6 980- and 1 200-query calls, nprobe 8 / 32 / 128."""
+"""IVF: size of the per-query sample that places the candidate threshold (development tool, GPU; round 6): ms per search for
+SAMPLE_ROWS in (12288, 6144, 3072, 1536), 6 980- and 1 200-query calls, nprobe 8 / 32 / 128."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from repconc_amd.ivf import IVFPQIndex
