@@ -552,9 +552,14 @@ def main():
         barrier()
         lib.rc_profile_enable(h, 1)
         t0 = time.perf_counter()
-        pending = [search(bi) for bi in range(args.adc_batches)]     # as batch_search: every batch enqueued, then read
-        for fin in pending:
+        pending = []
+        for bi in range(args.adc_batches):                           # as batch_search: every batch enqueued, then read
+            pending.append((search(bi), index.last_search))
+        adc_repeated = adc_exact = 0
+        for fin, pend_ in pending:
             sc, ids = fin()
+            adc_repeated += pend_.stats["retried_queries"]
+            adc_exact += pend_.stats["exact_queries"]
         barrier()
         adt = max_over_ranks(time.perf_counter() - t0)
         lib.rc_profile_enable(h, 0)
@@ -572,6 +577,8 @@ def main():
             "metric": "adc_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "k": k,
             "index": f"{N_CORPUS} x {M} B uint8 uniform codes, resident", "query_batch": nq_batch,
             "batches": args.adc_batches, "ms_per_batch": round(adt / args.adc_batches * 1e3, 2),
+            "threshold_head_room_sigmas": ops.ADC_SEL_SLACK,
+            "queries_repeated_alone": adc_repeated, "queries_answered_by_the_exact_path": adc_exact,
             "parallelism": f"index replicated, queries split x{world}",
             "parity": "ids and score bits equal the repo's C restatement of Faiss IndexPQ search (tests); Faiss itself is "
                       "not available offline: Faiss-side tie order / last-ulp LUT rounding unpinned",
