@@ -1007,24 +1007,10 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             if (more_in_flight) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
         };
-        auto fold = [&](int c, adc_u32x4v (&e)[4], bool more_in_flight) {
-            (void)more_in_flight;
+        auto fold = [&](int c, const adc_u32x4v (&e)[4]) {
             if constexpr (!PACK) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-#ifdef ADC_EXP_WAIT1            // A/B: every MFMA waits for its own gather only (lgkmcnt counts down one at a time)
-                    if (more_in_flight) {
-                        if (j == 0) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(e[0]));
-                        else if (j == 1) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(e[1]));
-                        else if (j == 2) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(e[2]));
-                        else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[3]));
-                    } else {
-                        if (j == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(e[0]));
-                        else if (j == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[1]));
-                        else if (j == 2) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(e[2]));
-                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[3]));
-                    }
-#endif
                     const adc_i32x4v a = {(int)e[j][0], (int)e[j][1], (int)e[j][2], (int)e[j][3]};
                     acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bsel, acc[c], 0, 0, 0);
                 }
@@ -1076,9 +1062,7 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
             // of chunks c - 2 .. c + 1 are used up, so the same chunks' codes of the step after next go there.  No extra
             // registers, and the phase change no longer waits for a load issued at the start of the step it ends:
             // 7.95 -> 7.62 ms per 1200 queries at M = 48 (M = 96: -3 %; M = 32, which has no phase change: unchanged).
-#ifndef ADC_EXP_NOLOAD          // A/B timing only: the step's codes are reused for every later step
             if ((c & 3) == 2 && it + 2 < nsteps) w[c >> 2] = load_quad(it + 2, c >> 2);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (LATE) {
                 // Round 6.  The survivor test of a round used to follow its last MFMAs directly: every wave then sat through the
@@ -1102,17 +1086,13 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-#ifndef ADC_EXP_WAIT1
             gather_wait(ea, true);
-#endif
-            fold(c, ea, true);
+            fold(c, ea);
             __builtin_amdgcn_sched_barrier(0);
             if (c + 2 < R) gather(c + 2, ea);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef ADC_EXP_WAIT1
             gather_wait(eb, c + 2 < R);
-#endif
-            fold(c + 1, eb, c + 2 < R);
+            fold(c + 1, eb);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!PACK && !LATE) {

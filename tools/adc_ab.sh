@@ -2,11 +2,12 @@
 # Round 6: A/B timing of the 16-query ADC screen under structural switches (development tool, GPU).
 #   build here (no GPU):  tools/adc_ab.sh build         -> build/var/ab_<name>.so  (travels with gpurun)
 #   on the GPU box:       tools/adc_ab.sh run [M ...]   -> one table per library (tools/adc_quick_bench.py)
-# Variants whose switches change RESULTS (nosurv, noload) are timing probes only; the others are complete kernels.
+# nosurv changes RESULTS (a timing probe of the kernel without its survivor path); the others are complete kernels.
+# (Round 6 also timed per-gather waits and a kernel without its code loads: no gain / slower, profiles/r06a_adc_ab.txt; removed.)
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
-names=(nosurv noload wait1 w12r12 w12r8 w8r16 pack12)
-flags=("-DADC_EXP_NOSURV" "-DADC_EXP_NOLOAD" "-DADC_EXP_WAIT1"
+names=(nosurv late0 w12r12 w12r8 w8r16 pack12)
+flags=("-DADC_EXP_NOSURV" "-DADC_Q16_LATE_TEST=0"
        "-DADC_Q16_WAVES=12 -DADC_Q16_R=12 -DADC_Q16_TILE=32256" "-DADC_Q16_WAVES=12 -DADC_Q16_R=8 -DADC_Q16_TILE=30720"
        "-DADC_Q16_WAVES=8 -DADC_Q16_R=16" "-DADC_Q16_PACK=1 -DADC_Q16_R=12 -DADC_Q16_TILE=30720")
 if [ "$1" == "build" ]; then
