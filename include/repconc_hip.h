@@ -287,7 +287,10 @@ int rc_kmeans_split_empty(rc_handle_t h, float* C, const int64_t* counts, int M,
  * score when fewer than k rows exist.  status_host semantics are reported through `status`
  * (device int, caller zeroes): bit0 = some query collected fewer than k candidates,
  * bit1 = candidate buffer overflowed; the host retries with another `sel_slack` (see
- * repconc_amd.index).  ws: rc_adc_search_ws_bytes(N, M, K, nq, k) bytes. */
+ * repconc_amd.index).  sel_slack: head-room of the sampled candidate threshold in standard deviations of the sample rank —
+ * the threshold is the r-th best of 32768 exactly scored sample rows, r = floor(mu + sel_slack sqrt(mu + 1) + 4) + 1,
+ * mu = k 32768 / N; the Python wrapper passes 3 (repconc_amd.ops.ADC_SEL_SLACK: 8e-6 repeated queries per query at k = 1000
+ * over 8.84 M rows); larger = fewer repeats, more rows screened in.  ws: rc_adc_search_ws_bytes(N, M, K, nq, k) bytes. */
 size_t rc_adc_search_ws_bytes(int64_t N, int M, int K, int nq, int k);
 int rc_adc_search(rc_handle_t h, const uint8_t* codes, int64_t N, int M, int K, const float* C,
                   int D, const float* q, int nq, int k, int64_t id_offset, double sel_slack,
@@ -423,7 +426,7 @@ int rc_ivf_search_lists(rc_handle_t h, const uint8_t* codes, const uint8_t* imag
 /* The same search with the plan made on the device: sample layout, threshold ranks and the task list are derived from
  * `probes` by four small kernels (no host round trip).  probes [nq,nprobe]: distinct cells per query, nprobe <= nlist;
  * sstride: capacity of a query's sample array, >= the largest possible number of sampled rows of nprobe cells;
- * sel_slack: standard deviations of head-room in the threshold rank (6 is the default of the Python wrapper);
+ * sel_slack: standard deviations of head-room in the threshold rank (the Python wrapper passes 4: IVFPQIndex.SEL_SLACK);
  * keep_all_rows: queries probing no more rows than this re-score every probed row.  Status bits and results as above.
  * ws: rc_ivf_search_probes_ws_bytes(M, nq, nprobe, nlist, sstride). */
 /* Probe selection for the calls below: per query the nprobe cells with the largest coarse score (scores [nq,nlist] fp32,
