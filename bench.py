@@ -666,9 +666,13 @@ def main():
             index_b.search_async(q_all[:nq_batch], k)()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            pend_b = [index_b.search_async(q_all[bi * nq_batch:(bi + 1) * nq_batch], k) for bi in range(args.adc_batches)]
-            for fin in pend_b:
+            pend_b = []
+            for bi in range(args.adc_batches):
+                pend_b.append((index_b.search_async(q_all[bi * nq_batch:(bi + 1) * nq_batch], k), index_b.last_search))
+            rep_b = 0
+            for fin, pb_ in pend_b:
                 fin()
+                rep_b += pb_.stats["retried_queries"]
             torch.cuda.synchronize()
             bdt_ = time.perf_counter() - t0
             st_b = {}
@@ -678,7 +682,7 @@ def main():
                 "ms_per_batch": round(bdt_ / args.adc_batches * 1e3, 2),
                 "index": f"{N_CORPUS} x {M} B: nearest codes of clustered synthetic embeddings (512 Gaussian clusters) against "
                          "Lloyd-refined centroids, built on this GPU (SURVEY 8d-C)",
-                "screen_survivors_per_query": _count_stats(st_b),
+                "screen_survivors_per_query": _count_stats(st_b), "queries_repeated_alone": rep_b,
                 "code_histogram_sub_quantiser_0": {"max_over_mean": round(float(hist0.max() / hist0.mean()), 3),
                                                    "empty_codes": int((hist0 == 0).sum())},
                 "corpus_build": {"rows": N_CORPUS, "assignment_s": round(build_ms * 1e-3, 4),
