@@ -829,14 +829,14 @@ __global__ __launch_bounds__(ADC_Q16_WAVES * 64) void adc_screen_q16_kernel(cons
     const int r = l & 15, g = l >> 4;
     const unsigned xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3;
     unsigned group, btile;
-    if (groups >= 8) {                                        // XCD x owns the groups == x (mod 8), every tile
-        const unsigned gpx = (unsigned)(groups + 7) / 8u;     // groups per XCD
+    if (!(flags & 2)) {                                       // XCD x owns the groups == x (mod 8), every tile: the XCD's ~10
+        const unsigned gpx = (unsigned)(groups + 7) / 8u;     // groups' tables stay in its L2, a tile is read once per XCD
         group = (jx % gpx) * 8u + xcd;
         btile = jx / gpx;
         if (group >= (unsigned)groups) return;                // block-uniform
-    } else {                                                  // few queries (JPQ steps, validation): every XCD takes all the
-        group = jx % (unsigned)groups;                        // groups (their tables fit any L2) and the tiles == x (mod 8)
-        btile = (jx / (unsigned)groups) * 8u + xcd;
+    } else {                                                  // few queries (JPQ steps, validation): every XCD takes ALL the
+        group = jx % (unsigned)groups;                        // groups (their tables fit its L2) and the tiles == x (mod 8): the
+        btile = (jx / (unsigned)groups) * 8u + xcd;           // image is read ONCE from HBM instead of once per XCD
         if ((int64_t)btile * TILE >= N) return;
     }
     const int q0 = (int)group * 16;
@@ -1308,10 +1308,19 @@ static int adc_launch_scans(rc_handle_t h, const uint8_t* codes, const uint8_t* 
             RC_HIP_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
             const unsigned tiles16 = (unsigned)((N + ADC_Q16_TILE - 1) / ADC_Q16_TILE);
             const unsigned gpx = (unsigned)(groups + 7) / 8u;
-            const unsigned nblocks = groups >= 8 ? 8u * gpx * tiles16 : 8u * (unsigned)groups * ((tiles16 + 7u) / 8u);
+            // block -> (group, tile).  Many groups: XCD x owns the groups == x (mod 8) and walks every tile — each XCD streams the
+            // whole image (8 x N M bytes from HBM per launch: nothing beside 1200 queries' gathers).  Few groups (round 6): with
+            // 8 groups that traffic IS the launch (3.4 GB per 128-query search: 1.04 ms where 8 / 75 of a full launch is 0.78), so
+            // while all the groups' tables fit an XCD's L2 (groups x M / 16 x 64 KiB <= 4 MiB) the TILES are dealt to the XCDs and
+            // every XCD takes all groups: the image is read once.  [MI355X] ms per search, k = 200, M = 48: 128 queries 1.27 -> 1.15,
+            // 256: 1.91 -> 1.80, 384: 2.71 -> 2.63, 512: 3.30 -> 3.34 (not used there); M = 32 / 96 at 128 queries: 1.02 -> 0.94,
+            // 2.20 -> 2.04 (profiles/r06s_adc_small_batches.txt).
+            const int by_tiles_max = rc_env_int("RC_ADC_Q16_TILESPLIT_GROUPS", 64 / (M / 16));
+            const bool by_tiles = groups < 8 || groups <= by_tiles_max;
+            const unsigned nblocks = !by_tiles ? 8u * gpx * tiles16 : 8u * (unsigned)groups * ((tiles16 + 7u) / 8u);
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             hipLaunchKernelGGL(kern, dim3(nblocks), dim3(TH), sl, s, image, N, b.qlut, b.tint, nq, groups, b.idcnt, b.ids,
-                               rc_env_int("RC_ADC_Q16_PRIO", 1));
+                               (rc_env_int("RC_ADC_Q16_PRIO", 1) ? 1 : 0) | (by_tiles ? 2 : 0));
             rc_prof_mark(h, RC_PROF_ADC_SCAN, s);
             RC_LAUNCH_CHECK(h);
         }
