@@ -121,3 +121,19 @@ def test_numeric_defaults_quoted_in_the_header_match_the_code():
     for name, dflt in quoted:
         assert name in code, f"{name}: quoted in the header, not read by any source through rc_env_int"
         assert code[name] == {int(dflt)}, f"{name}: header says {dflt}, the sources use {sorted(code[name])}"
+
+
+def test_search_threshold_defaults_and_the_retry_warm_up_run_without_a_gpu():
+    """Round 6: the head-room of the sampled candidate thresholds (flat 3, IVF 4 standard deviations of the sample rank — the
+    values the header and INTEGRATION.md quote) and the warm-up of the retry path's framework operators, which must be a no-op
+    the second time and run on any device type."""
+    import torch
+    from repconc_amd import ops
+    from repconc_amd.ivf import IVFPQIndex
+    assert ops.ADC_SEL_SLACK == 3.0 and IVFPQIndex.SEL_SLACK == 4.0 and IVFPQIndex.SAMPLE_ROWS == 1536
+    hdr = open(os.path.join(ROOT, "include", "repconc_hip.h")).read()
+    assert "the Python wrapper passes 3 (repconc_amd.ops.ADC_SEL_SLACK" in hdr and "the Python wrapper passes 4: IVFPQIndex.SEL_SLACK" in hdr
+    ops._retry_ops_warm.discard(("cpu", None))
+    ops._warm_retry_ops(torch.device("cpu"))
+    assert ("cpu", None) in ops._retry_ops_warm
+    ops._warm_retry_ops(torch.device("cpu"))
