@@ -25,7 +25,7 @@ from . import _lib, ops
 from .index import PQIndex
 
 
-def coarse_kmeans(x: torch.Tensor, nlist: int, iters: int = 10, seed: int = 1234, chunk: int = 1 << 16) -> torch.Tensor:
+def coarse_kmeans(x: torch.Tensor, nlist: int, iters: int = 10, seed: int = 1234, chunk: int = 1 << 20) -> torch.Tensor:
     """Lloyd k-means of `nlist` centroids on x [n, D] (device): assignment by the fp32-MFMA GEMM + argmin kernel
     (rc_ivf_coarse_assign), centroid update by rc_ivf_coarse_update (stable counting sort of the rows by cell, one block per
     cell sums its rows in ascending order in fp64; an empty cell takes a counter-based random row) — nothing is read back
