@@ -148,7 +148,7 @@ def test_in_place_centroid_write_reaches_every_part_of_a_multi_index(mode):
     assert np.array_equal(faiss.vector_to_array(multi.pq.centroids), C2.ravel())
 
 
-@pytest.mark.parametrize("method", ["lists", "scan"])
+@pytest.mark.parametrize("method", ["lists", "lists8", "lists16", "scan"])
 def test_ivf_search_never_raises_on_degenerate_cells(method):
     """IVF cells full of identical rows (duplicated passages): the list-centric screen and the per-query scan both hand
     over to the exact path instead of raising; answers equal the brute-force oracle (score desc, corpus id asc)."""
@@ -191,10 +191,11 @@ def test_ivf_pipelined_screen_on_cells_of_several_rounds(M):
     ivf.set_lists(_t(codes), _t(cells))
     for nq, nprobe in ((3, 2), (19, 5), (70, nlist)):
         q = synth.gaussian(4104 + M + nq, (nq, 768))
-        s, i = ivf.search(_t(q), k, nprobe, method="lists")
         ws, wi = pq_oracle.ivf_search(q, C, codes, cells, coarse, k, nprobe)
-        assert np.array_equal(i.cpu().numpy(), wi), (M, nq, nprobe)
-        assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+        for method in ("lists8", "lists16"):                 # both widths of the screen (round 6)
+            s, i = ivf.search(_t(q), k, nprobe, method=method)
+            assert np.array_equal(i.cpu().numpy(), wi), (M, nq, nprobe, method)
+            assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
 
 
 def test_ivf_survivor_stream_overflow_is_answered_not_raised(monkeypatch):
@@ -215,9 +216,10 @@ def test_ivf_survivor_stream_overflow_is_answered_not_raised(monkeypatch):
     ivf.coarse = _t(coarse)
     ivf.set_lists(_t(codes), _t(cells))
     monkeypatch.setenv("RC_IVF_STREAM_CAP", "16")
-    s, i = ivf.search(_t(q), k, nprobe, method="lists")
     ws, wi = pq_oracle.ivf_search(q, C, codes, cells, coarse, k, nprobe)
-    assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    for method in ("lists8", "lists16"):
+        s, i = ivf.search(_t(q), k, nprobe, method=method)
+        assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32)), method
 
 
 def test_ivf_list_search_equals_the_per_query_scan_in_a_fresh_process(tmp_path):
