@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-opq", action="store_true",
                     help="skip the OPQ / PQ training leg (profiling runs: its many small launches of the assignment "
                          "kernels would dilute the per-kernel means of the index-build leg)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the live rocprofv3 --pmc passes of roofline.traffic (profiling runs: bench.py is then already under "
+                         "rocprofv3); the figure of profiles/pmc_summary.json is reported instead")
     ap.add_argument("--no-per-rank", action="store_true",
                     help="skip the per_rank_6144 leg (profiling runs: its launches of the sweep kernel would mix into "
                          "the per-kernel averages of the timed 49152-row configuration)")
@@ -75,6 +78,47 @@ def pmc_traffic(kernel):
         return json.load(open(p))[kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
+
+
+def measure_sweep_traffic(B):
+    """HBM bytes per launch of the dominant kernel MEASURED BY THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE — the
+    two do not fit one pass; counters only, never combined with a trace domain other than the kernel trace, as MI355X_MICROARCH.md's
+    HBM section prescribes) over tools/sweep_traffic_child.py, which solves one batch of this run's shape twice with eager launches.
+    FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (the guide's gfx950 correction).  None if rocprofv3 is missing or a pass
+    fails — the line then keeps the figure of profiles/pmc_summary.json and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    child = os.path.join(ROOT, "tools", "sweep_traffic_child.py")
+    means, launches = {}, None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        work = tempfile.mkdtemp(prefix="rc_pmc_")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", work, "-o", "p", "--",
+                                sys.executable, child, str(B)], cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(work, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and "sk_sweep2_kernel<2, true" in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            means[counter], launches = sum(vals) / len(vals), len(vals)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    return {"bytes_per_launch": int(2 * means["FETCH_SIZE"] * 1024 + means["WRITE_SIZE"] * 1024), "launches": launches,
+            "fetch_size_kib": round(means["FETCH_SIZE"], 1), "write_size_kib": round(means["WRITE_SIZE"], 1)}
 
 
 def spawn_ranks(args) -> int:
@@ -1248,6 +1292,20 @@ def main():
                 "value": round(3 / adt_1, 3), "unit": "queries/s", "cores": 1, "kind": "port",
                 "sample": f"3 queries over the whole index on one thread ({adt_1:.1f} s) - the reference's eval default "
                           "threads=1"}
+
+    # ------------------------------------------------------------------ roofline.traffic measured by THIS run (N = 1)
+    under_profiler = any("rocprof" in os.environ.get(v_, "") for v_ in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES"))   # no nesting
+    if world == 1 and not args.no_traffic and B == B_GLOBAL and not under_profiler:
+        torch.cuda.empty_cache()
+        live = measure_sweep_traffic(B)
+        if live is not None:
+            out["roofline"]["traffic"] = live["bytes_per_launch"]
+            out["roofline"]["traffic_source"] = (
+                f"measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each, --kernel-trace only) over "
+                f"tools/sweep_traffic_child.py ({live['launches']} launches of sk_sweep2_kernel<2, true>; FETCH_SIZE {live['fetch_size_kib']} KiB "
+                f"doubled per the gfx950 note + WRITE_SIZE {live['write_size_kib']} KiB); profiles/pmc_summary.json of an earlier "
+                f"profiled run says {pmc_traffic('sk_sweep_kernel')}")
+            out["roofline"]["traffic_over_algorithmic"] = round(live["bytes_per_launch"] / out["roofline"]["algorithmic_bytes_per_launch"], 4)
 
     if use_dist:
         try:

@@ -7,10 +7,10 @@ cd $ROOT
 python -m pytest tests -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -15 > $O/${TAG}_pytest_gpu.txt
 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- python $ROOT/bench.py --steps 3 --no-cpu --no-per-rank --no-opq > $O/bench_prof.out 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- python $ROOT/bench.py --steps 3 --no-cpu --no-per-rank --no-opq --no-traffic > $O/bench_prof.out 2>&1)
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats_bench_steps3.csv
 grep -h "^{\"metric\"" $O/bench_prof.out > $O/${TAG}_bench_under_rocprof.json   # the bench line of the PROFILED run (its HIP-event average must match the CSV)
-tools/pmc_collect.sh $O/${TAG}_pmc_counters_raw.json -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-per-rank --no-opq --adc-batches 1 > $O/pmc.out 2>&1
+tools/pmc_collect.sh $O/${TAG}_pmc_counters_raw.json -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-per-rank --no-opq --no-traffic --adc-batches 1 > $O/pmc.out 2>&1
 tools/pmc_collect.sh $O/${TAG}_pmc_kmeans_raw.json -- python $ROOT/tools/kmeans_one.py 48 > $O/pmc_km.out 2>&1
 python tools/pmc_summary.py $O/${TAG}_pmc_counters_raw.json $O/pmc_summary.json "MI355X, round ${TAG:2:1}, profile $TAG." $O/${TAG}_pmc_kmeans_raw.json >> $O/pmc.out 2>&1
 python tools/config_bench.py 2>&1 | grep constrained > $O/${TAG}_config_bench.txt
